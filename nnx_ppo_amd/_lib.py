@@ -1,0 +1,95 @@
+"""ctypes binding of libmippo.so (the C ABI declared in include/mippo.h).
+
+The product path has no fallback: if the shared library is missing or a symbol
+cannot be resolved, importing an op raises.  Tensors cross the boundary as raw
+device pointers (`tensor.data_ptr()`), sizes as int64, and the HIP stream as
+the handle of torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libmippo.so"
+
+ABI_VERSION = 1
+
+_P = c_void_p
+_I = c_int64
+_F = c_float
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_SIGNATURES: dict[str, list] = {
+    "mi_abi_version": [],
+    "mi_last_error": [],
+    "mi_gae_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P],
+}
+_RESTYPES = {"mi_last_error": c_char_p}
+
+
+class MippoError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not _LIB_PATH.exists():
+        raise MippoError(
+            f"{_LIB_PATH} not found: build it with `python -m nnx_ppo_amd.csrc.build` "
+            "(there is no CPU / PyTorch fallback for the HIP path)"
+        )
+    lib = ctypes.CDLL(os.fspath(_LIB_PATH))
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    got = lib.mi_abi_version()
+    if got != ABI_VERSION:
+        raise MippoError(f"libmippo ABI {got} != binding ABI {ABI_VERSION}; rebuild")
+    return lib
+
+
+_lib: ctypes.CDLL | None = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGNATURES)
+
+
+def last_error() -> str:
+    return lib().mi_last_error().decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise MippoError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def stream() -> int:
+    """Handle of torch's current HIP stream (what kernels are enqueued on)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None, dtype: torch.dtype | None = None) -> int | None:
+    """Device pointer of a contiguous GPU tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MippoError(
+            "libmippo ops need GPU tensors (got a CPU tensor); there is no CPU fallback"
+        )
+    if not t.is_contiguous():
+        raise MippoError("libmippo ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise MippoError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
