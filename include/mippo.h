@@ -59,6 +59,145 @@ int mi_gae_f32(const float* rewards, const float* values,
                int64_t T, int64_t N, float gamma, float lambda,
                mi_stream_t stream);
 
+/* ---- a8 / a16: running observation normaliser -------------------------- */
+
+/* Normalizer.__call__, `nnx_ppo/networks/normalizer.py:63-96`:
+ *   std = counter > 0 ? sqrt(max(M2 / counter, epsilon)) : 10 ; out = (x - mean) / std
+ * x, out: [M, F]; mean, m2: [F]; counter: device scalar (fp32, as the reference). */
+int mi_normalize_fwd_f32(const float* x, const float* mean, const float* m2,
+                         const float* counter, float epsilon, float* out,
+                         int64_t M, int64_t F, mi_stream_t stream);
+
+/* Gradient of the above w.r.t. x (statistics are constants): g_x = g_out / std. */
+int mi_normalize_bwd_f32(const float* g_out, const float* m2, const float* counter,
+                         float epsilon, float* g_x, int64_t M, int64_t F,
+                         mi_stream_t stream);
+
+/* Normalizer.update_statistics, `normalizer.py:98-136`, in two halves so that a
+ * multi-GPU run can combine per-shard batch statistics in between:
+ *   (1) batch_stats[3][F] = (n, mean, sum of squared deviations) of x[M, F]
+ *       (the reference's batch_mean / batch_M2, computed in one pass);
+ *   (2) merge into the running (mean, M2, counter) with the reference's formula.
+ * `advance_counter` != 0 also does counter += n (a PyTree normaliser shares one
+ * counter across leaves, so only the last leaf's merge advances it). */
+int64_t mi_welford_workspace_bytes(int64_t M, int64_t F);
+int mi_welford_batch_stats_f32(const float* x, float* batch_stats, void* workspace,
+                               int64_t M, int64_t F, mi_stream_t stream);
+int mi_welford_merge_f32(float* mean, float* m2, float* counter,
+                         const float* batch_stats, int64_t F, int advance_counter,
+                         mi_stream_t stream);
+
+/* ---- a10: tanh-Gaussian sampler ---------------------------------------- */
+
+/* NormalTanhSampler.__call__, `nnx_ppo/networks/sampling_layers.py:82-147`.
+ * mean_and_std: [B, 2A] = [mu | s];  sigma = (softplus(s) + min_std) * std_scale.
+ * extras == NULL (ROLLOUT / INFERENCE): z = deterministic ? mu : mu + sigma*eps;
+ * extras != NULL (LOSS_REPLAY): z = extras (the stored raw action).
+ * Outputs (each nullable): raw_out[B,A] = z, action[B,A] = tanh z,
+ * loglik[B], reg[B] = -entropy_weight * H_hat (one-sample entropy estimate with
+ * noise eps2), mu_out / sigma_out [B,A].
+ * Noise: Philox4x32-10 on (seed, offset + offset_add, element) read from the
+ * device-resident rng_state = {seed, offset} (uint64[2]), unless eps / eps2
+ * ([B,A], nullable) are injected. */
+int mi_tanh_gauss_fwd_f32(const float* mean_and_std, const float* extras,
+                          const uint64_t* rng_state, uint64_t offset_add,
+                          const float* eps, const float* eps2, float* raw_out,
+                          float* action, float* loglik, float* reg, float* mu_out,
+                          float* sigma_out, int64_t B, int64_t A, float min_std,
+                          float std_scale, float entropy_weight, int deterministic,
+                          mi_stream_t stream);
+
+/* Backward of the replay forward (what nnx.grad derives, `ppo.py:301-312`):
+ * g_mean_and_std[B,2A] from g_loglik[B] (nullable = 0) and the uniform
+ * regulariser gradient g_reg (d loss / d reg element).  The entropy noise is
+ * regenerated from the same (rng_state, offset_add) or taken from eps2. */
+int mi_tanh_gauss_bwd_f32(const float* mean_and_std, const float* extras,
+                          const uint64_t* rng_state, uint64_t offset_add,
+                          const float* eps2, const float* g_loglik, float g_reg,
+                          float* g_mean_and_std, int64_t B, int64_t A, float min_std,
+                          float std_scale, float entropy_weight, mi_stream_t stream);
+
+/* The sampler's noise streams on their own (eps, eps2: [n], nullable), and the
+ * offset bump that ends an iteration (replaces `self.rng()` advancing,
+ * `sampling_layers.py:96,144`). */
+int mi_philox_normal_f32(const uint64_t* rng_state, uint64_t offset_add, float* eps,
+                         float* eps2, int64_t n, mi_stream_t stream);
+int mi_rng_advance(uint64_t* rng_state, uint64_t n, mi_stream_t stream);
+
+/* ---- a9: Dense layer ---------------------------------------------------- */
+
+/* Dense.__call__, `nnx_ppo/networks/feedforward.py:42-51`: y = act(x @ w + bias).
+ * x: [M, K]; w: [K, N] (flax kernel layout); bias: [N] (nullable); y: [M, N];
+ * preact (nullable): [M, N] pre-activation, needed by the swish backward.
+ * fp32 MFMA (exact fp32 products, fp32 accumulate). */
+int mi_dense_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                     float* preact, int64_t M, int64_t K, int64_t N, int act,
+                     mi_stream_t stream);
+
+/* g_x[M,K] = (g_y ⊙ act'(aux)) @ w^T.  aux = y for relu / tanh, the
+ * pre-activation for swish, ignored (nullable) for MI_ACT_NONE. */
+int mi_dense_bwd_dx_f32(const float* g_y, const float* aux, const float* w, float* g_x,
+                        int64_t M, int64_t K, int64_t N, int act, mi_stream_t stream);
+
+/* g_w[K,N] (+)= x^T @ (g_y ⊙ act'(aux)), g_b[N] (+)= column sums (g_b nullable).
+ * Split over M into slabs in `workspace`, reduced in fixed order. */
+int64_t mi_dense_bwd_dw_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int mi_dense_bwd_dw_f32(const float* x, const float* g_y, const float* aux, float* g_w,
+                        float* g_b, void* workspace, int64_t M, int64_t K, int64_t N,
+                        int act, int accumulate, mi_stream_t stream);
+
+/* ---- a14: loss terms ---------------------------------------------------- */
+
+/* Advantage statistics for `ppo.py:477-480`: stats[3] = (sum, sum of squares,
+ * count) in fp64 — a multi-GPU run all-reduces this triple before the loss. */
+int64_t mi_ppo_loss_workspace_bytes(int64_t n);
+int mi_adv_stats_f32(const float* adv, int64_t n, double* stats, void* workspace,
+                     mi_stream_t stream);
+
+/* Clipped surrogate + value loss + regulariser mean, `ppo.py:456-531`, over a
+ * flattened [T*mb] minibatch.  adv is the raw GAE output; adv_stats (nullable)
+ * turns on normalisation; reg (nullable) is the per-element regulariser.
+ * Outputs: g_ll = d total / d ll_new, g_v = d total / d values (includes
+ * critic_weight), loss_out[4] = (actor, critic, regularization,
+ * clipping_fraction). */
+int mi_ppo_loss_f32(const float* ll_new, const float* ll_old, const float* adv,
+                    const float* values, const float* reg, const double* adv_stats,
+                    float clip_range, float critic_weight, float* g_ll, float* g_v,
+                    float* loss_out, void* workspace, int64_t n, mi_stream_t stream);
+
+/* ---- a15: optimiser ------------------------------------------------------ */
+
+/* Start of a gradient step: grads[n] = 0 and *step += 1 (step nullable). */
+int mi_begin_grad_step_f32(float* grads, int64_t n, int64_t* step, mi_stream_t stream);
+
+/* norm_out[0] = ||grads||_2 (fp64 accumulation) — `ppo.py:313-315` GRAD_NORM and
+ * optax.clip_by_global_norm. */
+int64_t mi_global_norm_workspace_bytes(int64_t n);
+int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out, void* workspace,
+                       mi_stream_t stream);
+
+/* optax.chain([clip_by_global_norm(max_norm)]?, adam | adamw) over flat arenas
+ * (`ppo.py:555-569`).  step: device int64 holding t (already advanced);
+ * grad_norm (nullable): device scalar from mi_global_norm_f32, enables clipping;
+ * weight_decay = 0 gives plain adam. */
+int mi_adam_step_f32(float* params, const float* grads, float* m, float* v, int64_t n,
+                     float lr, float b1, float b2, float eps, float weight_decay,
+                     const int64_t* step, const float* grad_norm, float max_norm,
+                     mi_stream_t stream);
+
+/* ---- a5 / a7: data movement ---------------------------------------------- */
+
+/* Minibatch gather `x[:, inds]`, `ppo.py:297-300`: dst[t, j, :] = src[t, idx[j], :]
+ * for time-major src [T, N, row_bytes], idx int64 [L]. */
+int mi_gather_cols(const void* src, const int64_t* idx, void* dst, int64_t T, int64_t N,
+                   int64_t L, int64_t row_bytes, mi_stream_t stream);
+
+/* tree_where leaf, `rollout.py:270-279`: out[b,:] = mask[b] ? on_true[b,:] : on_false[b,:].
+ * true_row_stride_bytes = row_bytes, or 0 to broadcast one on_true row. */
+int mi_select_rows(const uint8_t* mask, const void* on_true, int64_t true_row_stride_bytes,
+                   const void* on_false, void* out, int64_t B, int64_t row_bytes,
+                   mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

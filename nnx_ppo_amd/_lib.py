@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import re
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 from pathlib import Path
 
@@ -18,17 +19,42 @@ _LIB_PATH = Path(__file__).resolve().parent / "libmippo.so"
 
 ABI_VERSION = 1
 
-_P = c_void_p
-_I = c_int64
-_F = c_float
+_HEADER = Path(__file__).resolve().parent.parent / "include" / "mippo.h"
 
-# name -> argtypes (restype is always int unless listed in _RESTYPES)
-_SIGNATURES: dict[str, list] = {
-    "mi_abi_version": [],
-    "mi_last_error": [],
-    "mi_gae_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P],
+_CTYPES = {
+    "float": c_float,
+    "double": c_double,
+    "int": c_int,
+    "int64_t": c_int64,
+    "uint64_t": c_uint64,
+    "mi_stream_t": c_void_p,
 }
-_RESTYPES = {"mi_last_error": c_char_p}
+
+
+def _parse_header(path: Path) -> dict[str, tuple]:
+    """Read the C ABI from include/mippo.h so the binding can never drift from
+    the header: name -> (restype, argtypes)."""
+    text = re.sub(r"/\*.*?\*/", "", path.read_text(), flags=re.S)
+    sigs: dict[str, tuple] = {}
+    for m in re.finditer(r"([A-Za-z_0-9]+[\s\*]+)(mi_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        restype = c_char_p if "char" in ret else _CTYPES[ret.replace("const", "").strip()]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(c_void_p)
+                else:
+                    ty = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPES[ty])
+        sigs[name] = (restype, argtypes)
+    return sigs
+
+
+_SIGNATURES = _parse_header(_HEADER)
 
 
 class MippoError(RuntimeError):
@@ -42,10 +68,10 @@ def _load() -> ctypes.CDLL:
             "(there is no CPU / PyTorch fallback for the HIP path)"
         )
     lib = ctypes.CDLL(os.fspath(_LIB_PATH))
-    for name, argtypes in _SIGNATURES.items():
+    for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = _RESTYPES.get(name, c_int)
+        fn.restype = restype
     got = lib.mi_abi_version()
     if got != ABI_VERSION:
         raise MippoError(f"libmippo ABI {got} != binding ABI {ABI_VERSION}; rebuild")

@@ -1,0 +1,403 @@
+"""PPO driver, one-iteration step, GAE and loss (counterpart of
+`nnx_ppo/algorithms/ppo.py`): `train_ppo` 41-251, `ppo_step` 254-348, `gae`
+351-394, `ppo_loss` 397-531, `new_training_state` 534-572, `_should_run` 34-38 —
+same names, signatures, defaults and semantics, with the arithmetic done by the
+HIP kernels of libmippo:
+
+  * advantages / targets are recomputed inside every minibatch loss from the
+    CURRENT parameters' values (ppo.py:447-458);
+  * minibatches are over envs only and replay starts from the PRE-rollout
+    carry (ppo.py:297-300);
+  * the entropy regulariser is a one-sample estimate with fresh noise per loss
+    evaluation (sampling_layers.py:137-147);
+  * normaliser statistics are frozen during the iteration and updated last
+    (ppo.py:336).
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+from collections.abc import Callable
+from typing import Any, Optional
+
+import torch
+
+from .. import ops, parallel
+from .. import random as rnd
+from ..networks.types import PPONetworkOutput, StatefulModule
+from ..optim import Optimizer
+from ..tree import tree_leaves, tree_map
+from . import rollout
+from .config import (EvalConfig, PPOConfig, TrainConfig, TrainResult, VideoConfig,  # noqa: F401
+                     VideoData)
+from .metrics import compute_metrics, log_weight_stats
+from .types import LoggingLevel, TrainingState, Transition
+
+
+def default_config() -> TrainConfig:
+    return TrainConfig()
+
+
+def _should_run(steps: int, last_step: int, every_steps: int) -> bool:
+    """ppo.py:34-38."""
+    if every_steps <= 0:
+        return False
+    return (steps // every_steps) > (last_step // every_steps)
+
+
+def train_ppo(
+    env,
+    networks: StatefulModule,
+    config: Optional[TrainConfig] = None,
+    *,
+    total_steps: Optional[int] = None,
+    seed: Optional[int] = None,
+    log_fn: Optional[Callable[[dict, int], None]] = None,
+    video_fn: Optional[Callable[[VideoData], None]] = None,
+    checkpoint_fn: Optional[Callable[[TrainingState, int], None]] = None,
+    eval_env=None,
+    initial_state: Optional[TrainingState] = None,
+) -> TrainResult:
+    """ppo.py:41-251.  `networks` is trained in place."""
+    if config is None:
+        config = default_config()
+    if total_steps is not None:
+        config = dataclasses.replace(config,
+                                     ppo=dataclasses.replace(config.ppo, total_steps=total_steps))
+    if seed is not None:
+        config = dataclasses.replace(config, seed=seed)
+    if eval_env is None:
+        eval_env = env
+
+    if initial_state is None:
+        training_state = new_training_state(
+            env, networks, config.ppo.n_envs, config.seed, config.ppo.learning_rate,
+            config.ppo.gradient_clipping, config.ppo.weight_decay)
+    else:
+        training_state = initial_state
+    device = training_state.steps_taken.device
+
+    eval_history: list[dict] = []
+    last_eval_step = -config.eval.every_steps
+    last_video_step = -config.video.every_steps
+    last_checkpoint_step = -config.checkpoint_every_steps
+    metrics: dict = {}
+    n_iterations = 0
+    measure_throughput = LoggingLevel.THROUGHPUT in config.ppo.logging_level
+
+    def run_eval(steps: int) -> dict:
+        networks.eval()
+        t0 = time.perf_counter() if measure_throughput else None
+        eval_metrics = rollout.eval_rollout(
+            eval_env, networks, config.eval.n_envs, config.eval.max_episode_length,
+            rnd.key(config.seed, device), config.eval.logging_percentiles)
+        if measure_throughput:
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            eval_metrics = dict(eval_metrics)
+            eval_metrics["throughput/eval_sps"] = (
+                config.eval.n_envs * config.eval.max_episode_length / elapsed)
+        networks.train()
+        return dict(eval_metrics)
+
+    def run_video(steps: int, iteration: int) -> dict:
+        # Rendering needs a MuJoCo renderer (rollout.py:150-267); out of scope.
+        return {}
+
+    steps = int(training_state.steps_taken)
+    if config.eval.enabled:
+        eval_metrics = run_eval(steps)
+        metrics.update(eval_metrics)
+        eval_history.append({"step": steps, **eval_metrics})
+        last_eval_step = steps
+    if config.video.enabled:
+        metrics.update(run_video(steps, n_iterations))
+        last_video_step = steps
+    if checkpoint_fn is not None and _should_run(steps, last_checkpoint_step,
+                                                 config.checkpoint_every_steps):
+        checkpoint_fn(training_state, steps)
+        last_checkpoint_step = steps
+    if log_fn is not None and metrics:
+        log_fn(metrics, steps)
+
+    while int(training_state.steps_taken) < config.ppo.total_steps:
+        t0 = time.perf_counter() if measure_throughput else None
+        training_state, metrics = ppo_step(
+            env, training_state, config.ppo.n_envs, config.ppo.rollout_length,
+            config.ppo.gae_lambda, config.ppo.discounting_factor, config.ppo.clip_range,
+            config.ppo.normalize_advantages, config.ppo.combine_advantages,
+            config.ppo.n_epochs, config.ppo.n_minibatches, config.ppo.critic_loss_weight,
+            config.ppo.logging_level, config.ppo.logging_percentiles)
+        n_iterations += 1
+        steps = int(training_state.steps_taken)  # the one host sync per iteration
+        if measure_throughput:
+            elapsed = time.perf_counter() - t0
+            metrics["throughput/train_sps"] = (
+                config.ppo.n_envs * config.ppo.rollout_length / elapsed)
+
+        if config.eval.enabled and _should_run(steps, last_eval_step, config.eval.every_steps):
+            eval_metrics = run_eval(steps)
+            metrics.update(eval_metrics)
+            eval_history.append({"step": steps, **eval_metrics})
+            last_eval_step = steps
+        if config.video.enabled and _should_run(steps, last_video_step,
+                                                config.video.every_steps):
+            metrics.update(run_video(steps, n_iterations))
+            last_video_step = steps
+        if checkpoint_fn is not None and _should_run(steps, last_checkpoint_step,
+                                                     config.checkpoint_every_steps):
+            checkpoint_fn(training_state, steps)
+            last_checkpoint_step = steps
+        if log_fn is not None:
+            log_fn(metrics, steps)
+
+    return TrainResult(
+        training_state=training_state,
+        final_metrics=metrics,
+        eval_history=eval_history,
+        total_steps=int(training_state.steps_taken),
+        total_iterations=n_iterations,
+    )
+
+
+def minibatch_indices(new_key: torch.Tensor, n_envs: int, n_epochs: int,
+                      n_minibatches: int) -> torch.Tensor:
+    """ppo.py:284-294 — per epoch a permutation of the envs (time axis kept
+    whole), reshaped `[n_minibatches, n_envs // n_minibatches]`; int64
+    `[n_epochs * n_minibatches, minibatch_size]`."""
+    minibatch_size = n_envs // n_minibatches
+    rows = []
+    for e in range(n_epochs):
+        perm = rnd.permutation(rnd.fold_in(new_key, e), n_envs)
+        rows.append(perm[: n_minibatches * minibatch_size].reshape(n_minibatches, minibatch_size))
+    return torch.cat(rows, dim=0)
+
+
+def _advance_noise(networks: StatefulModule) -> None:
+    for m in networks.modules():
+        adv = getattr(m, "advance_rng", None)
+        if adv is not None:
+            adv()
+
+
+def ppo_step(
+    env,
+    training_state: TrainingState,
+    n_envs: int,
+    rollout_length: int,
+    gae_lambda: float,
+    discounting_factor: float,
+    clip_range: float,
+    normalize_advantages: bool,
+    combine_advantages: bool,
+    n_epochs: int,
+    n_minibatches: int,
+    critic_loss_weight: float = 1.0,
+    logging_level: LoggingLevel = LoggingLevel.LOSSES,
+    logging_percentiles: Optional[tuple] = None,
+    *,
+    minibatch_inds: Optional[torch.Tensor] = None,
+) -> tuple[TrainingState, dict]:
+    """ppo.py:254-348.  `minibatch_inds` (optional, int64
+    `[n_epochs*n_minibatches, mb]`) injects the minibatch indices instead of
+    drawing them from the key (parity tests)."""
+    networks: StatefulModule = training_state.networks
+    optimizer: Optimizer = training_state.optimizer
+
+    keys = rnd.split(training_state.rng_key)
+    reset_key, new_key = keys[0], keys[1]
+    next_net_state, next_env_state, rollout_data = rollout.unroll_env(
+        env, training_state.env_states, networks, training_state.network_states,
+        rollout_length, reset_key)
+
+    total_iterations = n_epochs * n_minibatches
+    if minibatch_inds is None:
+        all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
+    else:
+        all_indices = minibatch_inds
+    assert all_indices.shape[0] == total_iterations
+
+    # only the Transition fields the loss reads are gathered (ppo.py:297 gathers
+    # every leaf; `metrics`, `actions`, `value_estimates` are dead there)
+    loss_view = Transition(
+        obs=rollout_data.obs,
+        network_output=PPONetworkOutput(
+            actions=None, loglikelihoods=rollout_data.network_output.loglikelihoods,
+            value_estimates=None),
+        rewards=rollout_data.rewards, done=rollout_data.done,
+        truncated=rollout_data.truncated,
+        next_obs=tree_map(lambda x: x[-1:], rollout_data.next_obs),
+        metrics={}, rollout_extras=rollout_data.rollout_extras)
+
+    device = rollout_data.done.device
+    loss_rows = torch.zeros(total_iterations, 4, dtype=torch.float32, device=device)
+    grad_norms = None
+    if LoggingLevel.GRAD_NORM in logging_level:
+        grad_norms = torch.zeros(total_iterations, dtype=torch.float32, device=device)
+
+    for i in range(total_iterations):
+        inds = all_indices[i].contiguous()
+        minibatch = tree_map(lambda x: ops.gather_cols(x, inds), loss_view)
+        net_state_subset = tree_map(
+            lambda x: ops.gather_cols(x.unsqueeze(0), inds).squeeze(0),
+            training_state.network_states)
+        optimizer.begin()
+        ppo_loss(networks, net_state_subset, minibatch, clip_range, normalize_advantages,
+                 combine_advantages, discounting_factor, gae_lambda, critic_loss_weight,
+                 logging_level, loss_out=loss_rows[i])
+        have_norm = False
+        if grad_norms is not None:
+            grad_norms[i:i + 1].copy_(optimizer.compute_grad_norm())
+            have_norm = True
+        optimizer.update(have_norm=have_norm)
+
+    if parallel.is_distributed():
+        parallel.allreduce_sum_(loss_rows)
+        loss_rows = loss_rows / parallel.world_size()
+
+    loss_metrics: dict = {}
+    if LoggingLevel.LOSSES in logging_level:
+        loss_metrics["losses/actor"] = loss_rows[:, 0]
+        loss_metrics["losses/critic"] = loss_rows[:, 1]
+        loss_metrics["losses/regularization"] = loss_rows[:, 2]
+    if LoggingLevel.ACTOR_EXTRA in logging_level:
+        loss_metrics["losses/clipping_fraction"] = loss_rows[:, 3]
+    if grad_norms is not None:
+        loss_metrics["grad_norm"] = grad_norms
+
+    total_steps = training_state.steps_taken + rollout_length * n_envs * parallel.world_size()
+    metrics = compute_metrics(loss_metrics, rollout_data, logging_level, logging_percentiles)
+    metrics["total_steps"] = total_steps
+    if LoggingLevel.WEIGHTS in logging_level:
+        log_weight_stats(metrics, optimizer.params, logging_percentiles)
+    networks.update_statistics(rollout_data.rollout_extras)
+    _advance_noise(networks)
+
+    training_state = training_state.replace(
+        network_states=next_net_state,
+        env_states=next_env_state,
+        rng_key=new_key,
+        steps_taken=total_steps,
+    )
+    return training_state, metrics
+
+
+def gae(rewards: torch.Tensor, values_excl_last: torch.Tensor, last_value: torch.Tensor,
+        done: torch.Tensor, truncation: torch.Tensor, lambda_: float,
+        gamma: float) -> torch.Tensor:
+    """ppo.py:351-394 (same argument order) — one launch of `mi_gae_f32`."""
+    return ops.gae(rewards.contiguous(), values_excl_last.contiguous(),
+                   last_value.contiguous(), done.contiguous(), truncation.contiguous(),
+                   gamma, lambda_)
+
+
+def ppo_loss(
+    networks: StatefulModule,
+    network_state: Any,
+    rollout_data: Transition,
+    clip_range: float,
+    normalize_advantages: bool,
+    combine_advantages: bool,
+    discounting_factor: float,
+    gae_lambda: float,
+    critic_loss_weight: float,
+    logging_level: LoggingLevel,
+    *,
+    loss_out: Optional[torch.Tensor] = None,
+    backward: bool = True,
+) -> tuple[torch.Tensor, dict]:
+    """ppo.py:397-531.  Evaluates the loss on one minibatch (`[T, mb, ...]` leaves)
+    and — where the reference returns gradients from `nnx.grad` — ACCUMULATES the
+    parameter gradients into `Parameter.grad`.  Returns (total_loss, loss_metrics);
+    `loss_out` (float32 [4]) receives (actor, critic, regularization,
+    clipping_fraction) without a host sync."""
+    done = rollout_data.done
+    truncated = rollout_data.truncated
+    T, B = done.shape
+
+    # replay scan (ppo.py:411-431), layer by layer over the whole sequence
+    ctx, out, reg_seq, final_state = networks.replay(
+        network_state, rollout_data.obs, done, rollout_data.rollout_extras,
+        need_input_grad=False)
+    # bootstrap value at T (ppo.py:433-437): fresh forward on the last next_obs
+    last_obs = tree_map(lambda x: x[-1], rollout_data.next_obs)
+    out_last = networks(final_state, last_obs).output
+
+    rewards = rollout_data.rewards
+    values = out.value_estimates
+    ll_new = out.loglikelihoods
+    ll_old = rollout_data.network_output.loglikelihoods
+    if not (isinstance(rewards, torch.Tensor) and isinstance(values, torch.Tensor)
+            and isinstance(ll_new, torch.Tensor)):
+        raise NotImplementedError(
+            "PyTree rewards / value heads / per-module log-likelihoods "
+            "(ppo.py:440-474, combine_advantages) are a 'next' row of the scope table; "
+            "this build handles a single reward, value and log-likelihood tensor")
+    del combine_advantages  # single reward key: nothing to combine
+
+    values = values.contiguous()
+    adv = ops.gae(rewards.contiguous(), values, out_last.value_estimates.contiguous(),
+                  done.contiguous(), truncated.contiguous(), discounting_factor, gae_lambda)
+    stats = None
+    if normalize_advantages:
+        stats = ops.adv_stats(adv)
+        if parallel.is_distributed():
+            parallel.allreduce_sum_(stats)
+    reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
+    g_ll, g_v, loss_out = ops.ppo_loss(
+        ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1), values.reshape(-1), reg_flat,
+        stats, clip_range, critic_loss_weight, loss_out=loss_out)
+    if backward:
+        g_out = PPONetworkOutput(actions=None, loglikelihoods=g_ll.view(T, B),
+                                 value_estimates=g_v.view(T, B))
+        networks.replay_backward(ctx, g_out, 1.0 / float(T * B))
+
+    loss_metrics: dict = {}
+    if LoggingLevel.LOSSES in logging_level:
+        loss_metrics["losses/actor"] = loss_out[0]
+        loss_metrics["losses/critic"] = loss_out[1]
+        loss_metrics["losses/regularization"] = loss_out[2]
+    if LoggingLevel.ACTOR_EXTRA in logging_level:
+        loss_metrics["losses/clipping_fraction"] = loss_out[3]
+    total = loss_out[0] + critic_loss_weight * loss_out[1] + loss_out[2]
+    return total, loss_metrics
+
+
+def new_training_state(
+    env,
+    networks: StatefulModule,
+    n_envs: int,
+    seed: int,
+    learning_rate: float = 1e-4,
+    gradient_clipping: Optional[float] = None,
+    weight_decay: Optional[float] = None,
+    *,
+    device=None,
+) -> TrainingState:
+    """ppo.py:534-572.  Moves `networks` to the device and re-homes its
+    parameters into the optimiser's flat arenas.  In a sharded run every rank
+    passes the same `seed`: parameters come from the (already constructed)
+    network, while env / permutation / noise keys are folded with the rank."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "nnx_ppo_amd needs a GPU: the PPO path runs on HIP kernels and has no CPU "
+                "fallback")
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    key = rnd.key(seed, device)
+    if parallel.is_distributed():
+        key = rnd.fold_in(key, 1 + parallel.rank())
+        for m in networks.modules():
+            if hasattr(m, "seed") and hasattr(m, "advance_rng"):
+                m.seed = (m.seed + 0x9E3779B97F4A7C15 * (1 + parallel.rank())) & (2**63 - 1)
+    ks = rnd.split(key)
+    key, training_key = ks[0], ks[1]
+    env_init_keys = rnd.split(key, n_envs)
+    env_states = env.reset(env_init_keys)
+    networks.to(device)
+    network_states = networks.initialize_state(n_envs)
+    optimizer = Optimizer(networks, learning_rate, gradient_clipping, weight_decay,
+                          device=device)
+    return TrainingState(networks, network_states, env_states, optimizer, training_key,
+                         torch.zeros((), dtype=torch.int64, device=device))

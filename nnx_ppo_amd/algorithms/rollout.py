@@ -1,0 +1,129 @@
+"""Env x network rollout with reset-on-done (counterpart of
+`nnx_ppo/algorithms/rollout.py`: `single_transition` 11-45, `unroll_env` 48-73,
+`eval_rollout` 97-148, `tree_where` 270-279)."""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+import torch
+
+from .. import ops
+from .. import random as rnd
+from ..networks.types import StatefulModule
+from ..tree import tree_all, tree_map
+from .types import Transition
+
+
+def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
+    """rollout.py:270-279 — per leaf `where(cond[:, None...], x, y)`; leaves whose
+    leading dim is not the batch are taken from `on_true` unchanged (the
+    reference's shared-field rule, 272-275).  One byte-exact select kernel per
+    leaf (`mi_select_rows`)."""
+    B = cond.shape[0]
+
+    def leaf(x, y):
+        if not isinstance(x, torch.Tensor) or x.dim() == 0 or x.shape[0] != B:
+            return x
+        if not isinstance(y, torch.Tensor):
+            return x
+        if y.dtype != x.dtype:
+            y = y.to(x.dtype)
+        return ops.select_rows(cond, x.contiguous(), y.contiguous())
+
+    return tree_map(leaf, on_true, on_false)
+
+
+def _as_bool(x: torch.Tensor) -> torch.Tensor:
+    return x if x.dtype == torch.bool else x != 0
+
+
+def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_reset):
+    """rollout.py:11-45."""
+    network_state, env_state = carry
+    out = networks(network_state, env_state.obs)
+    next_network_state = out.next_state
+    ppo_output = out.output
+    next_env_state = env.step(env_state, ppo_output.actions)
+    done = _as_bool(next_env_state.done)
+    trunc = next_env_state.info.get("truncated", None)
+    trunc = torch.zeros_like(done) if trunc is None else _as_bool(trunc)
+    transition = Transition(
+        obs=env_state.obs,
+        network_output=ppo_output,
+        rewards=next_env_state.reward,
+        done=done,
+        truncated=trunc,
+        next_obs=next_env_state.obs,
+        metrics={"env": next_env_state.metrics, "net": out.metrics},
+        rollout_extras=out.rollout_extras,
+    )
+    reset_states = env.reset(rng_keys_for_env_reset)
+    next_env_state = tree_where(done, reset_states, next_env_state)
+    reset_network_states = networks.reset_state(next_network_state)
+    next_network_state = tree_where(done, reset_network_states, next_network_state)
+    return (next_network_state, next_env_state), transition
+
+
+def unroll_env(env, env_state, networks: StatefulModule, network_state, unroll_length: int,
+               rng_key_for_env_reset: torch.Tensor):
+    """rollout.py:48-73 — returns (final_network_state, final_env_state, Transition
+    with time-major `[T, N, ...]` leaves)."""
+    batch_size = env_state.done.shape[0]
+    keys = rnd.split(rng_key_for_env_reset, (unroll_length, batch_size))
+    carry = (network_state, env_state)
+    steps = []
+    for t in range(unroll_length):
+        carry, tr = single_transition(env, networks, carry, keys[t])
+        steps.append(tr)
+    rollout = tree_map(lambda *xs: torch.stack(xs, dim=0), steps[0], *steps[1:])
+    shapes_match = tree_map(lambda v, r: v.shape == r.shape,
+                            rollout.network_output.value_estimates, rollout.rewards)
+    assert tree_all(shapes_match), "value_estimates leaves must match rewards leaves"
+    return carry[0], carry[1], rollout
+
+
+def _add_reward_metrics(out: dict, name: str, reward: Any,
+                        percentile_levels: Optional[tuple]) -> None:
+    """rollout.py:76-94."""
+    if isinstance(reward, dict):
+        for k, v in reward.items():
+            _add_reward_metrics(out, f"{name}/{k}", v, percentile_levels)
+    elif percentile_levels is not None:
+        q = torch.tensor(percentile_levels, dtype=torch.float32, device=reward.device) / 100.0
+        pct = torch.quantile(reward.float(), q)
+        for pl, p in zip(percentile_levels, pct):
+            out[f"{name}/p{int(pl)}"] = p
+    else:
+        out[f"{name}/mean"] = reward.mean()
+        out[f"{name}/std"] = reward.std(unbiased=False)
+
+
+def eval_rollout(env, networks: StatefulModule, n_envs: int, max_episode_length: int,
+                 key: torch.Tensor, logging_percentiles: Optional[tuple] = None) -> dict:
+    """rollout.py:97-148 — sticky-done evaluation: reward accumulates until the
+    first done of each env; lifespan counts the steps before it."""
+    env_states = env.reset(rnd.split(key, n_envs))
+    net_states = networks.initialize_state(n_envs)
+    cuml_reward = tree_map(torch.zeros_like, env_states.reward)
+    dev = env_states.done.device
+    lifespan = torch.zeros(n_envs, dtype=torch.float32, device=dev)
+    env_state = env_states
+    for _ in range(max_episode_length):
+        out = networks(net_states, env_state.obs)
+        net_states = out.next_state
+        nxt = env.step(env_state, out.output.actions)
+        prev_done = _as_bool(env_state.done)
+        sticky = torch.logical_or(_as_bool(nxt.done), prev_done)
+        nxt = nxt.replace(done=sticky.to(torch.float32))
+        reward_this_step = tree_map(lambda r: torch.where(prev_done, torch.zeros_like(r), r),
+                                    nxt.reward)
+        cuml_reward = tree_map(torch.add, cuml_reward, reward_this_step)
+        lifespan = lifespan + torch.where(sticky, 0.0, 1.0)
+        env_state = nxt
+    metrics = dict(lifespan_mean=lifespan.mean(), lifespan_std=lifespan.std(unbiased=False))
+    _add_reward_metrics(metrics, "episode_reward", cuml_reward, logging_percentiles)
+    if logging_percentiles is not None:
+        q = torch.tensor(logging_percentiles, dtype=torch.float32, device=dev) / 100.0
+        for pl, p in zip(logging_percentiles, torch.quantile(lifespan, q)):
+            metrics[f"lifespan/p{int(pl)}"] = p
+    return metrics

@@ -16,7 +16,7 @@ int check_launch(const char* what);
 
 inline hipStream_t as_stream(mi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Memory-bound kernels: cap the grid at 8 blocks per CU and grid-stride the rest.
 constexpr int kNumCU = 256;

@@ -1,0 +1,94 @@
+// a5 / a7 — byte-exact data movement of the hot path:
+//   * minibatch gather  x[:, inds]  over time-major [T, N, row] leaves
+//     (reference: nnx_ppo/algorithms/ppo.py:297-300)
+//   * masked row select  where(done[:, None], on_true, on_false)  used for
+//     env / carry reset-on-done (reference: nnx_ppo/algorithms/rollout.py:270-279,
+//     ppo.py:411-413)
+// Both are dtype-agnostic (rows are moved as 4-byte words when the row size
+// allows, bytes otherwise) and therefore bit-exact by construction.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// dst[t, j, :] = src[t, idx[j], :]   (W words of type T per row)
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+gather_cols_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx,
+                   T* __restrict__ dst, int64_t Tn, int64_t N, int64_t L, int64_t W) {
+  const int64_t total = Tn * L * W;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t w = i % W;
+    const int64_t j = (i / W) % L;
+    const int64_t t = i / (W * L);
+    dst[i] = src[(t * N + idx[j]) * W + w];
+  }
+}
+
+// out[b, :] = mask[b] ? on_true[b * true_stride : ...] : on_false[b, :]
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+select_rows_kernel(const uint8_t* __restrict__ mask, const T* __restrict__ on_true,
+                   int64_t true_stride, const T* __restrict__ on_false, T* __restrict__ out,
+                   int64_t B, int64_t W) {
+  const int64_t total = B * W;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t b = i / W, w = i % W;
+    out[i] = mask[b] ? on_true[b * true_stride + w] : on_false[i];
+  }
+}
+
+int stream_grid(int64_t n) {
+  int64_t g = mippo::ceil_div(n, kThreads);
+  if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
+  return (int)(g < 1 ? 1 : g);
+}
+
+bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+
+}  // namespace
+
+extern "C" int mi_gather_cols(const void* src, const int64_t* idx, void* dst, int64_t T,
+                              int64_t N, int64_t L, int64_t row_bytes, mi_stream_t stream) {
+  MI_REQUIRE(T >= 0 && N >= 0 && L >= 0 && row_bytes >= 1, "mi_gather_cols: bad shape");
+  if (T == 0 || L == 0) return 0;
+  MI_REQUIRE(src && idx && dst && N >= 1, "mi_gather_cols: null pointer / empty source");
+  hipStream_t st = mippo::as_stream(stream);
+  if (row_bytes % 4 == 0 && aligned4(src) && aligned4(dst)) {
+    const int64_t W = row_bytes / 4;
+    hipLaunchKernelGGL(gather_cols_kernel<uint32_t>, dim3(stream_grid(T * L * W)),
+                       dim3(kThreads), 0, st, static_cast<const uint32_t*>(src), idx,
+                       static_cast<uint32_t*>(dst), T, N, L, W);
+  } else {
+    hipLaunchKernelGGL(gather_cols_kernel<uint8_t>, dim3(stream_grid(T * L * row_bytes)),
+                       dim3(kThreads), 0, st, static_cast<const uint8_t*>(src), idx,
+                       static_cast<uint8_t*>(dst), T, N, L, row_bytes);
+  }
+  return mippo::check_launch("mi_gather_cols");
+}
+
+extern "C" int mi_select_rows(const uint8_t* mask, const void* on_true, int64_t true_row_stride_bytes,
+                              const void* on_false, void* out, int64_t B, int64_t row_bytes,
+                              mi_stream_t stream) {
+  MI_REQUIRE(B >= 0 && row_bytes >= 1, "mi_select_rows: bad shape");
+  MI_REQUIRE(true_row_stride_bytes == 0 || true_row_stride_bytes == row_bytes,
+             "mi_select_rows: on_true stride must be 0 (broadcast row) or row_bytes");
+  if (B == 0) return 0;
+  MI_REQUIRE(mask && on_true && on_false && out, "mi_select_rows: null pointer");
+  hipStream_t st = mippo::as_stream(stream);
+  if (row_bytes % 4 == 0 && aligned4(on_true) && aligned4(on_false) && aligned4(out)) {
+    const int64_t W = row_bytes / 4;
+    hipLaunchKernelGGL(select_rows_kernel<uint32_t>, dim3(stream_grid(B * W)), dim3(kThreads), 0,
+                       st, mask, static_cast<const uint32_t*>(on_true), true_row_stride_bytes / 4,
+                       static_cast<const uint32_t*>(on_false), static_cast<uint32_t*>(out), B, W);
+  } else {
+    hipLaunchKernelGGL(select_rows_kernel<uint8_t>, dim3(stream_grid(B * row_bytes)),
+                       dim3(kThreads), 0, st, mask, static_cast<const uint8_t*>(on_true),
+                       true_row_stride_bytes, static_cast<const uint8_t*>(on_false),
+                       static_cast<uint8_t*>(out), B, row_bytes);
+  }
+  return mippo::check_launch("mi_select_rows");
+}

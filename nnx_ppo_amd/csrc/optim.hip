@@ -1,0 +1,135 @@
+// a15 — optimiser step over a flat fp32 parameter arena
+// (reference: nnx.Optimizer.update with optax.chain([clip_by_global_norm?],
+//  adam | adamw), nnx_ppo/algorithms/ppo.py:316,555-569).  optax / flax are not
+//  in the reference tree; the formulas below are the published optax ones and
+//  are PARITY UNPINNED (no reference test pins optimiser arithmetic).
+//
+//   clip_by_global_norm(c): g <- g            if ||g|| < c
+//                           g <- g / ||g|| * c otherwise
+//   scale_by_adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; t = count + 1
+//                  u = (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)
+//   adamw: u += weight_decay * p ;  p <- p - lr * u
+// All parameters, gradients and moments of a network live in four flat fp32
+// arenas, so one launch updates the whole network (28 B/param of HBM traffic).
+// The step counter and the gradient norm are device-resident so the whole
+// update is HIP-graph capturable.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxPartials = 512;
+
+// Zero the gradient arena and advance the step counter (start of a grad step).
+__global__ void __launch_bounds__(kThreads)
+begin_step_kernel(float* __restrict__ grads, int64_t n, int64_t* step) {
+  const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  for (int64_t i = i0; i < n; i += (int64_t)gridDim.x * kThreads) grads[i] = 0.0f;
+  if (i0 == 0 && step) *step += 1;
+}
+
+__global__ void __launch_bounds__(kThreads)
+sumsq_partial_kernel(const float* __restrict__ g, int64_t n, double* partials) {
+  __shared__ double scratch[kThreads / 64];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kThreads) {
+    const double x = g[i];
+    s += x * x;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += scratch[w];
+    partials[blockIdx.x] = t;
+  }
+}
+
+__global__ void norm_finalize_kernel(const double* partials, int G, float* norm_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t = 0.0;
+  for (int g = 0; g < G; ++g) t += partials[g];
+  *norm_out = (float)sqrt(t);
+}
+
+__global__ void __launch_bounds__(kThreads)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+            float weight_decay, const int64_t* __restrict__ step,
+            const float* __restrict__ grad_norm, float max_norm) {
+  const float t = (float)(*step);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2 = 1.0f - powf(b2, t);
+  float gscale = 1.0f;
+  bool clip = false;
+  float gn = 1.0f;
+  if (grad_norm) {
+    gn = *grad_norm;
+    clip = !(gn < max_norm);
+  }
+  (void)gscale;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kThreads) {
+    float gi = g[i];
+    if (clip) gi = gi / gn * max_norm;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * (gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    const float pi = p[i];
+    if (weight_decay != 0.0f) u += weight_decay * pi;
+    p[i] = pi - lr * u;
+  }
+}
+
+int stream_grid(int64_t n) {
+  int64_t g = mippo::ceil_div(n, kThreads);
+  if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int mi_begin_grad_step_f32(float* grads, int64_t n, int64_t* step,
+                                      mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && (grads || n == 0), "mi_begin_grad_step_f32: bad arguments");
+  hipLaunchKernelGGL(begin_step_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), grads, n, step);
+  return mippo::check_launch("mi_begin_grad_step_f32");
+}
+
+extern "C" int64_t mi_global_norm_workspace_bytes(int64_t n) {
+  if (n < 0) return -EINVAL;
+  return (int64_t)kMaxPartials * (int64_t)sizeof(double);
+}
+
+extern "C" int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out,
+                                  void* workspace, mi_stream_t stream) {
+  MI_REQUIRE(n >= 1 && grads && norm_out && workspace, "mi_global_norm_f32: bad arguments");
+  int64_t G = mippo::ceil_div(n, (int64_t)kThreads * 8);
+  if (G > kMaxPartials) G = kMaxPartials;
+  if (G < 1) G = 1;
+  double* partials = static_cast<double*>(workspace);
+  hipStream_t st = mippo::as_stream(stream);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)G), dim3(kThreads), 0, st, grads, n,
+                     partials);
+  int rc = mippo::check_launch("mi_global_norm_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, partials, (int)G, norm_out);
+  return mippo::check_launch("mi_global_norm_f32(finalize)");
+}
+
+extern "C" int mi_adam_step_f32(float* params, const float* grads, float* m, float* v,
+                                int64_t n, float lr, float b1, float b2, float eps,
+                                float weight_decay, const int64_t* step,
+                                const float* grad_norm, float max_norm, mi_stream_t stream) {
+  MI_REQUIRE(n >= 1 && params && grads && m && v && step, "mi_adam_step_f32: bad arguments");
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), params, grads, m, v, n, lr, b1, b2, eps,
+                     weight_decay, step, grad_norm, max_norm);
+  return mippo::check_launch("mi_adam_step_f32");
+}

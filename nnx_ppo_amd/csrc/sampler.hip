@@ -1,0 +1,191 @@
+// a10 — tanh-Gaussian action sampler: sample / log-prob / entropy-MC regulariser
+// forward and backward (reference: nnx_ppo/networks/sampling_layers.py:82-147).
+//
+// Elementwise over [B, 2A] rows, fp32 only (the ratio exp(ll_new - ll_old) and
+// the tanh-Jacobian term are cancellation-prone).  One thread per row: rows are
+// 2A contiguous floats, so a wave reads one contiguous span.  Noise comes from
+// Philox (philox.h) keyed by a device-resident {seed, offset} pair so that a
+// captured HIP graph draws fresh noise on every replay; the backward kernel
+// regenerates the entropy noise from the same counter instead of storing it.
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kLog2 = 0.69314718055994530942f;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+__device__ inline float softplus(float x) {
+  // jax.nn.softplus = logaddexp(x, 0)
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ inline float log_det_jac(float z) {
+  // sampling_layers.py:133: 2 (log 2 - z - softplus(-2 z))
+  return 2.0f * (kLog2 - z - softplus(-2.0f * z));
+}
+
+struct Noise {
+  const uint64_t* rng;  // {seed, offset}; may be null when both eps are injected
+  uint64_t offset_add;
+  const float* eps;   // [B, A] injected action noise or null
+  const float* eps2;  // [B, A] injected entropy noise or null
+  __device__ inline void get(int64_t elem, float& e, float& e2) const {
+    if (eps && eps2) {
+      e = eps[elem];
+      e2 = eps2[elem];
+      return;
+    }
+    float pe, pe2;
+    mippo::philox_normal_pair(rng[0], rng[1] + offset_add, (uint64_t)elem, pe, pe2);
+    e = eps ? eps[elem] : pe;
+    e2 = eps2 ? eps2[elem] : pe2;
+  }
+};
+
+__global__ void __launch_bounds__(kThreads)
+sampler_fwd_kernel(const float* __restrict__ ms, const float* __restrict__ extras,
+                   Noise noise, float* __restrict__ raw_out, float* __restrict__ action,
+                   float* __restrict__ ll, float* __restrict__ reg,
+                   float* __restrict__ mu_out, float* __restrict__ sigma_out, int64_t B,
+                   int A, float min_std, float std_scale, float entropy_weight,
+                   int deterministic) {
+  const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* row = ms + b * 2 * A;
+  float ll_acc = 0.0f, h_acc = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    const int64_t e = b * A + a;
+    const float mu = row[a];
+    const float sigma = (softplus(row[A + a]) + min_std) * std_scale;
+    float eps, eps2;
+    noise.get(e, eps, eps2);
+    const float sampled = deterministic ? mu : mu + sigma * eps;
+    const float z = extras ? extras[e] : sampled;
+    // _loglikelihood, sampling_layers.py:118-135
+    const float q = (z - mu) / sigma;
+    float lp = -0.5f * (q * q) - (kHalfLog2Pi + logf(sigma));
+    lp -= log_det_jac(z);
+    ll_acc += lp;
+    // _entropy, sampling_layers.py:137-147
+    const float z2 = mu + sigma * eps2;
+    h_acc += (0.5f + kHalfLog2Pi + logf(sigma)) + log_det_jac(z2);
+    if (raw_out) raw_out[e] = z;
+    if (action) action[e] = tanhf(z);
+    if (mu_out) mu_out[e] = mu;
+    if (sigma_out) sigma_out[e] = sigma;
+  }
+  if (ll) ll[b] = ll_acc;
+  if (reg) reg[b] = -entropy_weight * h_acc;
+}
+
+__global__ void __launch_bounds__(kThreads)
+sampler_bwd_kernel(const float* __restrict__ ms, const float* __restrict__ extras,
+                   Noise noise, const float* __restrict__ g_ll, float g_reg,
+                   float* __restrict__ g_ms, int64_t B, int A, float min_std,
+                   float std_scale, float entropy_weight) {
+  const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* row = ms + b * 2 * A;
+  float* grow = g_ms + b * 2 * A;
+  const float gl = g_ll ? g_ll[b] : 0.0f;
+  const float gh = -entropy_weight * g_reg;  // d loss / d H
+  for (int a = 0; a < A; ++a) {
+    const int64_t e = b * A + a;
+    const float mu = row[a];
+    const float s = row[A + a];
+    const float sigma = (softplus(s) + min_std) * std_scale;
+    float eps, eps2;
+    noise.get(e, eps, eps2);
+    const float z = extras[e];
+    const float inv = 1.0f / sigma;
+    const float q = (z - mu) * inv;
+    // ll: d/dmu = q/sigma ; d/dsigma = (q^2 - 1)/sigma
+    float g_mu = gl * q * inv;
+    float g_sigma = gl * (q * q - 1.0f) * inv;
+    // H: z2 = mu + sigma*eps2 ; d logdetjac / dz2 = -2 tanh(z2)
+    const float t2 = tanhf(mu + sigma * eps2);
+    g_mu += gh * (-2.0f * t2);
+    g_sigma += gh * (inv - 2.0f * t2 * eps2);
+    grow[a] = g_mu;
+    grow[A + a] = g_sigma * sigmoidf(s) * std_scale;
+  }
+}
+
+__global__ void philox_normal_kernel(const uint64_t* rng, uint64_t offset_add,
+                                     float* eps, float* eps2, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  float a, b;
+  mippo::philox_normal_pair(rng[0], rng[1] + offset_add, (uint64_t)i, a, b);
+  if (eps) eps[i] = a;
+  if (eps2) eps2[i] = b;
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng, uint64_t n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += n;
+}
+
+}  // namespace
+
+extern "C" int mi_tanh_gauss_fwd_f32(const float* mean_and_std, const float* extras,
+                                     const uint64_t* rng_state, uint64_t offset_add,
+                                     const float* eps, const float* eps2, float* raw_out,
+                                     float* action, float* loglik, float* reg,
+                                     float* mu_out, float* sigma_out, int64_t B,
+                                     int64_t A, float min_std, float std_scale,
+                                     float entropy_weight, int deterministic,
+                                     mi_stream_t stream) {
+  MI_REQUIRE(B >= 0 && A >= 1 && A <= (1 << 20), "mi_tanh_gauss_fwd_f32: bad shape");
+  if (B == 0) return 0;
+  MI_REQUIRE(mean_and_std, "mi_tanh_gauss_fwd_f32: null mean_and_std");
+  MI_REQUIRE(rng_state || (eps && eps2),
+             "mi_tanh_gauss_fwd_f32: need rng_state or both injected noises");
+  Noise nz = {rng_state, offset_add, eps, eps2};
+  hipLaunchKernelGGL(sampler_fwd_kernel, dim3((unsigned)mippo::ceil_div(B, kThreads)),
+                     dim3(kThreads), 0, mippo::as_stream(stream), mean_and_std, extras, nz,
+                     raw_out, action, loglik, reg, mu_out, sigma_out, B, (int)A, min_std,
+                     std_scale, entropy_weight, deterministic);
+  return mippo::check_launch("mi_tanh_gauss_fwd_f32");
+}
+
+extern "C" int mi_tanh_gauss_bwd_f32(const float* mean_and_std, const float* extras,
+                                     const uint64_t* rng_state, uint64_t offset_add,
+                                     const float* eps2, const float* g_loglik, float g_reg,
+                                     float* g_mean_and_std, int64_t B, int64_t A,
+                                     float min_std, float std_scale, float entropy_weight,
+                                     mi_stream_t stream) {
+  MI_REQUIRE(B >= 0 && A >= 1 && A <= (1 << 20), "mi_tanh_gauss_bwd_f32: bad shape");
+  if (B == 0) return 0;
+  MI_REQUIRE(mean_and_std && extras && g_mean_and_std, "mi_tanh_gauss_bwd_f32: null pointer");
+  MI_REQUIRE(rng_state || eps2, "mi_tanh_gauss_bwd_f32: need rng_state or injected eps2");
+  // the action noise is irrelevant in replay (z is given); alias it to eps2 so
+  // Noise::get() never touches Philox when the entropy noise is injected.
+  Noise nz = {rng_state, offset_add, eps2, eps2};
+  hipLaunchKernelGGL(sampler_bwd_kernel, dim3((unsigned)mippo::ceil_div(B, kThreads)),
+                     dim3(kThreads), 0, mippo::as_stream(stream), mean_and_std, extras, nz,
+                     g_loglik, g_reg, g_mean_and_std, B, (int)A, min_std, std_scale,
+                     entropy_weight);
+  return mippo::check_launch("mi_tanh_gauss_bwd_f32");
+}
+
+extern "C" int mi_philox_normal_f32(const uint64_t* rng_state, uint64_t offset_add,
+                                    float* eps, float* eps2, int64_t n,
+                                    mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && rng_state, "mi_philox_normal_f32: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)mippo::ceil_div(n, kThreads)),
+                     dim3(kThreads), 0, mippo::as_stream(stream), rng_state, offset_add, eps,
+                     eps2, n);
+  return mippo::check_launch("mi_philox_normal_f32");
+}
+
+extern "C" int mi_rng_advance(uint64_t* rng_state, uint64_t n, mi_stream_t stream) {
+  MI_REQUIRE(rng_state, "mi_rng_advance: null rng_state");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, mippo::as_stream(stream),
+                     rng_state, n);
+  return mippo::check_launch("mi_rng_advance");
+}

@@ -1,0 +1,135 @@
+"""Closed-form batched envs.  All arithmetic is integer hashing plus exact /
+single-rounding float ops, so a CPU run and a GPU run of the same env from the
+same keys produce bit-identical observations, rewards and flags."""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from .. import random as rnd
+from ..algorithms.types import State
+
+
+class MockEnv:
+    """`nnx_ppo/test_dummies/mock_env.py:25-63`: observations are unit-variance
+    noise regenerated every step from a counter-based key, actions are ignored,
+    reward is 1.0, the episode ends when `step_count >= max_steps`.
+    `obs_size` may be an int (flat obs) or a dict `{name: size}` (PyTree obs).
+    Unlike the reference's mock (whose noise key depends on the step only) each
+    env mixes its own key in, so envs are decorrelated."""
+
+    def __init__(self, obs_size, action_size: int, max_steps: int = 5):
+        self.obs_size = obs_size
+        self.action_size = action_size
+        self.max_steps = max_steps
+        self.observation_size = obs_size
+
+    def _obs(self, key: torch.Tensor, step: torch.Tensor) -> Any:
+        k = rnd._mix(key ^ rnd._mix(step + rnd._GOLDEN))
+        if isinstance(self.obs_size, dict):
+            out = {}
+            for i, name in enumerate(sorted(self.obs_size)):
+                out[name] = rnd.unit_uniform(rnd._mix(k + i + 1), (self.obs_size[name],))
+            return out
+        return rnd.unit_uniform(k, (self.obs_size,))
+
+    def reset(self, rng: torch.Tensor) -> State:
+        n = rng.shape
+        zero = torch.zeros(n, dtype=torch.int64, device=rng.device)
+        return State(
+            data={"key": rng, "step_count": zero},
+            obs=self._obs(rng, zero),
+            reward=torch.zeros(n, dtype=torch.float32, device=rng.device),
+            done=torch.zeros(n, dtype=torch.bool, device=rng.device),
+            metrics={}, info={})
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        step = state.data["step_count"] + 1
+        key = state.data["key"]
+        return State(
+            data={"key": key, "step_count": step},
+            obs=self._obs(key, step),
+            reward=torch.ones(step.shape, dtype=torch.float32, device=step.device),
+            done=step >= self.max_steps,
+            metrics={}, info={})
+
+
+def cartpole_shaped(max_steps: int = 1000) -> MockEnv:
+    """CartpoleBalance-shaped workload: obs 5, action 1 (BASELINE configs 1/2/4/5)."""
+    return MockEnv(5, 1, max_steps=max_steps)
+
+
+def cheetah_shaped(max_steps: int = 1000) -> MockEnv:
+    """CheetahRun-shaped workload: PyTree obs {"position": 8, "velocity": 9},
+    action 6 (BASELINE config 3)."""
+    return MockEnv({"position": 8, "velocity": 9}, 6, max_steps=max_steps)
+
+
+class DummyCounterEnv:
+    """`nnx_ppo/test_dummies/dummy_counter.py:10-43`: reward 1.0 iff the action
+    equals the number of steps since the last reset; resets after a random 3..9
+    steps.  Used to prove that carry reset stays in lock-step with env reset."""
+
+    observation_size = 1
+    action_size = 1
+
+    def reset(self, rng: torch.Tensor) -> State:
+        n = rng.shape
+        dev = rng.device
+        zero = torch.zeros(n, dtype=torch.int64, device=dev)
+        return State(
+            data={"current_step": zero, "reset_step": rnd.randint(rng, (), 3, 10)},
+            obs=torch.zeros(*n, 1, dtype=torch.float32, device=dev),
+            info={"current_step": zero},
+            reward=torch.ones(n, dtype=torch.float32, device=dev),
+            done=torch.zeros(n, dtype=torch.float32, device=dev),
+            metrics={})
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        cur = state.data["current_step"] + 1
+        data = {"current_step": cur, "reset_step": state.data["reset_step"]}
+        done = (cur >= data["reset_step"]).to(torch.float32)
+        a = action.reshape(cur.shape)
+        return State(
+            data=data,
+            obs=torch.zeros(*cur.shape, 1, dtype=torch.float32, device=cur.device),
+            info={"current_step": cur},
+            reward=torch.where(a == cur.to(a.dtype), 1.0, 0.0).to(torch.float32),
+            done=done,
+            metrics=state.metrics)
+
+
+class MoveToCenterEnv:
+    """`nnx_ppo/test_dummies/move_to_center_env.py:10-50`: 2-D point, reward
+    exp(-d^2 / (2 falloff^2)), done when outside `border_radius`."""
+
+    def __init__(self, reward_falloff: float = 0.5, border_radius: float = 2.0):
+        self.reward_falloff = reward_falloff
+        self.border_radius = border_radius
+
+    def reset(self, rng: torch.Tensor) -> State:
+        u = rnd.uniform(rng, (2,))
+        phi, rad = u[..., 0], u[..., 1] * (self.border_radius * 0.9)
+        ang = 2 * torch.pi * phi
+        pos = torch.stack([torch.cos(ang) * rad, torch.sin(ang) * rad], dim=-1)
+        return self._get_state({"pos": pos})
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        action = torch.clamp(action, -1, 1)
+        return self._get_state({"pos": state.data["pos"] + action})
+
+    def _get_state(self, data) -> State:
+        d_sqr = torch.square(data["pos"]).sum(-1)
+        reward = torch.exp(-(d_sqr / (self.reward_falloff ** 2) / 2))
+        done = torch.where(d_sqr > self.border_radius ** 2, 1.0, 0.0).to(torch.float32)
+        return State(data=data, obs=data["pos"] / 10.0, info={}, reward=reward, done=done,
+                     metrics={})
+
+    @property
+    def observation_size(self):
+        return 2
+
+    @property
+    def action_size(self):
+        return 2

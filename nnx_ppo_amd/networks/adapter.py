@@ -1,0 +1,100 @@
+"""PPOAdapter: two-port router from network output to `PPONetworkOutput`
+(counterpart of `nnx_ppo/networks/adapter.py:48-133`).  Routing only — both
+ports see the same input; the action port's output is a tree of sampler dicts
+`{"action", "log_likelihood"}`; the value port's trailing singleton axis is
+squeezed (`adapter.py:55-58,98`)."""
+from __future__ import annotations
+
+from typing import Any
+
+from ..tree import tree_map
+from .types import (ModuleState, PPONetworkOutput, StatefulModule, StatefulModuleOutput,
+                    add_reg)
+
+_SAMPLER_DICT_KEYS = frozenset({"action", "log_likelihood"})
+
+
+def _is_sampler_dict(x: Any) -> bool:
+    return isinstance(x, dict) and _SAMPLER_DICT_KEYS.issubset(x.keys())
+
+
+def _squeeze_trailing_one(v: Any) -> Any:
+    if hasattr(v, "shape") and len(v.shape) and v.shape[-1] == 1:
+        return v.squeeze(-1)
+    return v
+
+
+class PPOAdapter(StatefulModule):
+    def __init__(self, action: StatefulModule, value: StatefulModule):
+        self.action = action
+        self.value = value
+
+    def __call__(self, state: dict[str, ModuleState], x: Any,
+                 rollout_extras: Any = None) -> StatefulModuleOutput:
+        if rollout_extras is None:
+            a_re = v_re = None
+        else:
+            a_re = rollout_extras["action"]
+            v_re = rollout_extras["value"]
+        a_out = self.action(state["action"], x, a_re)
+        v_out = self.value(state["value"], x, v_re)
+        actions = tree_map(lambda d: d["action"], a_out.output, is_leaf=_is_sampler_dict)
+        loglikelihoods = tree_map(lambda d: d["log_likelihood"], a_out.output,
+                                  is_leaf=_is_sampler_dict)
+        value_estimates = tree_map(_squeeze_trailing_one, v_out.output)
+        return StatefulModuleOutput(
+            next_state={"action": a_out.next_state, "value": v_out.next_state},
+            output=PPONetworkOutput(actions=actions, loglikelihoods=loglikelihoods,
+                                    value_estimates=value_estimates),
+            regularization_loss=add_reg(a_out.regularization_loss, v_out.regularization_loss),
+            metrics={"action": a_out.metrics, "value": v_out.metrics},
+            rollout_extras={"action": a_out.rollout_extras, "value": v_out.rollout_extras},
+        )
+
+    def initialize_state(self, batch_size: int) -> dict[str, ModuleState]:
+        return {"action": self.action.initialize_state(batch_size),
+                "value": self.value.initialize_state(batch_size)}
+
+    def reset_state(self, prev_state: dict[str, ModuleState]) -> dict[str, ModuleState]:
+        return {"action": self.action.reset_state(prev_state["action"]),
+                "value": self.value.reset_state(prev_state["value"])}
+
+    def update_statistics(self, rollout_extras: Any) -> None:
+        self.action.update_statistics(rollout_extras["action"])
+        self.value.update_statistics(rollout_extras["value"])
+
+    # ---- training protocol ------------------------------------------------------
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+        a_re = None if extras_seq is None else extras_seq["action"]
+        v_re = None if extras_seq is None else extras_seq["value"]
+        a_ctx, a_out, a_reg, a_fs = self.action.replay(state0["action"], x_seq, done_seq, a_re,
+                                                       need_input_grad)
+        v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], x_seq, done_seq, v_re,
+                                                      need_input_grad)
+        actions = tree_map(lambda d: d["action"], a_out, is_leaf=_is_sampler_dict)
+        loglik = tree_map(lambda d: d["log_likelihood"], a_out, is_leaf=_is_sampler_dict)
+        values = tree_map(_squeeze_trailing_one, v_out)
+        squeezed = tree_map(lambda v, s: v.shape != s.shape, v_out, values)
+        out = PPONetworkOutput(actions=actions, loglikelihoods=loglik, value_estimates=values)
+        ctx = (a_ctx, v_ctx, a_out, squeezed)
+        return ctx, out, add_reg(a_reg, v_reg), {"action": a_fs, "value": v_fs}
+
+    def replay_backward(self, ctx, g_out: PPONetworkOutput, g_reg):
+        a_ctx, v_ctx, a_out, squeezed = ctx
+        # gradient tree for the action port: sampler dicts with d/d log_likelihood
+        if _is_sampler_dict(a_out):
+            g_a = {"action": None, "log_likelihood": g_out.loglikelihoods}
+        else:
+            g_a = tree_map(lambda d, g: {"action": None, "log_likelihood": g}, a_out,
+                           g_out.loglikelihoods, is_leaf=_is_sampler_dict)
+        g_v = tree_map(lambda g, sq: g.unsqueeze(-1) if sq else g, g_out.value_estimates,
+                       squeezed)
+        gx_a = self.action.replay_backward(a_ctx, g_a, g_reg)
+        gx_v = self.value.replay_backward(v_ctx, g_v, g_reg)
+        if gx_a is None and gx_v is None:
+            return None
+        if gx_a is None:
+            return gx_v
+        if gx_v is None:
+            return gx_a
+        return tree_map(lambda a, b: a + b, gx_a, gx_v)

@@ -1,0 +1,62 @@
+"""MLP builders (counterpart of `nnx_ppo/networks/factories.py`):
+`make_mlp_layers` 14-45, `make_mlp` 48-69, `make_mlp_actor_critic` 72-146 —
+same signatures and defaults."""
+from __future__ import annotations
+
+from typing import Any, Union
+
+from . import activations, initializers
+from .adapter import PPOAdapter
+from .containers import Sequential
+from .feedforward import Dense
+from .normalizer import Normalizer
+from .sampling_layers import NormalTanhSampler
+from .types import Rngs, StatefulModule
+
+
+def make_mlp_layers(sizes: list[int], rngs: Rngs, activation: Any = activations.relu,
+                    activation_last_layer: bool = True, **linear_kwargs) -> list[Dense]:
+    layers = []
+    for i, (din, dout) in enumerate(zip(sizes[:-1], sizes[1:])):
+        is_last = i == len(sizes) - 2
+        act = activation if (not is_last or activation_last_layer) else None
+        layers.append(Dense(din, dout, rngs, activation=act, **linear_kwargs))
+    return layers
+
+
+def make_mlp(sizes: list[int], rngs: Rngs, activation: Any = activations.relu,
+             activation_last_layer: bool = True, **linear_kwargs) -> Sequential:
+    return Sequential(
+        make_mlp_layers(sizes, rngs, activation, activation_last_layer, **linear_kwargs))
+
+
+def make_mlp_actor_critic(
+    obs_size: int,
+    action_size: int,
+    actor_hidden_sizes: list[int],
+    critic_hidden_sizes: list[int],
+    rngs: Rngs,
+    activation: Union[Any, str] = activations.relu,
+    normalize_obs: bool = True,
+    initializer_scale: float = 1.0,
+    entropy_weight: float = 1e-2,
+    min_std: float = 1e-1,
+    std_scale: float = 1.0,
+) -> StatefulModule:
+    """Sequential([Normalizer(obs_size)?, PPOAdapter(action=Sequential([actor...,
+    NormalTanhSampler]), value=critic)]) — factories.py:88-146."""
+    if isinstance(activation, str):
+        activation = {"swish": activations.swish, "tanh": activations.tanh,
+                      "relu": activations.relu}[activation]
+    kernel_init = initializers.variance_scaling(initializer_scale, "fan_in", "uniform")
+    actor_layers = make_mlp_layers([obs_size] + list(actor_hidden_sizes) + [action_size * 2],
+                                   rngs, activation, activation_last_layer=False,
+                                   kernel_init=kernel_init)
+    critic = make_mlp([obs_size] + list(critic_hidden_sizes) + [1], rngs, activation,
+                      activation_last_layer=False, kernel_init=kernel_init)
+    sampler = NormalTanhSampler(rngs, entropy_weight=entropy_weight, min_std=min_std,
+                                std_scale=std_scale)
+    adapter = PPOAdapter(action=Sequential([*actor_layers, sampler]), value=critic)
+    if normalize_obs:
+        return Sequential([Normalizer(obs_size), adapter])
+    return adapter

@@ -1,18 +1,37 @@
 """Thin Python wrappers over the libmippo C ABI (one per entry point).
 
 Each wrapper validates shapes/dtypes on the host (so a kernel never sees an
-operand it was not sized for), allocates the outputs with torch, and enqueues
-the kernel on torch's current stream.  No wrapper synchronises.
+operand it was not sized for), allocates outputs with torch, and enqueues the
+kernel on torch's current stream.  No wrapper synchronises, and none falls back
+to torch arithmetic: a CPU tensor or a missing library raises `MippoError`.
 """
 from __future__ import annotations
 
 import torch
 
-from . import _lib
 from ._lib import MippoError, check, lib, ptr, stream
 
 f32 = torch.float32
+f64 = torch.float64
 u8 = torch.uint8
+i64 = torch.int64
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
+ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "tanh": ACT_TANH,
+             "swish": ACT_SWISH}
+
+# Workspaces are keyed by (device, tag, bytes) and never freed or regrown, so a
+# pointer baked into a captured HIP graph stays valid for the process lifetime.
+_workspaces: dict = {}
+
+
+def workspace(device, tag: str, nbytes: int) -> torch.Tensor:
+    key = (str(device), tag, int(nbytes))
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
 
 
 def _as_u8(t: torch.Tensor) -> torch.Tensor:
@@ -24,39 +43,294 @@ def _as_u8(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def gae(
-    rewards: torch.Tensor,
-    values: torch.Tensor,
-    last_value: torch.Tensor,
-    done: torch.Tensor,
-    truncated: torch.Tensor,
-    gamma: float,
-    lambda_: float,
-    with_targets: bool = False,
-    out: torch.Tensor | None = None,
-    out_targets: torch.Tensor | None = None,
-):
-    """GAE reverse scan over `[T, N]` (reference ppo.py:351-394).
+def _need(cond: bool, msg: str) -> None:
+    if not cond:
+        raise MippoError(msg)
 
-    Returns `advantages` or `(advantages, targets)` with `targets = V + A`.
-    """
-    if rewards.dim() != 2:
-        raise MippoError(f"rewards must be [T, N], got {tuple(rewards.shape)}")
+
+# ---------------------------------------------------------------- a13: GAE
+def gae(rewards, values, last_value, done, truncated, gamma: float, lambda_: float,
+        with_targets: bool = False, out=None, out_targets=None):
+    """GAE reverse scan over `[T, N]` (reference ppo.py:351-394).
+    Returns `advantages` or `(advantages, targets)` with `targets = V + A`."""
+    _need(rewards.dim() == 2, f"rewards must be [T, N], got {tuple(rewards.shape)}")
     T, N = rewards.shape
-    if values.shape != (T, N) or done.shape != (T, N) or truncated.shape != (T, N):
-        raise MippoError("gae: values/done/truncated must match rewards [T, N]")
-    if last_value.shape != (N,):
-        raise MippoError(f"gae: last_value must be [{N}], got {tuple(last_value.shape)}")
+    _need(values.shape == (T, N) and done.shape == (T, N) and truncated.shape == (T, N),
+          "gae: values/done/truncated must match rewards [T, N]")
+    _need(last_value.shape == (N,), f"gae: last_value must be [{N}]")
     done = _as_u8(done)
     truncated = _as_u8(truncated)
     adv = out if out is not None else torch.empty_like(rewards)
     tgt = None
     if with_targets:
         tgt = out_targets if out_targets is not None else torch.empty_like(rewards)
-    rc = lib().mi_gae_f32(
-        ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32),
-        ptr(done, u8), ptr(truncated, u8), ptr(adv, f32), ptr(tgt, f32),
-        T, N, float(gamma), float(lambda_), stream(),
-    )
+    rc = lib().mi_gae_f32(ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32),
+                          ptr(done, u8), ptr(truncated, u8), ptr(adv, f32), ptr(tgt, f32),
+                          T, N, float(gamma), float(lambda_), stream())
     check(rc, "mi_gae_f32")
     return (adv, tgt) if with_targets else adv
+
+
+# ------------------------------------------------------- a8 / a16: normaliser
+def normalize_fwd(x, mean, m2, counter, epsilon: float, out=None):
+    F = mean.numel()
+    _need(F >= 1 and tuple(x.shape[x.dim() - mean.dim():]) == tuple(mean.shape),
+          "normalize_fwd: trailing dims of x must equal the statistics' shape")
+    M = x.numel() // F
+    out = out if out is not None else torch.empty_like(x)
+    check(lib().mi_normalize_fwd_f32(ptr(x, f32), ptr(mean, f32), ptr(m2, f32), ptr(counter, f32),
+                                     float(epsilon), ptr(out, f32), M, F, stream()),
+          "mi_normalize_fwd_f32")
+    return out
+
+
+def normalize_bwd(g_out, m2, counter, epsilon: float):
+    F = m2.numel()
+    M = g_out.numel() // F
+    g_x = torch.empty_like(g_out)
+    check(lib().mi_normalize_bwd_f32(ptr(g_out, f32), ptr(m2, f32), ptr(counter, f32),
+                                     float(epsilon), ptr(g_x, f32), M, F, stream()),
+          "mi_normalize_bwd_f32")
+    return g_x
+
+
+def welford_batch_stats(x: torch.Tensor, F: int) -> torch.Tensor:
+    """(n, mean, sum of squared deviations) per column of x viewed as [M, F];
+    returns a [3, F] tensor."""
+    _need(x.numel() % F == 0 and x.numel() > 0, "welford_batch_stats: bad shape")
+    M = x.numel() // F
+    nbytes = lib().mi_welford_workspace_bytes(M, F)
+    _need(nbytes >= 0, "mi_welford_workspace_bytes failed")
+    ws = workspace(x.device, "welford", nbytes)
+    stats = torch.empty(3, F, dtype=f32, device=x.device)
+    check(lib().mi_welford_batch_stats_f32(ptr(x, f32), ptr(stats, f32), ptr(ws), M, F, stream()),
+          "mi_welford_batch_stats_f32")
+    return stats
+
+
+def welford_merge(mean, m2, counter, batch_stats, advance_counter: bool) -> None:
+    F = mean.numel()
+    _need(batch_stats.shape == (3, F), "welford_merge: batch_stats must be [3, F]")
+    check(lib().mi_welford_merge_f32(ptr(mean, f32), ptr(m2, f32), ptr(counter, f32),
+                                     ptr(batch_stats, f32), F, int(bool(advance_counter)),
+                                     stream()), "mi_welford_merge_f32")
+
+
+# ----------------------------------------------------------- a10: sampler
+def tanh_gauss_fwd(mean_and_std, extras, rng_state, offset_add: int, *, min_std: float,
+                   std_scale: float, entropy_weight: float, deterministic: bool,
+                   eps=None, eps2=None, want_action=True, want_raw=True, want_reg=True,
+                   want_stats=False):
+    """Returns dict(raw, action, log_likelihood, reg, mu, sigma) (None where not asked)."""
+    _need(mean_and_std.dim() == 2 and mean_and_std.shape[1] % 2 == 0,
+          "tanh_gauss_fwd: mean_and_std must be [B, 2A]")
+    B, A2 = mean_and_std.shape
+    A = A2 // 2
+    dev = mean_and_std.device
+    if extras is not None:
+        _need(extras.shape == (B, A), "tanh_gauss_fwd: extras must be [B, A]")
+    for e in (eps, eps2):
+        if e is not None:
+            _need(e.shape == (B, A), "tanh_gauss_fwd: injected noise must be [B, A]")
+    mk = lambda *s: torch.empty(*s, dtype=f32, device=dev)
+    raw = mk(B, A) if (want_raw and extras is None) else None
+    action = mk(B, A) if want_action else None
+    ll = mk(B)
+    reg = mk(B) if want_reg else None
+    mu = mk(B, A) if want_stats else None
+    sigma = mk(B, A) if want_stats else None
+    check(lib().mi_tanh_gauss_fwd_f32(
+        ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
+        ptr(eps, f32), ptr(eps2, f32), ptr(raw, f32), ptr(action, f32), ptr(ll, f32),
+        ptr(reg, f32), ptr(mu, f32), ptr(sigma, f32), B, A, float(min_std), float(std_scale),
+        float(entropy_weight), int(bool(deterministic)), stream()), "mi_tanh_gauss_fwd_f32")
+    return dict(raw=raw if extras is None else extras, action=action, log_likelihood=ll,
+                reg=reg, mu=mu, sigma=sigma)
+
+
+def tanh_gauss_bwd(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float, *,
+                   min_std: float, std_scale: float, entropy_weight: float, eps2=None):
+    B, A2 = mean_and_std.shape
+    A = A2 // 2
+    _need(extras.shape == (B, A), "tanh_gauss_bwd: extras must be [B, A]")
+    if g_ll is not None:
+        _need(g_ll.shape == (B,), "tanh_gauss_bwd: g_ll must be [B]")
+    g = torch.empty_like(mean_and_std)
+    check(lib().mi_tanh_gauss_bwd_f32(
+        ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
+        ptr(eps2, f32), ptr(g_ll, f32), float(g_reg), ptr(g, f32), B, A, float(min_std),
+        float(std_scale), float(entropy_weight), stream()), "mi_tanh_gauss_bwd_f32")
+    return g
+
+
+def philox_normal(rng_state, offset_add: int, n: int):
+    dev = rng_state.device
+    eps = torch.empty(n, dtype=f32, device=dev)
+    eps2 = torch.empty(n, dtype=f32, device=dev)
+    check(lib().mi_philox_normal_f32(ptr(rng_state), int(offset_add), ptr(eps, f32),
+                                     ptr(eps2, f32), n, stream()), "mi_philox_normal_f32")
+    return eps, eps2
+
+
+def rng_advance(rng_state, n: int) -> None:
+    check(lib().mi_rng_advance(ptr(rng_state), int(n), stream()), "mi_rng_advance")
+
+
+def make_rng_state(seed: int, device, offset: int = 0) -> torch.Tensor:
+    """Device-resident {seed, offset} pair (uint64 stored as int64 bit patterns)."""
+    def s64(v):
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >= (1 << 63) else v
+    return torch.tensor([s64(int(seed)), s64(int(offset))], dtype=i64, device=device)
+
+
+# -------------------------------------------------------------- a9: dense
+def dense_fwd(x, w, bias, act: int, want_preact: bool = False):
+    _need(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0],
+          f"dense_fwd: x {tuple(x.shape)} @ w {tuple(w.shape)}")
+    M, K = x.shape
+    N = w.shape[1]
+    if bias is not None:
+        _need(bias.shape == (N,), "dense_fwd: bias must be [N]")
+    y = torch.empty(M, N, dtype=f32, device=x.device)
+    pre = torch.empty(M, N, dtype=f32, device=x.device) if want_preact else None
+    check(lib().mi_dense_fwd_f32(ptr(x, f32), ptr(w, f32), ptr(bias, f32), ptr(y, f32),
+                                 ptr(pre, f32), M, K, N, int(act), stream()), "mi_dense_fwd_f32")
+    return (y, pre) if want_preact else y
+
+
+def dense_bwd_dx(g_y, aux, w, act: int):
+    M, N = g_y.shape
+    K = w.shape[0]
+    _need(w.shape == (K, N), "dense_bwd_dx: w must be [K, N]")
+    if act != ACT_NONE:
+        _need(aux is not None and aux.shape == (M, N), "dense_bwd_dx: aux must be [M, N]")
+    g_x = torch.empty(M, K, dtype=f32, device=g_y.device)
+    check(lib().mi_dense_bwd_dx_f32(ptr(g_y, f32), ptr(aux, f32) if act != ACT_NONE else None,
+                                    ptr(w, f32), ptr(g_x, f32), M, K, N, int(act), stream()),
+          "mi_dense_bwd_dx_f32")
+    return g_x
+
+
+def dense_bwd_dw(x, g_y, aux, g_w, g_b, act: int, accumulate: bool = True) -> None:
+    M, K = x.shape
+    N = g_y.shape[1]
+    _need(g_y.shape == (M, N) and g_w.shape == (K, N), "dense_bwd_dw: shape mismatch")
+    if g_b is not None:
+        _need(g_b.shape == (N,), "dense_bwd_dw: g_b must be [N]")
+    if act != ACT_NONE:
+        _need(aux is not None and aux.shape == (M, N), "dense_bwd_dw: aux must be [M, N]")
+    nbytes = lib().mi_dense_bwd_dw_workspace_bytes(M, K, N)
+    _need(nbytes >= 0, "mi_dense_bwd_dw_workspace_bytes failed")
+    ws = workspace(x.device, "dense_dw", nbytes)
+    check(lib().mi_dense_bwd_dw_f32(ptr(x, f32), ptr(g_y, f32),
+                                    ptr(aux, f32) if act != ACT_NONE else None, ptr(g_w, f32),
+                                    ptr(g_b, f32), ptr(ws), M, K, N, int(act),
+                                    int(bool(accumulate)), stream()), "mi_dense_bwd_dw_f32")
+
+
+# ------------------------------------------------------------- a14: loss
+def _loss_ws(device):
+    return workspace(device, "loss", lib().mi_ppo_loss_workspace_bytes(1))
+
+
+def adv_stats(adv: torch.Tensor) -> torch.Tensor:
+    """fp64 [3] = (sum, sum of squares, count) of the advantages."""
+    n = adv.numel()
+    stats = torch.empty(3, dtype=f64, device=adv.device)
+    check(lib().mi_adv_stats_f32(ptr(adv, f32), n, ptr(stats, f64), ptr(_loss_ws(adv.device)),
+                                 stream()), "mi_adv_stats_f32")
+    return stats
+
+
+def ppo_loss(ll_new, ll_old, adv, values, reg, stats, clip_range: float, critic_weight: float,
+             loss_out: torch.Tensor | None = None):
+    """Returns (g_ll, g_v, loss_out[4] = actor, critic, regularization, clip_frac)."""
+    n = ll_new.numel()
+    for t in (ll_old, adv, values):
+        _need(t.numel() == n, "ppo_loss: operand sizes differ")
+    if reg is not None:
+        _need(reg.numel() == n, "ppo_loss: reg size differs")
+    dev = ll_new.device
+    g_ll = torch.empty(n, dtype=f32, device=dev)
+    g_v = torch.empty(n, dtype=f32, device=dev)
+    if loss_out is None:
+        loss_out = torch.empty(4, dtype=f32, device=dev)
+    check(lib().mi_ppo_loss_f32(ptr(ll_new, f32), ptr(ll_old, f32), ptr(adv, f32),
+                                ptr(values, f32), ptr(reg, f32), ptr(stats, f64),
+                                float(clip_range), float(critic_weight), ptr(g_ll, f32),
+                                ptr(g_v, f32), ptr(loss_out, f32), ptr(_loss_ws(dev)), n,
+                                stream()), "mi_ppo_loss_f32")
+    return g_ll, g_v, loss_out
+
+
+# -------------------------------------------------------- a15: optimiser
+def begin_grad_step(grads: torch.Tensor, step: torch.Tensor | None) -> None:
+    check(lib().mi_begin_grad_step_f32(ptr(grads, f32), grads.numel(), ptr(step, i64), stream()),
+          "mi_begin_grad_step_f32")
+
+
+def global_norm(grads: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    n = grads.numel()
+    out = out if out is not None else torch.empty(1, dtype=f32, device=grads.device)
+    ws = workspace(grads.device, "gnorm", lib().mi_global_norm_workspace_bytes(n))
+    check(lib().mi_global_norm_f32(ptr(grads, f32), n, ptr(out, f32), ptr(ws), stream()),
+          "mi_global_norm_f32")
+    return out
+
+
+def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: float = 0.999,
+              eps: float = 1e-8, weight_decay: float = 0.0, grad_norm=None,
+              max_norm: float = 0.0) -> None:
+    n = params.numel()
+    for t in (grads, m, v):
+        _need(t.numel() == n, "adam_step: arena sizes differ")
+    check(lib().mi_adam_step_f32(ptr(params, f32), ptr(grads, f32), ptr(m, f32), ptr(v, f32), n,
+                                 float(lr), float(b1), float(b2), float(eps),
+                                 float(weight_decay), ptr(step, i64), ptr(grad_norm, f32),
+                                 float(max_norm), stream()), "mi_adam_step_f32")
+
+
+# ------------------------------------------------------ a5 / a7: movement
+def gather_cols(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """`src[:, idx]` for a time-major `[T, N, ...]` tensor of any dtype."""
+    _need(src.dim() >= 2, "gather_cols: src must be [T, N, ...]")
+    _need(idx.dim() == 1 and idx.dtype == i64, "gather_cols: idx must be int64 [L]")
+    T, N = src.shape[:2]
+    L = idx.numel()
+    row_bytes = src.element_size()
+    for s in src.shape[2:]:
+        row_bytes *= s
+    dst = torch.empty((T, L, *src.shape[2:]), dtype=src.dtype, device=src.device)
+    if row_bytes == 0:
+        return dst
+    s_ = src.view(torch.uint8) if src.dtype == torch.bool else src
+    d_ = dst.view(torch.uint8) if dst.dtype == torch.bool else dst
+    check(lib().mi_gather_cols(ptr(s_), ptr(idx, i64), ptr(d_), T, N, L, row_bytes, stream()),
+          "mi_gather_cols")
+    return dst
+
+
+def select_rows(mask: torch.Tensor, on_true: torch.Tensor, on_false: torch.Tensor,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """`where(mask[:, None...], on_true, on_false)` over the leading axis; `on_true`
+    may be a single row (shape `on_false.shape[1:]`) that is broadcast."""
+    B = mask.shape[0]
+    _need(on_false.shape[0] == B, "select_rows: leading dim must equal the mask's")
+    row_bytes = on_false.element_size()
+    for s in on_false.shape[1:]:
+        row_bytes *= s
+    if on_true.shape == on_false.shape:
+        stride = row_bytes
+    elif on_true.shape == on_false.shape[1:]:
+        stride = 0
+    else:
+        raise MippoError("select_rows: on_true must match on_false or be one row")
+    _need(on_true.dtype == on_false.dtype, "select_rows: dtype mismatch")
+    out = out if out is not None else torch.empty_like(on_false)
+    if row_bytes == 0 or B == 0:
+        return out
+    v = lambda t: t.view(torch.uint8) if t.dtype == torch.bool else t
+    check(lib().mi_select_rows(ptr(_as_u8(mask)), ptr(v(on_true)), stride, ptr(v(on_false)),
+                               ptr(v(out)), B, row_bytes, stream()), "mi_select_rows")
+    return out

@@ -1,0 +1,96 @@
+"""Flat-arena optimiser in the role of `nnx.Optimizer(networks,
+optax.chain([clip_by_global_norm?], adam | adamw), wrt=nnx.Param)`
+(`nnx_ppo/algorithms/ppo.py:555-569`).
+
+All parameters of a network are re-homed into ONE contiguous fp32 arena (and
+their gradients / Adam moments into three more), each parameter starting on a
+256-byte boundary, so that
+  * the whole optimiser step is one kernel launch (`mi_adam_step_f32`),
+  * the multi-GPU gradient exchange is one all-reduce of one buffer,
+  * zeroing gradients + advancing the step counter is one launch.
+`Parameter.data` / `.grad` become views of the arenas; modules keep working
+unchanged.  The step counter and gradient norm stay on the device."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops, parallel
+from .networks.types import StatefulModule
+
+_ALIGN = 64  # floats (256 B)
+
+
+class Optimizer:
+    def __init__(self, networks: StatefulModule, learning_rate: float = 1e-4,
+                 gradient_clipping: Optional[float] = None,
+                 weight_decay=None, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
+                 device=None):
+        self.learning_rate = float(learning_rate)
+        self.gradient_clipping = gradient_clipping
+        # ppo.py:558-566: None -> adam; True -> adamw with optax's default 1e-4;
+        # a float -> adamw with that decay.
+        if weight_decay is None or weight_decay is False:
+            self.weight_decay = 0.0
+        elif weight_decay is True:
+            self.weight_decay = 1e-4
+        else:
+            self.weight_decay = float(weight_decay)
+        self.b1, self.b2, self.eps = b1, b2, eps
+        named = networks.named_parameters()
+        device = torch.device(device) if device is not None else networks.device
+        self.device = device
+        offsets = []
+        total = 0
+        for _, p in named:
+            offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n = max(total, _ALIGN)
+        self.names = [n for n, _ in named]
+        self.offsets = offsets
+        self.shapes = [tuple(p.shape) for _, p in named]
+        self.params = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.m = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=device)
+        for (_, p), off in zip(named, offsets):
+            n = p.numel()
+            self.params[off:off + n].copy_(p.data.reshape(-1).to(device))
+            p.data = self.params[off:off + n].view(p.shape)
+            p.grad = self.grads[off:off + n].view(p.shape)
+
+    # ---- one gradient step = begin() ... backward ... update() --------------------
+    def begin(self) -> None:
+        """Zero the gradient arena and advance the step counter (one launch)."""
+        ops.begin_grad_step(self.grads, self.step)
+
+    def compute_grad_norm(self) -> torch.Tensor:
+        return ops.global_norm(self.grads, out=self.grad_norm)
+
+    def update(self, have_norm: bool = False) -> None:
+        """All-reduce (if sharded), optional global-norm clip, Adam(W)."""
+        if parallel.is_distributed():
+            parallel.allreduce_mean_(self.grads)
+            have_norm = False
+        gn = None
+        if self.gradient_clipping is not None:
+            gn = self.grad_norm if have_norm else self.compute_grad_norm()
+        ops.adam_step(self.params, self.grads, self.m, self.v, self.step,
+                      lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
+                      weight_decay=self.weight_decay, grad_norm=gn,
+                      max_norm=float(self.gradient_clipping or 0.0))
+
+    # ---- state export (checkpoint callbacks) ----------------------------------------
+    def state_dict(self) -> dict:
+        return {"params": self.params.clone(), "m": self.m.clone(), "v": self.v.clone(),
+                "step": self.step.clone(), "names": list(self.names),
+                "offsets": list(self.offsets), "shapes": list(self.shapes)}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.params.copy_(sd["params"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step.copy_(sd["step"])

@@ -1,0 +1,98 @@
+"""Integer key derivation for env resets, minibatch permutations and seeds.
+
+The reference threads `jax.random` keys (`ppo.py:271,284-294,544-548`,
+`rollout.py:57-59`, `episode_wrapper.py:26-30`).  JAX's threefry streams cannot
+be reproduced without JAX (parity on RNG *values* is unpinned, SURVEY §7 hard
+part 3), so keys here are int64 tensors mixed with splitmix64.  Everything is
+plain integer torch arithmetic (wrap-around multiply, xor, logical shift), so
+the same key gives bit-identical children, integers and permutations on CPU
+and on the GPU — index parity between the oracle run and the HIP run is exact.
+"""
+from __future__ import annotations
+
+import torch
+
+_GOLDEN = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
+_M1 = -4658895280553007687  # 0xBF58476D1CE4E5B9
+_M2 = -7723592293110705685  # 0x94D049BB133111EB
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    """Logical shift right on int64 (torch's >> is arithmetic)."""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix(z: torch.Tensor) -> torch.Tensor:
+    z = (z ^ _lsr(z, 30)) * _M1
+    z = (z ^ _lsr(z, 27)) * _M2
+    return z ^ _lsr(z, 31)
+
+
+def key(seed: int, device=None) -> torch.Tensor:
+    """Scalar int64 key from an integer seed (`jax.random.key`)."""
+    s = int(seed) & 0xFFFFFFFFFFFFFFFF
+    if s >= 1 << 63:
+        s -= 1 << 64
+    return _mix(torch.tensor(s, dtype=torch.int64, device=device) + _GOLDEN)
+
+
+def split(k: torch.Tensor, num=2) -> torch.Tensor:
+    """Children of `k` (any shape): result shape `k.shape + shape(num)`
+    (`jax.random.split(key, num)`; `num` may be an int or a shape tuple)."""
+    shape = (num,) if isinstance(num, int) else tuple(num)
+    n = 1
+    for s in shape:
+        n *= s
+    idx = torch.arange(1, n + 1, dtype=torch.int64, device=k.device)
+    out = _mix(k.unsqueeze(-1) + idx * _GOLDEN)
+    return out.reshape(*k.shape, *shape)
+
+
+def fold_in(k: torch.Tensor, data: int) -> torch.Tensor:
+    """`jax.random.fold_in`: a new key from a key and an integer."""
+    return _mix(k ^ _mix(torch.as_tensor(int(data), dtype=torch.int64, device=k.device) + _GOLDEN))
+
+
+def bits(k: torch.Tensor, shape=()) -> torch.Tensor:
+    """64 random bits per element: result `k.shape + shape` (int64)."""
+    shape = tuple(shape)
+    n = 1
+    for s in shape:
+        n *= s
+    idx = torch.arange(1, n + 1, dtype=torch.int64, device=k.device)
+    out = _mix(_mix(k).unsqueeze(-1) ^ (idx * _M2))
+    return out.reshape(*k.shape, *shape)
+
+
+def randint(k: torch.Tensor, shape, minval: int, maxval: int) -> torch.Tensor:
+    """Integers in [minval, maxval) (`jax.random.randint`); int64."""
+    span = int(maxval) - int(minval)
+    if span <= 0:
+        return torch.full((*k.shape, *tuple(shape)), int(minval), dtype=torch.int64,
+                          device=k.device)
+    b = _lsr(bits(k, shape), 1)  # non-negative 63-bit
+    return b % span + int(minval)
+
+
+def uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor:
+    """U[0,1) with 24 random bits — exact in fp32, identical on CPU and GPU."""
+    b = _lsr(bits(k, shape), 40)  # 24 bits
+    return b.to(dtype) * (1.0 / (1 << 24))
+
+
+def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor:
+    """Zero-mean unit-variance uniform noise, (u - 1/2)·sqrt(12).  One IEEE
+    multiply after exact operands, so CPU and GPU agree bit for bit; synthetic
+    envs use it where the reference's test envs draw `jax.random.normal`
+    (`test_dummies/mock_env.py:41-52`)."""
+    u = uniform(k, shape, dtype)
+    return (u - 0.5) * 3.4641016151377544
+
+
+def permutation(k: torch.Tensor, n: int) -> torch.Tensor:
+    """Random permutation of arange(n) (`jax.random.permutation(key, n)`):
+    stable argsort of n distinct-with-overwhelming-probability 64-bit hashes."""
+    if k.dim() != 0:
+        raise ValueError("permutation expects a scalar key")
+    h = bits(k, (n,))
+    return torch.argsort(h, stable=True)

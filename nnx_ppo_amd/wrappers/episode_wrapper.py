@@ -1,0 +1,41 @@
+"""EpisodeWrapper (counterpart of `nnx_ppo/wrappers/episode_wrapper.py:7-39`),
+batched: `info["step_counter"]` is int64 `[n_envs]`, `info["truncated"]` bool
+`[n_envs]`, `done` is returned as float like the reference (`.astype(float)`).
+Counters and flags are integer / boolean torch ops — bit-exact on any device."""
+from __future__ import annotations
+
+import torch
+
+from .. import random as rnd
+
+
+class EpisodeWrapper:
+    def __init__(self, env, max_len: int):
+        self.env = env
+        self.max_len = max_len
+
+    def step(self, state, action):
+        next_state = self.env.step(state, action)
+        next_state.info["step_counter"] = state.info["step_counter"] + 1
+        prev_trunc = next_state.info.get("truncated", False)
+        over = next_state.info["step_counter"] >= self.max_len
+        truncated = over if prev_trunc is False else torch.logical_or(prev_trunc, over)
+        next_state.info["truncated"] = truncated
+        done = torch.logical_or(next_state.done.to(torch.bool), truncated)
+        return next_state.replace(done=done.to(torch.float32))
+
+    def reset(self, rng: torch.Tensor):
+        keys = rnd.split(rng)  # [..., 2]: base_rng, step_counter_rng
+        base_rng, step_counter_rng = keys[..., 0], keys[..., 1]
+        next_state = self.env.reset(base_rng)
+        next_state.info["step_counter"] = rnd.randint(step_counter_rng, (), 0, self.max_len // 2)
+        next_state.info["truncated"] = torch.zeros(rng.shape, dtype=torch.bool, device=rng.device)
+        return next_state
+
+    @property
+    def observation_size(self):
+        return self.env.observation_size
+
+    @property
+    def action_size(self):
+        return self.env.action_size
