@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Benchmark of the PPO hot path: env-steps/sec on a synthetic 4096-env x 30-step
+rollout + update (BASELINE.json configs[1]; per GPU when sharded).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--compute f32|bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full `ppo_step` iteration (rollout -> n_epochs x n_minibatches
+replay/GAE/loss/Adam steps -> normaliser update) including the reference's one
+host sync per iteration (`int(steps_taken)`, nnx_ppo/algorithms/ppo.py:209).
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+`roofline` (dominant kernel, timed live with HIP events on the launch stream)
+and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+# workload = BASELINE.json configs[1] (C2 in SURVEY §8): CartpoleBalance-shaped
+N_ENVS = 4096
+T = 30
+OBS, ACT = 5, 1
+ACTOR_H, CRITIC_H = [64, 64, 64, 64], [256, 256]
+N_EPOCHS, N_MB = 4, 4
+SEED = 17
+FWD_FLOP_PER_SAMPLE = 2 * (OBS * 64 + 3 * 64 * 64 + 64 * 2 * ACT + OBS * 256 + 256 * 256 + 256)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16
+
+
+def build(device):
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    env = EpisodeWrapper(cartpole_shaped(max_steps=1000), 1000)
+    net = factories.make_mlp_actor_critic(OBS, ACT, ACTOR_H, CRITIC_H, Rngs(SEED),
+                                          normalize_obs=True)
+    ts = ppo.new_training_state(env, net, N_ENVS, SEED, 1e-4, device=device)
+    return env, net, ts
+
+
+def one_iter(env, ts):
+    from nnx_ppo_amd.algorithms import ppo
+
+    ts, metrics = ppo.ppo_step(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, False, N_EPOCHS, N_MB)
+    _ = int(ts.steps_taken)  # the reference's per-iteration host sync
+    return ts, metrics
+
+
+def roofline_of_dominant_kernel(env, ts):
+    """One instrumented iteration: every C-ABI call bracketed by HIP events on
+    the launch stream.  Dominant kernel = the dense GEMM family (MFMA-bound);
+    achieved = algorithmic FLOPs (2*M*K*N per GEMM) / device time."""
+    from nnx_ppo_amd import _lib
+
+    with _lib.profiler as prof:
+        ts, _ = one_iter(env, ts)
+    summ = prof.summary()
+    flops = 0.0
+    ms = 0.0
+    per_kernel = {}
+    for name, d in summ.items():
+        per_kernel[name] = {"calls": d["calls"], "ms": round(d["ms"], 4)}
+        if name in ("mi_dense_fwd_f32", "mi_dense_bwd_dx_f32", "mi_dense_bwd_dw_f32"):
+            for ints, t_ms in d["args"]:
+                M, K, N = ints[0], ints[1], ints[2]
+                flops += 2.0 * M * K * N
+                ms += t_ms
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    dom = max(("mi_dense_fwd_f32", "mi_dense_bwd_dx_f32", "mi_dense_bwd_dw_f32"),
+              key=lambda k: summ.get(k, {"ms": 0})["ms"])
+    roof = {
+        "bound": "mfma", "kernel": "dense GEMM family (fwd, dX, dW); largest: " + dom,
+        "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "gemm_ms_per_iter": round(ms, 3), "gemm_flop_per_iter": flops,
+    }
+    return ts, roof, per_kernel
+
+
+def cpu_baseline(iters: int = 2):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference's ppo_step,
+    autograd through the T-step scan) on the same workload, on this box's host
+    cores.  Bounded sample: 1 warm-up + `iters` timed iterations at full C2 size."""
+    from nnx_ppo_amd import random as keys
+    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+    from oracle import networks as on
+    from oracle import ppo as op
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    net = factories.make_mlp_actor_critic(OBS, ACT, ACTOR_H, CRITIC_H, Rngs(SEED))
+    onet = on.from_product(net, torch.float32)
+    env = EpisodeWrapper(cartpole_shaped(max_steps=1000), 1000)
+    ts = op.new_training_state(env, onet, N_ENVS, SEED, keys)
+    ts, _ = op.ppo_step(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, N_EPOCHS, N_MB, keys)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ts, _ = op.ppo_step(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, N_EPOCHS, N_MB, keys)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(N_ENVS * T * iters / dt, 1), "unit": "env-steps/s", "cores": threads,
+        "kind": "port",
+        "sample": f"{iters} timed ppo_step iterations (+1 warm-up) of the CPU oracle at the "
+                  f"full workload ({N_ENVS} envs x {T} steps, {N_EPOCHS}x{N_MB} grad steps), "
+                  "torch-CPU fp32",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    env, net, ts = build(device)
+    for _ in range(args.warmup):
+        ts, _ = one_iter(env, ts)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts, metrics = one_iter(env, ts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = per_kernel = None
+    if rank == 0:
+        pass
+    # instrumented iteration on every rank (collectives must match), reported by rank 0
+    ts, roof, per_kernel = roofline_of_dominant_kernel(env, ts)
+
+    if rank == 0:
+        total_env_steps = world * N_ENVS * T * args.steps
+        line = {
+            "metric": "env-steps/sec (whole node), 4096-env x 30-step PPO rollout+update",
+            "value": round(total_env_steps / elapsed, 1),
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: CartpoleBalance-shaped synthetic env "
+                            "(obs 5, act 1), MLP actor 4x64 / critic 2x256, "
+                            f"n_envs={N_ENVS}/GPU, rollout_length={T}, {N_EPOCHS} epochs x "
+                            f"{N_MB} minibatches, normalize_obs, Adam",
+                "n_envs_per_gpu": N_ENVS, "rollout_length": T,
+                "global_n_envs": world * N_ENVS, "parallelism": f"env-sharded dp{world}",
+            },
+            "roofline": roof,
+            "kernels_ms_per_iter": per_kernel,
+            "final_losses": {k: float(v) for k, v in metrics.items() if k.startswith("losses/")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,13 +78,75 @@ def _load() -> ctypes.CDLL:
     return lib
 
 
-_lib: ctypes.CDLL | None = None
+class Profiler:
+    """Per-entry-point device timing: when active, every C-ABI call is bracketed by
+    HIP events recorded on torch's current stream (the stream the kernels are
+    enqueued on).  `summary()` synchronises and returns, per symbol, the call
+    count, total / average milliseconds and the integer arguments of each call
+    (shapes), from which bench.py derives algorithmic FLOPs / bytes."""
+
+    def __init__(self):
+        self.active = False
+        self.records: list = []
+
+    def __enter__(self):
+        self.records = []
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        self.active = False
+        return False
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out: dict = {}
+        for name, ints, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": []})
+            d["calls"] += 1
+            ms = e0.elapsed_time(e1)
+            d["ms"] += ms
+            d["args"].append((ints, ms))
+        for d in out.values():
+            d["avg_ms"] = d["ms"] / max(d["calls"], 1)
+        return out
 
 
-def lib() -> ctypes.CDLL:
+profiler = Profiler()
+
+
+class _Proxy:
+    """Attribute access returns the raw ctypes function, or an event-bracketed
+    wrapper of it while the profiler is active."""
+
+    def __init__(self, cdll: ctypes.CDLL):
+        self._cdll = cdll
+
+    def __getattr__(self, name: str):
+        fn = getattr(self._cdll, name)
+        if not profiler.active:
+            return fn
+
+        def timed(*args):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            ints = tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 40))
+            profiler.records.append((name, ints, e0, e1))
+            return rc
+
+        return timed
+
+
+_lib: _Proxy | None = None
+
+
+def lib() -> _Proxy:
     global _lib
     if _lib is None:
-        _lib = _load()
+        _lib = _Proxy(_load())
     return _lib
 
 

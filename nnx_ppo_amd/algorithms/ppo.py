@@ -92,7 +92,8 @@ def train_ppo(
             eval_env, networks, config.eval.n_envs, config.eval.max_episode_length,
             rnd.key(config.seed, device), config.eval.logging_percentiles)
         if measure_throughput:
-            torch.cuda.synchronize()
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
             elapsed = time.perf_counter() - t0
             eval_metrics = dict(eval_metrics)
             eval_metrics["throughput/eval_sps"] = (
