@@ -1,0 +1,105 @@
+"""N>1 path on CPU: world_size-2 `gloo` process group exercising every
+exchange the env-sharded PPO step makes (nnx_ppo_amd/parallel.py): gradient
+all-reduce-mean, advantage-statistics all-reduce, rank-ordered Chan merge of
+normaliser batch statistics — each checked against the single-process value
+on the union of the shards."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard_data(rank, world):
+    rng = np.random.default_rng(1234)
+    x = rng.normal(2.0, 3.0, size=(world, 30 * 64, 5)).astype(np.float32)
+    adv = rng.normal(0.5, 2.0, size=(world, 30 * 16)).astype(np.float32)
+    grads = rng.normal(size=(world, 1000)).astype(np.float32)
+    return x, adv, grads
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nnx_ppo_amd import parallel
+    from nnx_ppo_amd import random as keys
+
+    assert parallel.is_distributed() and parallel.world_size() == world
+    x, adv, grads = _shard_data(rank, world)
+    # (3) normaliser batch statistics: per-shard (n, mean, M2) -> merged, identical on all ranks
+    xs = x[rank].astype(np.float64)
+    stats = torch.tensor(np.stack([np.full(5, xs.shape[0]), xs.mean(0),
+                                   ((xs - xs.mean(0)) ** 2).sum(0)]), dtype=torch.float32)
+    merged = parallel.merge_batch_stats(stats)
+    # (2) advantage statistics triple
+    a = adv[rank].astype(np.float64)
+    tri = torch.tensor([a.sum(), (a * a).sum(), float(a.size)], dtype=torch.float64)
+    parallel.allreduce_sum_(tri)
+    # (1) gradient mean
+    g = torch.tensor(grads[rank])
+    parallel.allreduce_mean_(g)
+    # per-rank key folding gives distinct env / permutation streams
+    k = keys.fold_in(keys.key(17), 1 + parallel.rank())
+    torch.save({"merged": merged, "tri": tri, "g": g, "key": k}, f"{out_dir}/r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_exchanges(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(world)]
+    x, adv, grads = _shard_data(0, world)
+    allx = x.reshape(-1, 5).astype(np.float64)
+    for i in range(world):
+        m = r[i]["merged"].numpy()
+        assert m[0, 0] == allx.shape[0]
+        assert np.allclose(m[1], allx.mean(0), atol=1e-5)
+        assert np.allclose(m[2], ((allx - allx.mean(0)) ** 2).sum(0), rtol=1e-5)
+        a = adv.reshape(-1).astype(np.float64)
+        assert np.allclose(r[i]["tri"].numpy(), [a.sum(), (a * a).sum(), a.size], rtol=1e-12)
+        assert np.allclose(r[i]["g"].numpy(), grads.mean(0), atol=1e-6)
+    # replicas hold bit-identical merged statistics and gradients
+    assert torch.equal(r[0]["merged"], r[1]["merged"])
+    assert torch.equal(r[0]["g"], r[1]["g"])
+    assert int(r[0]["key"]) != int(r[1]["key"])
+
+
+def test_single_process_is_identity():
+    from nnx_ppo_amd import parallel
+
+    t = torch.arange(6, dtype=torch.float32).reshape(3, 2)
+    assert parallel.merge_batch_stats(t) is t
+    assert torch.equal(parallel.allreduce_mean_(t.clone()), t)
+    assert parallel.world_size() == 1 and parallel.rank() == 0
+
+
+def test_chan_merge_matches_global_moments():
+    from nnx_ppo_amd import parallel
+
+    rng = np.random.default_rng(0)
+    parts, data = [], []
+    for n in (7, 1, 300, 64):
+        x = rng.normal(size=(n, 3))
+        data.append(x)
+        parts.append(torch.tensor(np.stack([np.full(3, n), x.mean(0), ((x - x.mean(0)) ** 2).sum(0)])))
+    m = parallel.chan_merge(parts).numpy()
+    allx = np.concatenate(data)
+    assert np.allclose(m[0], allx.shape[0]) and np.allclose(m[1], allx.mean(0))
+    assert np.allclose(m[2], ((allx - allx.mean(0)) ** 2).sum(0))
