@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel from Python instead of replaying the captured "
+                         "HIP graph of the iteration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,8 +150,25 @@ def main():
     torch.cuda.set_device(device)
 
     env, net, ts = build(device)
+    if args.eager or world > 1:
+        ts_box = [ts]
+
+        def run_one():
+            ts_box[0], m = one_iter(env, ts_box[0])
+            return m
+    else:
+        from nnx_ppo_amd.algorithms.graph import GraphedPPOStep
+
+        graphed = GraphedPPOStep(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, False, N_EPOCHS,
+                                 N_MB, warmup=2)
+        ts_box = [graphed.ts]
+
+        def run_one():
+            ts_, m = graphed()
+            _ = int(ts_.steps_taken)  # the reference's per-iteration host sync
+            return m
     for _ in range(args.warmup):
-        ts, _ = one_iter(env, ts)
+        run_one()
 
     def barrier():
         if world > 1:
@@ -160,7 +180,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ts, metrics = one_iter(env, ts)
+        metrics = run_one()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -174,7 +194,7 @@ def main():
     if rank == 0:
         pass
     # instrumented iteration on every rank (collectives must match), reported by rank 0
-    ts, roof, per_kernel = roofline_of_dominant_kernel(env, ts)
+    ts, roof, per_kernel = roofline_of_dominant_kernel(env, ts_box[0])
 
     if rank == 0:
         total_env_steps = world * N_ENVS * T * args.steps
@@ -199,6 +219,7 @@ def main():
                 "n_envs_per_gpu": N_ENVS, "rollout_length": T,
                 "global_n_envs": world * N_ENVS, "parallelism": f"env-sharded dp{world}",
             },
+            "launch_mode": "eager" if args.eager else "hip-graph (one hipGraphLaunch per iteration)",
             "roofline": roof,
             "kernels_ms_per_iter": per_kernel,
             "final_losses": {k: float(v) for k, v in metrics.items() if k.startswith("losses/")},

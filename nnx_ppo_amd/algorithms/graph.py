@@ -1,0 +1,81 @@
+"""Whole-iteration HIP-graph capture of `ppo_step`.
+
+The reference compiles one XLA program per iteration with `nnx.jit(ppo_step)`
+(`nnx_ppo/algorithms/ppo.py:105,192-207`) and crosses the host/device boundary
+once per iteration.  The MI355X-native equivalent is not a tracing compiler but
+a captured HIP graph: one eager pass records every kernel launch of the
+iteration (rollout, minibatch permutations, 16 gradient steps, normaliser
+update, RNG advance) and each later iteration is ONE `hipGraphLaunch`.  At this
+workload's size the iteration is launch-bound (~1500 launches of tiny kernels),
+so removing the per-launch host cost is the first-order win.
+
+What makes the iteration capturable (and is required of user envs/modules):
+  * every kernel is enqueued on torch's current stream with caller-owned
+    buffers; nothing synchronises or reads a device value on the host;
+  * all iteration-to-iteration state is device-resident and updated in place:
+    parameters / Adam moments / step counter, normaliser statistics, the
+    sampler's {seed, offset} (so replays draw fresh noise), and the training
+    state's env / carry / key tensors, which are copied back into the static
+    input buffers at the end of the captured region.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from ..tree import tree_leaves
+from .ppo import ppo_step
+from .types import TrainingState
+
+
+def _copy_state(dst: TrainingState, src: TrainingState) -> None:
+    for name in ("network_states", "env_states", "rng_key", "steps_taken"):
+        d = tree_leaves(getattr(dst, name))
+        s = tree_leaves(getattr(src, name))
+        if len(d) != len(s):
+            raise RuntimeError(
+                f"ppo_step changed the structure of training_state.{name}; "
+                "HIP-graph capture needs a stable state pytree")
+        for a, b in zip(d, s):
+            if not isinstance(a, torch.Tensor):
+                continue
+            if a.shape != b.shape or a.dtype != b.dtype:
+                raise RuntimeError(
+                    f"training_state.{name}: leaf changed from {a.dtype}{tuple(a.shape)} to "
+                    f"{b.dtype}{tuple(b.shape)}; HIP-graph capture needs stable leaves")
+            if a.data_ptr() != b.data_ptr():
+                a.copy_(b)
+
+
+class GraphedPPOStep:
+    """`step = GraphedPPOStep(env, training_state, *ppo_step_args)`; then
+    `training_state, metrics = step()` runs one iteration as a single graph
+    launch.  `training_state` keeps the same (static) tensors across calls;
+    `metrics` are device scalars refreshed by every replay.  `warmup` eager
+    iterations run first (they are real iterations and advance training)."""
+
+    def __init__(self, env, training_state: TrainingState, *args: Any, warmup: int = 2,
+                 **kwargs: Any):
+        self.env = env
+        self.ts = training_state
+        self.args, self.kwargs = args, kwargs
+        self.warmup_iterations = warmup
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                new_ts, _ = ppo_step(env, self.ts, *args, **kwargs)
+                _copy_state(self.ts, new_ts)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            new_ts, metrics = ppo_step(env, self.ts, *args, **kwargs)
+            _copy_state(self.ts, new_ts)
+        self.metrics = metrics
+
+    def __call__(self):
+        self.graph.replay()
+        return self.ts, self.metrics

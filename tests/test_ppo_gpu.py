@@ -271,3 +271,39 @@ def test_pytree_obs_network(dev):
     assert float(n.counter.value.item()) == 640
     for k in ("position", "velocity"):
         assert np.allclose(_cpu(n.mean.value[k]).numpy(), o.mean[k].numpy(), atol=1e-5)
+
+
+def test_graphed_step_equals_eager(dev):
+    """The captured HIP graph of an iteration replays to exactly what eager
+    launches compute: same kernels, same order, same device-resident RNG /
+    optimiser state -> bitwise-equal parameters, statistics and metrics."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.graph import GraphedPPOStep
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    N, T = 128, 8
+    args = (N, T, 0.95, 0.99, 0.2, True, False, 2, 2)
+
+    def setup():
+        env = EpisodeWrapper(MockEnv(5, 1, max_steps=5), 30)
+        net = _make(5, 1, [32, 32], [64, 64])
+        return env, net, ppo.new_training_state(env, net, N, 11, 1e-3, 1.0, device=dev)
+
+    env_a, net_a, ts_a = setup()
+    for _ in range(4):
+        ts_a, m_a = ppo.ppo_step(env_a, ts_a, *args)
+    env_b, net_b, ts_b = setup()
+    g = GraphedPPOStep(env_b, ts_b, *args, warmup=1)
+    for _ in range(3):
+        ts_b, m_b = g()
+    torch.cuda.synchronize()
+    assert int(ts_a.steps_taken) == int(ts_b.steps_taken) == 4 * N * T
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(pa.data, pb.data)
+    assert torch.equal(net_a.layers[0].mean.value, net_b.layers[0].mean.value)
+    assert torch.equal(net_a.layers[0].counter.value, net_b.layers[0].counter.value)
+    assert torch.equal(ts_a.env_states.obs, ts_b.env_states.obs)
+    assert torch.equal(ts_a.rng_key, ts_b.rng_key)
+    for k in m_a:
+        assert torch.equal(torch.as_tensor(m_a[k]), torch.as_tensor(m_b[k])), k
