@@ -39,6 +39,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16
 
 
+# symbol -> (M, K, N) from the integer arguments of a recorded call
+GEMM_SYMBOLS = {
+    "mi_dense_fwd_f32": lambda a: (a[0], a[1], a[2]),
+    "mi_dense_bwd_dx_f32": lambda a: (a[0], a[1], a[2]),
+    "mi_dense_bwd_dw_f32": lambda a: (a[0], a[1], a[2]),
+    # bf16: integer arguments in call order (leading dimensions first)
+    "mi_dense_fwd_bf16": lambda a: (a[4], a[5], a[6]),      # ldx ldwt ldy ldyt M K N act
+    "mi_dense_bwd_dx_bf16": lambda a: (a[6], a[7], a[8]),   # lddz ldw ldprev act ldgx ldgxt M K N
+    "mi_dense_bwd_dw_bf16": lambda a: (a[2], a[3], a[4]),   # ldxt lddzt M K N acc
+}
+
+
 def build(device):
     from nnx_ppo_amd.algorithms import ppo
     from nnx_ppo_amd.envs import cartpole_shaped
@@ -75,18 +87,21 @@ def roofline_of_dominant_kernel(env, ts):
     per_kernel = {}
     for name, d in summ.items():
         per_kernel[name] = {"calls": d["calls"], "ms": round(d["ms"], 4)}
-        if name in ("mi_dense_fwd_f32", "mi_dense_bwd_dx_f32", "mi_dense_bwd_dw_f32"):
+        if name in GEMM_SYMBOLS:
             for ints, t_ms in d["args"]:
-                M, K, N = ints[0], ints[1], ints[2]
+                # the trailing integer arguments of every dense entry point are M, K, N[, act..]
+                M, K, N = GEMM_SYMBOLS[name](ints)
                 flops += 2.0 * M * K * N
                 ms += t_ms
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    dom = max(("mi_dense_fwd_f32", "mi_dense_bwd_dx_f32", "mi_dense_bwd_dw_f32"),
-              key=lambda k: summ.get(k, {"ms": 0})["ms"])
+    dom = max(GEMM_SYMBOLS, key=lambda k: summ.get(k, {"ms": 0})["ms"])
+    from nnx_ppo_amd import config as mi_config
+
+    peak = PEAK_BF16_MFMA_TFLOPS if mi_config.compute_dtype() == "bf16" else PEAK_F32_MFMA_TFLOPS
     roof = {
         "bound": "mfma", "kernel": "dense GEMM family (fwd, dX, dW); largest: " + dom,
-        "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 5), "traffic": None,
         "gemm_ms_per_iter": round(ms, 3), "gemm_flop_per_iter": flops,
     }
     return ts, roof, per_kernel
@@ -131,6 +146,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compute", choices=["f32", "bf16"], default="bf16",
+                    help="MFMA path of the Dense layers (BASELINE configs[1] is bf16)")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from Python instead of replaying the captured "
                          "HIP graph of the iteration")
@@ -149,6 +166,9 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    from nnx_ppo_amd import config as mi_config
+
+    mi_config.set_compute_dtype(args.compute)
     env, net, ts = build(device)
     if args.eager or world > 1:
         ts_box = [ts]
@@ -209,7 +229,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.compute,
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: CartpoleBalance-shaped synthetic env "

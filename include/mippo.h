@@ -146,6 +146,50 @@ int mi_dense_bwd_dw_f32(const float* x, const float* g_y, const float* aux, floa
                         float* g_b, void* workspace, int64_t M, int64_t K, int64_t N,
                         int act, int accumulate, mi_stream_t stream);
 
+/* ---- a9 (bf16 path): Dense layer on bf16 MFMA, fp32 accumulate --------- */
+
+/* Operand conventions: every bf16 operand is a dense row-major matrix whose
+ * leading dimension `ld*` is a multiple of 8 elements (16 bytes) with the
+ * padding ZERO-filled, 16-byte-aligned base.  fp32 master weights stay in the
+ * optimiser arena; `mi_weights_to_bf16` refreshes the two bf16 shadows
+ * (w_bf [K][ldw] for dX, wt_bf [N][ldwt] = W^T for the forward).  Activations
+ * are kept as bf16 plus a TRANSPOSED bf16 copy (the dW operand), both written
+ * by the producing kernel's epilogue. */
+
+/* fp32 x[M][F] (times act'(aux_bf[M][ldaux]) if act != MI_ACT_NONE) -> bf16
+ * out[M][ld] (zero padded, nullable) and bf16 out_t[F][ldt] (nullable). */
+int mi_cast_pad_bf16(const float* x, const void* aux_bf, int64_t ldaux, int act, void* out,
+                     int64_t ld, void* out_t, int64_t ldt, int64_t M, int64_t F,
+                     mi_stream_t stream);
+
+int mi_weights_to_bf16(const float* w, void* w_bf, int64_t ldw, void* wt_bf, int64_t ldwt,
+                       int64_t K, int64_t N, mi_stream_t stream);
+
+/* y = act(x @ w + bias) (`feedforward.py:42-51`).  Outputs (each nullable, at
+ * least one of y_f32 / y_bf): y_f32 [M][N], y_bf [M][ldy], yt_bf [N][ldyt]
+ * (transposed), preact_bf [M][ldy] (pre-activation, for the swish backward). */
+int mi_dense_fwd_bf16(const void* x_bf, int64_t ldx, const void* wt_bf, int64_t ldwt,
+                      const float* bias, float* y_f32, void* y_bf, int64_t ldy, void* yt_bf,
+                      int64_t ldyt, void* preact_bf, int64_t M, int64_t K, int64_t N, int act,
+                      mi_stream_t stream);
+
+/* gx = (dz @ w^T) ⊙ prev_act'(prev): the gradient w.r.t. the PREVIOUS layer's
+ * pre-activation when `prev_bf` is that layer's output (its pre-activation for
+ * swish), or the plain input gradient with prev_act = MI_ACT_NONE.
+ * Outputs (nullable): gx_f32 [M][K], gx_bf [M][ldgx], gxt_bf [K][ldgxt]. */
+int mi_dense_bwd_dx_bf16(const void* dz_bf, int64_t lddz, const void* w_bf, int64_t ldw,
+                         const void* prev_bf, int64_t ldprev, int prev_act, float* gx_f32,
+                         void* gx_bf, int64_t ldgx, void* gxt_bf, int64_t ldgxt, int64_t M,
+                         int64_t K, int64_t N, mi_stream_t stream);
+
+/* g_w[K][N] (+)= x^T dz, g_b[N] (+)= column sums of dz, from the transposed
+ * copies xt_bf [K][ldxt], dzt_bf [N][lddzt]; split over M into fp32 slabs in
+ * `workspace`, reduced in fixed order. */
+int64_t mi_dense_bwd_dw_bf16_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int mi_dense_bwd_dw_bf16(const void* xt_bf, int64_t ldxt, const void* dzt_bf, int64_t lddzt,
+                         float* g_w, float* g_b, void* workspace, int64_t M, int64_t K,
+                         int64_t N, int accumulate, mi_stream_t stream);
+
 /* ---- a14: loss terms ---------------------------------------------------- */
 
 /* Advantage statistics for `ppo.py:477-480`: stats[3] = (sum, sum of squares,

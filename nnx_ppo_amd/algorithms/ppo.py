@@ -24,7 +24,7 @@ import torch
 
 from .. import ops, parallel
 from .. import random as rnd
-from ..networks.types import PPONetworkOutput, StatefulModule
+from ..networks.types import PPONetworkOutput, StatefulModule, bump_param_epoch
 from ..optim import Optimizer
 from ..tree import tree_leaves, tree_map
 from . import rollout
@@ -204,6 +204,9 @@ def ppo_step(
     drawing them from the key (parity tests)."""
     networks: StatefulModule = training_state.networks
     optimizer: Optimizer = training_state.optimizer
+    # derived parameter copies (bf16 shadows) are refreshed at first use in every
+    # iteration, so a captured graph never replays with stale ones
+    bump_param_epoch()
 
     keys = rnd.split(training_state.rng_key)
     reset_key, new_key = keys[0], keys[1]

@@ -218,7 +218,8 @@ dense_dw_kernel(const float* __restrict__ X, const float* __restrict__ gY,
     slab[K * N + n0 + threadIdx.x] = colsum;
 }
 
-// out[i] (+)= sum_s slabs[s][i], fixed order.
+// out[i] (+)= sum_s slabs[s][i], fixed order.  Loads are issued 8 slabs at a time
+// (independent addresses) so the sum is bandwidth- rather than latency-paced.
 __global__ void __launch_bounds__(kThreads)
 reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ gW,
                     float* __restrict__ gb, int64_t S, int64_t KN, int64_t N,
@@ -227,7 +228,15 @@ reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ gW,
   const int64_t stride = KN + N;
   if (i >= stride) return;
   float v = 0.0f;
-  for (int64_t s = 0; s < S; ++s) v += slabs[s * stride + i];
+  int64_t s = 0;
+  for (; s + 8 <= S; s += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slabs[(s + u) * stride + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; s < S; ++s) v += slabs[s * stride + i];
   if (i < KN) {
     gW[i] = accumulate ? gW[i] + v : v;
   } else if (gb) {
@@ -248,6 +257,16 @@ int64_t dw_splits(int64_t M, int64_t K, int64_t N) {
 }
 
 }  // namespace
+
+namespace mippo {
+int reduce_slabs(const float* slabs, float* g_w, float* g_b, int64_t S, int64_t KN, int64_t N,
+                 int accumulate, hipStream_t st) {
+  const int64_t total = KN + N;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(total, kThreads)),
+                     dim3(kThreads), 0, st, slabs, g_w, g_b, S, KN, N, accumulate);
+  return check_launch("reduce_slabs");
+}
+}  // namespace mippo
 
 extern "C" int mi_dense_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                                 float* preact, int64_t M, int64_t K, int64_t N, int act,
@@ -317,8 +336,5 @@ extern "C" int mi_dense_bwd_dw_f32(const float* x, const float* g_y, const float
                      act, rows);
   int rc = mippo::check_launch("mi_dense_bwd_dw_f32(partial)");
   if (rc) return rc;
-  const int64_t total = K * N + N;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mippo::ceil_div(total, kThreads)),
-                     dim3(kThreads), 0, st, slabs, g_w, g_b, S, K * N, N, accumulate);
-  return mippo::check_launch("mi_dense_bwd_dw_f32(reduce)");
+  return mippo::reduce_slabs(slabs, g_w, g_b, S, K * N, N, accumulate, st);
 }

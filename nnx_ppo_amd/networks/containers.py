@@ -5,6 +5,7 @@ from __future__ import annotations
 from collections.abc import Sequence
 from typing import Any
 
+from .. import config
 from .types import ModuleState, StatefulModule, StatefulModuleOutput, add_reg, zero_scalar
 
 
@@ -29,7 +30,26 @@ class Sequential(StatefulModule):
         x = obs
         reg = zero_scalar(_device_of(obs))
         metrics = {}
-        for i, (layer, layer_state) in enumerate(zip(self.layers, network_state)):
+        runs = self._dense_runs() if config.compute_dtype() == "bf16" else {}
+        i = 0
+        n = len(self.layers)
+        while i < n:
+            if i in runs:
+                # a run of Dense layers: one bf16 chain (state / extras / metrics of a
+                # Dense are (), None, {} — feedforward.py:51)
+                from . import dense_chain
+
+                j = runs[i]
+                lead = x.shape[:-1]
+                y = dense_chain.forward_infer(self.layers[i:j], x.reshape(-1, x.shape[-1]))
+                x = y.view(*lead, y.shape[-1])
+                for k in range(i, j):
+                    new_state.append(network_state[k])
+                    new_extras.append(None)
+                    metrics[len(metrics)] = {}
+                i = j
+                continue
+            layer, layer_state = self.layers[i], network_state[i]
             layer_extras = None if rollout_extras is None else rollout_extras[i]
             out = layer(layer_state, x, layer_extras)
             new_state.append(out.next_state)
@@ -37,7 +57,24 @@ class Sequential(StatefulModule):
             x = out.output
             reg = add_reg(reg, out.regularization_loss)
             metrics[len(metrics)] = out.metrics
+            i += 1
         return StatefulModuleOutput(new_state, x, reg, metrics, new_extras)
+
+    def _dense_runs(self) -> dict:
+        """start index -> end index (exclusive) of every maximal run of Dense layers."""
+        from .feedforward import Dense
+
+        runs, i, n = {}, 0, len(self.layers)
+        while i < n:
+            if type(self.layers[i]) is Dense:
+                j = i
+                while j < n and type(self.layers[j]) is Dense:
+                    j += 1
+                runs[i] = j
+                i = j
+            else:
+                i += 1
+        return runs
 
     def initialize_state(self, batch_size: int) -> list[ModuleState]:
         return [layer.initialize_state(batch_size) for layer in self.layers]
@@ -62,20 +99,48 @@ class Sequential(StatefulModule):
         x = x_seq
         reg = None
         upstream_needs = need_input_grad
-        for i, layer in enumerate(self.layers):
+        runs = self._dense_runs() if config.compute_dtype() == "bf16" else {}
+        i, n = 0, len(self.layers)
+        while i < n:
+            if i in runs:
+                from . import dense_chain
+
+                j = runs[i]
+                lead = x.shape[:-1]
+                cctx, y = dense_chain.forward_train(self.layers[i:j],
+                                                    x.reshape(-1, x.shape[-1]), upstream_needs)
+                x = y.view(*lead, y.shape[-1])
+                ctxs.append(("chain", i, j, cctx, lead))
+                final_state.extend(state0[i:j])
+                upstream_needs = True
+                i = j
+                continue
+            layer = self.layers[i]
             layer_extras = None if extras_seq is None else extras_seq[i]
             ctx, x, r, fs = layer.replay(state0[i], x, done_seq, layer_extras,
                                          need_input_grad=upstream_needs)
-            ctxs.append(ctx)
+            ctxs.append(("layer", i, ctx))
             final_state.append(fs)
             reg = add_reg(reg, r)
             upstream_needs = upstream_needs or bool(layer.parameters())
+            i += 1
         return ctxs, x, reg, final_state
 
     def replay_backward(self, ctxs, g_out, g_reg):
         g = g_out
-        for layer, ctx in zip(reversed(self.layers), reversed(ctxs)):
-            g = layer.replay_backward(ctx, g, g_reg)
+        for entry in reversed(ctxs):
+            if entry[0] == "chain":
+                from . import dense_chain
+
+                _, i, j, cctx, lead = entry
+                g2 = g.reshape(-1, g.shape[-1])
+                if not g2.is_contiguous():
+                    g2 = g2.contiguous()
+                gi = dense_chain.backward(self.layers[i:j], cctx, g2)
+                g = None if gi is None else gi.view(*lead, gi.shape[-1])
+            else:
+                _, i, ctx = entry
+                g = self.layers[i].replay_backward(ctx, g, g_reg)
             if g is None:
                 return None
         return g

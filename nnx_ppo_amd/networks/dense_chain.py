@@ -1,0 +1,104 @@
+"""bf16 execution of a run of consecutive Dense layers (an MLP trunk).
+
+A `Sequential` hands every maximal run of `Dense` layers to this module when
+`config.compute_dtype() == "bf16"`.  Knowing the whole run lets each GEMM's
+epilogue produce exactly what the next kernels consume, so no activation makes a
+separate cast / transpose / activation-derivative pass through HBM:
+
+  forward   layer l:  x_bf [M,K] . Wt_l  -> (+bias, act) -> y_bf [M,N] (next A operand,
+            act' input) and yt_bf [N,M] (dW operand of layer l+1); the last layer
+            also writes the fp32 chain output.
+  backward  layer l:  dW_l, db_l from (xt_bf_l, dzt_bf_l);  then
+            dz_{l-1} = (dz_l . W_l^T) ⊙ act'_{l-1}(y_{l-1}) written as bf16 and bf16
+            transposed by the dX kernel's epilogue.
+
+Math per layer is `nnx_ppo/networks/feedforward.py:42-51` and its derivative;
+products are bf16 x bf16 with fp32 accumulation, master weights stay fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from .types import param_epoch
+
+
+def _shadows(layer):
+    """bf16 shadows (W [K, pad8 N], W^T [N, pad8 K]) of a Dense layer's fp32
+    master kernel, refreshed when the parameters have changed."""
+    w = layer.kernel.data
+    if getattr(layer, "_shadow_epoch", None) != param_epoch() or layer._w_bf.device != w.device:
+        K, N = w.shape
+        if getattr(layer, "_w_bf", None) is None or layer._w_bf.device != w.device:
+            layer._w_bf = torch.zeros(K, ops.pad8(N), dtype=torch.bfloat16, device=w.device)
+            layer._wt_bf = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=w.device)
+        ops.weights_to_bf16(w, layer._w_bf, layer._wt_bf)
+        layer._shadow_epoch = param_epoch()
+    return layer._w_bf, layer._wt_bf
+
+
+def _bias(layer):
+    return layer.bias.data if layer.bias is not None else None
+
+
+def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, K0] -> fp32 [M, N_last]; no activations are kept."""
+    x_bf, _ = ops.cast_pad_bf16(x2, want_t=False)
+    y = None
+    for i, layer in enumerate(layers):
+        last = i == len(layers) - 1
+        _, wt = _shadows(layer)
+        y, y_bf, _, _ = ops.dense_fwd_bf16(x_bf, wt, _bias(layer), layer.in_features,
+                                           layer.out_features, layer.act_code, want_f32=last,
+                                           want_bf=not last, want_t=False)
+        x_bf = y_bf
+    return y
+
+
+def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
+    """Returns (ctx, fp32 output [M, N_last])."""
+    M = x2.shape[0]
+    x_bf, xt_bf = ops.cast_pad_bf16(x2, want_t=True)
+    saved = []
+    y = None
+    for i, layer in enumerate(layers):
+        last = i == len(layers) - 1
+        act = layer.act_code
+        swish = act == ops.ACT_SWISH
+        w_bf, wt = _shadows(layer)
+        y, y_bf, yt_bf, pre = ops.dense_fwd_bf16(
+            x_bf, wt, _bias(layer), layer.in_features, layer.out_features, act,
+            want_f32=last, want_bf=(not last) or act != ops.ACT_NONE, want_t=not last,
+            want_preact=swish)
+        saved.append((xt_bf, pre if swish else y_bf, w_bf))
+        x_bf, xt_bf = y_bf, yt_bf
+    return (saved, M, need_input_grad), y
+
+
+def backward(layers, ctx, g_out2: torch.Tensor):
+    """g_out2: fp32 [M, N_last] gradient of the chain output.  Accumulates weight /
+    bias gradients; returns the fp32 input gradient [M, K0] or None."""
+    saved, M, need_input_grad = ctx
+    L = len(layers)
+    last = layers[-1]
+    dz_bf, dzt_bf = ops.cast_pad_bf16(g_out2, want_t=True, aux=saved[-1][1]
+                                      if last.act_code != ops.ACT_NONE else None,
+                                      act=last.act_code)
+    g_in = None
+    for i in range(L - 1, -1, -1):
+        layer = layers[i]
+        xt_bf, _, w_bf = saved[i]
+        ops.dense_bwd_dw_bf16(xt_bf, dzt_bf, layer.kernel.grad,
+                              layer.bias.grad if layer.bias is not None else None, M,
+                              accumulate=True)
+        if i == 0:
+            if need_input_grad:
+                g_in, _, _ = ops.dense_bwd_dx_bf16(dz_bf, w_bf, None, ops.ACT_NONE,
+                                                   layer.in_features, layer.out_features,
+                                                   want_f32=True, want_bf=False, want_t=False)
+            break
+        prev = layers[i - 1]
+        _, dz_bf, dzt_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, saved[i - 1][1], prev.act_code,
+                                                 layer.in_features, layer.out_features,
+                                                 want_f32=False, want_bf=True, want_t=True)
+    return g_in

@@ -7,7 +7,7 @@ from typing import Any, Optional
 
 import torch
 
-from .. import ops
+from .. import config, ops
 from . import activations, initializers
 from .types import Parameter, Rngs, StatefulModule, StatefulModuleOutput, zero_scalar
 
@@ -37,7 +37,12 @@ class Dense(StatefulModule):
 
     def __call__(self, state, x: torch.Tensor, rollout_extras: Any = None) -> StatefulModuleOutput:
         lead = x.shape[:-1]
-        y, _ = self._fwd(x.reshape(-1, self.in_features), want_aux=False)
+        if config.compute_dtype() == "bf16":
+            from . import dense_chain
+
+            y = dense_chain.forward_infer([self], x.reshape(-1, self.in_features))
+        else:
+            y, _ = self._fwd(x.reshape(-1, self.in_features), want_aux=False)
         y = y.view(*lead, self.out_features)
         return StatefulModuleOutput(state, y, zero_scalar(x.device), {}, None)
 
@@ -45,11 +50,22 @@ class Dense(StatefulModule):
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
         lead = x_seq.shape[:-1]
         x2 = x_seq.reshape(-1, self.in_features)
+        if config.compute_dtype() == "bf16":
+            from . import dense_chain
+
+            cctx, y = dense_chain.forward_train([self], x2, need_input_grad)
+            return ("bf16", cctx, lead), y.view(*lead, self.out_features), None, state0
         y, aux = self._fwd(x2, want_aux=True)
         ctx = (x2, aux, lead, need_input_grad)
         return ctx, y.view(*lead, self.out_features), None, state0
 
     def replay_backward(self, ctx, g_out, g_reg):
+        if ctx[0] == "bf16":
+            from . import dense_chain
+
+            _, cctx, lead = ctx
+            g_in = dense_chain.backward([self], cctx, g_out.reshape(-1, self.out_features))
+            return None if g_in is None else g_in.view(*lead, self.in_features)
         x2, aux, lead, need_input_grad = ctx
         g2 = g_out.reshape(-1, self.out_features)
         if not g2.is_contiguous():

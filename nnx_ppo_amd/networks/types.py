@@ -280,3 +280,17 @@ def add_reg(a, b):
     if a is None or any(a is z for z in _ZERO_SCALARS.values()):
         return b
     return a + b
+
+
+# Epoch of the trainable parameters: bumped whenever they may have changed
+# (optimiser update, start of an iteration).  bf16 weight shadows compare it to
+# decide when to refresh.
+_PARAM_EPOCH = [0]
+
+
+def param_epoch() -> int:
+    return _PARAM_EPOCH[0]
+
+
+def bump_param_epoch() -> None:
+    _PARAM_EPOCH[0] += 1

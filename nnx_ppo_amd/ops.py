@@ -229,6 +229,89 @@ def dense_bwd_dw(x, g_y, aux, g_w, g_b, act: int, accumulate: bool = True) -> No
                                     int(bool(accumulate)), stream()), "mi_dense_bwd_dw_f32")
 
 
+# ------------------------------------------------------- a9: dense, bf16 MFMA
+bf16 = torch.bfloat16
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def _bf_buf(rows: int, cols: int, device) -> torch.Tensor:
+    """bf16 [rows][pad8(cols)] operand buffer; the padding must read as zero."""
+    ld = pad8(cols)
+    if ld != cols:
+        return torch.zeros(rows, ld, dtype=bf16, device=device)
+    return torch.empty(rows, ld, dtype=bf16, device=device)
+
+
+def cast_pad_bf16(x: torch.Tensor, want_t: bool, aux=None, act: int = ACT_NONE):
+    """fp32 [M, F] -> (bf16 [M, pad8(F)], bf16 transposed [F, pad8(M)] or None)."""
+    M, F = x.shape
+    out = torch.empty(M, pad8(F), dtype=bf16, device=x.device)
+    out_t = _bf_buf(F, M, x.device) if want_t else None
+    check(lib().mi_cast_pad_bf16(ptr(x, f32), ptr(aux), aux.shape[1] if aux is not None else 0,
+                                 int(act), ptr(out), out.shape[1], ptr(out_t),
+                                 out_t.shape[1] if out_t is not None else 0, M, F, stream()),
+          "mi_cast_pad_bf16")
+    return out, out_t
+
+
+def weights_to_bf16(w: torch.Tensor, w_bf: torch.Tensor, wt_bf: torch.Tensor) -> None:
+    K, N = w.shape
+    _need(w_bf.shape == (K, pad8(N)) and wt_bf.shape == (N, pad8(K)), "weights_to_bf16: shapes")
+    check(lib().mi_weights_to_bf16(ptr(w, f32), ptr(w_bf, bf16), w_bf.shape[1], ptr(wt_bf, bf16),
+                                   wt_bf.shape[1], K, N, stream()), "mi_weights_to_bf16")
+
+
+def dense_fwd_bf16(x_bf, wt_bf, bias, K: int, N: int, act: int, *, want_f32: bool,
+                   want_bf: bool, want_t: bool, want_preact: bool = False):
+    """Returns (y_f32 | None, y_bf | None, yt_bf | None, preact_bf | None)."""
+    M = x_bf.shape[0]
+    _need(x_bf.dtype == bf16 and x_bf.shape[1] == pad8(K), "dense_fwd_bf16: x_bf must be [M, pad8(K)]")
+    _need(wt_bf.shape == (N, pad8(K)), "dense_fwd_bf16: wt_bf must be [N, pad8(K)]")
+    dev = x_bf.device
+    y_f32 = torch.empty(M, N, dtype=f32, device=dev) if want_f32 else None
+    y_bf = _bf_buf(M, N, dev) if want_bf else None
+    yt_bf = _bf_buf(N, M, dev) if want_t else None
+    pre = _bf_buf(M, N, dev) if want_preact else None
+    check(lib().mi_dense_fwd_bf16(
+        ptr(x_bf, bf16), x_bf.shape[1], ptr(wt_bf, bf16), wt_bf.shape[1], ptr(bias, f32),
+        ptr(y_f32, f32), ptr(y_bf), pad8(N), ptr(yt_bf), pad8(M), ptr(pre), M, K, N, int(act),
+        stream()), "mi_dense_fwd_bf16")
+    return y_f32, y_bf, yt_bf, pre
+
+
+def dense_bwd_dx_bf16(dz_bf, w_bf, prev_bf, prev_act: int, K: int, N: int, *, want_f32: bool,
+                      want_bf: bool, want_t: bool):
+    """Returns (gx_f32 | None, gx_bf | None, gxt_bf | None)."""
+    M = dz_bf.shape[0]
+    _need(dz_bf.shape[1] == pad8(N) and w_bf.shape == (K, pad8(N)), "dense_bwd_dx_bf16: shapes")
+    dev = dz_bf.device
+    gx_f32 = torch.empty(M, K, dtype=f32, device=dev) if want_f32 else None
+    gx_bf = _bf_buf(M, K, dev) if want_bf else None
+    gxt_bf = _bf_buf(K, M, dev) if want_t else None
+    if prev_act != ACT_NONE:
+        _need(prev_bf is not None and prev_bf.shape == (M, pad8(K)), "dense_bwd_dx_bf16: prev")
+    check(lib().mi_dense_bwd_dx_bf16(
+        ptr(dz_bf, bf16), dz_bf.shape[1], ptr(w_bf, bf16), w_bf.shape[1],
+        ptr(prev_bf) if prev_act != ACT_NONE else None, pad8(K), int(prev_act), ptr(gx_f32, f32),
+        ptr(gx_bf), pad8(K), ptr(gxt_bf), pad8(M), M, K, N, stream()), "mi_dense_bwd_dx_bf16")
+    return gx_f32, gx_bf, gxt_bf
+
+
+def dense_bwd_dw_bf16(xt_bf, dzt_bf, g_w, g_b, M: int, accumulate: bool = True) -> None:
+    K, N = g_w.shape
+    _need(xt_bf.shape == (K, pad8(M)) and dzt_bf.shape == (N, pad8(M)),
+          "dense_bwd_dw_bf16: transposed operands must be [K, pad8(M)] / [N, pad8(M)]")
+    nbytes = lib().mi_dense_bwd_dw_bf16_workspace_bytes(M, K, N)
+    _need(nbytes >= 0, "mi_dense_bwd_dw_bf16_workspace_bytes failed")
+    ws = workspace(g_w.device, "dense_dw_bf16", nbytes)
+    check(lib().mi_dense_bwd_dw_bf16(ptr(xt_bf, bf16), xt_bf.shape[1], ptr(dzt_bf, bf16),
+                                     dzt_bf.shape[1], ptr(g_w, f32), ptr(g_b, f32), ptr(ws), M, K,
+                                     N, int(bool(accumulate)), stream()), "mi_dense_bwd_dw_bf16")
+
+
 # ------------------------------------------------------------- a14: loss
 def _loss_ws(device):
     return workspace(device, "loss", lib().mi_ppo_loss_workspace_bytes(1))

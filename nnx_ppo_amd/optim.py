@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 
 from . import ops, parallel
-from .networks.types import StatefulModule
+from .networks.types import StatefulModule, bump_param_epoch
 
 _ALIGN = 64  # floats (256 B)
 
@@ -61,6 +61,7 @@ class Optimizer:
             self.params[off:off + n].copy_(p.data.reshape(-1).to(device))
             p.data = self.params[off:off + n].view(p.shape)
             p.grad = self.grads[off:off + n].view(p.shape)
+        bump_param_epoch()
 
     # ---- one gradient step = begin() ... backward ... update() --------------------
     def begin(self) -> None:
@@ -82,6 +83,7 @@ class Optimizer:
                       lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
                       weight_decay=self.weight_decay, grad_norm=gn,
                       max_norm=float(self.gradient_clipping or 0.0))
+        bump_param_epoch()
 
     # ---- state export (checkpoint callbacks) ----------------------------------------
     def state_dict(self) -> dict:
@@ -94,3 +96,4 @@ class Optimizer:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step.copy_(sd["step"])
+        bump_param_epoch()

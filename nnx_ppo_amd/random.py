@@ -48,9 +48,26 @@ def split(k: torch.Tensor, num=2) -> torch.Tensor:
     return out.reshape(*k.shape, *shape)
 
 
+def _to_i64(v: int) -> int:
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _mix_host(z: int) -> int:
+    """`_mix` on a Python int (same bits as the tensor version)."""
+    m = 0xFFFFFFFFFFFFFFFF
+    z &= m
+    z = ((z ^ (z >> 30)) * (_M1 & m)) & m
+    z = ((z ^ (z >> 27)) * (_M2 & m)) & m
+    return z ^ (z >> 31)
+
+
 def fold_in(k: torch.Tensor, data: int) -> torch.Tensor:
-    """`jax.random.fold_in`: a new key from a key and an integer."""
-    return _mix(k ^ _mix(torch.as_tensor(int(data), dtype=torch.int64, device=k.device) + _GOLDEN))
+    """`jax.random.fold_in`: a new key from a key and an integer.  The integer is
+    mixed on the host and enters as a scalar operand, so no host-to-device copy
+    is issued (the call is legal inside HIP-graph capture)."""
+    c = _to_i64(_mix_host(int(data) + _GOLDEN))
+    return _mix(k ^ c)
 
 
 def bits(k: torch.Tensor, shape=()) -> torch.Tensor:

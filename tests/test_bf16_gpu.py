@@ -1,0 +1,179 @@
+"""bf16 MFMA path.  Kernel-level: against an fp64 evaluation on the SAME
+bf16-rounded operands (so the only admissible difference is fp32 accumulation
+order: 1e-4 rel, and the bf16 rounding of bf16 outputs: 2^-8 rel).  End to end:
+against the fp64 oracle with the looser stated bound for bf16 operands (SURVEY
+§8a: ~1e-2 rel on logits) — losses within 5e-2 (actor) / 2e-3 (critic, reg)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from nnx_ppo_amd import random as keys
+from oracle import networks as on
+from oracle import ppo as op
+
+pytestmark = pytest.mark.gpu
+D = torch.float64
+BF = torch.bfloat16
+
+
+def _r(a):  # round to bf16, back to fp64
+    return torch.as_tensor(a, dtype=torch.float32).to(BF).to(D)
+
+
+def _act(z, act):
+    return {"none": z, "relu": torch.relu(z), "tanh": torch.tanh(z),
+            "swish": z * torch.sigmoid(z)}[act]
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (4096, 5, 64), (30720, 64, 64), (30720, 64, 2),
+                                   (30720, 5, 256), (30720, 256, 256), (30720, 256, 1),
+                                   (777, 17, 512), (513, 512, 12), (130, 33, 65), (257, 40, 129)])
+@pytest.mark.parametrize("act", ["none", "relu", "tanh", "swish"])
+def test_dense_bf16_kernels(dev, M, K, N, act):
+    from nnx_ppo_amd import ops
+
+    if act in ("tanh", "swish") and M > 5000:
+        pytest.skip("covered by relu/none at this size")
+    rng = np.random.default_rng(M + 7 * K + 13 * N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(K, N)) / math.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    code = ops.ACT_CODES[act]
+    g = lambda a: torch.as_tensor(a).to(dev)
+    x_bf, xt_bf = ops.cast_pad_bf16(g(x), want_t=True)
+    assert x_bf.shape == (M, ops.pad8(K)) and xt_bf.shape == (K, ops.pad8(M))
+    assert torch.equal(x_bf[:, :K].cpu(), torch.as_tensor(x).to(BF))
+    assert torch.equal(xt_bf[:, :M].cpu(), torch.as_tensor(x).to(BF).t())
+    assert float(x_bf[:, K:].float().abs().sum()) == 0 and float(xt_bf[:, M:].float().abs().sum()) == 0
+    w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
+    wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
+    ops.weights_to_bf16(g(w), w_bf, wt_bf)
+    assert torch.equal(w_bf[:, :N].cpu(), torch.as_tensor(w).to(BF))
+    assert torch.equal(wt_bf[:, :K].cpu(), torch.as_tensor(w).to(BF).t())
+
+    y, y_bf, yt_bf, pre = ops.dense_fwd_bf16(x_bf, wt_bf, g(b), K, N, code, want_f32=True,
+                                             want_bf=True, want_t=True,
+                                             want_preact=(act == "swish"))
+    z64 = _r(x) @ _r(w) + torch.as_tensor(b, dtype=D)
+    y64 = _act(z64, act)
+    assert np.allclose(y.cpu().numpy(), y64.numpy(), rtol=1e-4, atol=1e-4)
+    assert np.allclose(y_bf[:, :N].float().cpu().numpy(), y64.numpy(), rtol=1e-2, atol=1e-2)
+    assert torch.equal(yt_bf[:, :M].cpu(), y_bf[:, :N].t().cpu())  # same rounding, transposed
+    if act == "swish":
+        assert np.allclose(pre[:, :N].float().cpu().numpy(), z64.numpy(), rtol=1e-2, atol=1e-2)
+
+    # dX of THIS layer given dz (bf16), times act' of a previous layer's output `prev`
+    dz = rng.normal(size=(M, N)).astype(np.float32)
+    prev = rng.normal(size=(M, K)).astype(np.float32)
+    dz_bf, dzt_bf = ops.cast_pad_bf16(g(dz), want_t=True)
+    prev_bf, _ = ops.cast_pad_bf16(g(prev), want_t=False)
+    gx, gx_bf, gxt_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, prev_bf, code, K, N, want_f32=True,
+                                              want_bf=True, want_t=True)
+    p64 = _r(prev)
+    dact = {"none": torch.ones_like(p64), "relu": (p64 > 0).to(D), "tanh": 1 - p64 * p64,
+            "swish": torch.sigmoid(p64) * (1 + p64 * (1 - torch.sigmoid(p64)))}[act]
+    gx64 = (_r(dz) @ _r(w).t()) * dact
+    assert np.allclose(gx.cpu().numpy(), gx64.numpy(), rtol=1e-4, atol=1e-4)
+    assert np.allclose(gx_bf[:, :K].float().cpu().numpy(), gx64.numpy(), rtol=1e-2, atol=1e-2)
+    assert torch.equal(gxt_bf[:, :M].cpu(), gx_bf[:, :K].t().cpu())
+
+    # dW, db from the transposed copies
+    gw = torch.zeros(K, N, device=dev)
+    gb = torch.zeros(N, device=dev)
+    ops.dense_bwd_dw_bf16(xt_bf, dzt_bf, gw, gb, M, accumulate=True)
+    gw64 = _r(x).t() @ _r(dz)
+    gb64 = _r(dz).sum(0)
+    s = math.sqrt(M)
+    assert np.allclose(gw.cpu().numpy(), gw64.numpy(), rtol=1e-4, atol=2e-5 * s)
+    assert np.allclose(gb.cpu().numpy(), gb64.numpy(), rtol=1e-4, atol=2e-5 * s)
+    gw2 = torch.zeros(K, N, device=dev)
+    ops.dense_bwd_dw_bf16(xt_bf, dzt_bf, gw2, None, M, accumulate=False)
+    assert torch.equal(gw2, gw)  # bitwise reproducible
+
+
+def test_cast_pad_with_activation_derivative(dev):
+    from nnx_ppo_amd import ops
+
+    M, F = 100, 12
+    g = torch.randn(M, F, device=dev)
+    y = torch.randn(M, F, device=dev)
+    y_bf, _ = ops.cast_pad_bf16(y, want_t=False)
+    dz, dzt = ops.cast_pad_bf16(g, want_t=True, aux=y_bf, act=ops.ACT_TANH)
+    want = (g * (1 - y_bf[:, :F].float() ** 2)).to(BF)
+    assert torch.equal(dz[:, :F], want) and torch.equal(dzt[:, :M], want.t())
+
+
+def _make(obs, act, ah, ch, activation="relu", seed=17):
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+
+    return factories.make_mlp_actor_critic(obs, act, ah, ch, Rngs(seed), activation=activation)
+
+
+@pytest.mark.parametrize("activation", ["relu", "swish"])
+def test_ppo_step_bf16_vs_oracle(dev, activation):
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    N, T = 64, 12
+    mk_env = lambda: EpisodeWrapper(MockEnv(5, 1, max_steps=5), 40)
+    with config.use_compute_dtype("bf16"):
+        env = mk_env()
+        net = _make(5, 1, [64, 64, 64, 64], [256, 256], activation)
+        ts = ppo.new_training_state(env, net, N, 18, 1e-3, device=dev)
+        onet = on.from_product(net)
+        oenv = mk_env()
+        ots = op.new_training_state(oenv, onet, N, 18, keys, 1e-3)
+        for k in range(2):
+            ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 2, 4)
+            ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 4, keys)
+            assert torch.equal(ts.env_states.obs.cpu(), ots.env_states.obs)  # events still exact
+            a, c, r = (info[n].numpy().mean() for n in ("actor", "critic", "regularization"))
+            assert np.allclose(m["losses/actor/mean"].item(), a, rtol=5e-2, atol=3e-4)
+            assert np.allclose(m["losses/critic/mean"].item(), c, rtol=2e-3)
+            assert np.allclose(m["losses/regularization/mean"].item(), r, rtol=5e-2, atol=1e-4)
+        for p, q in zip(net.parameters(), onet.parameters()):
+            assert float((p.data.cpu() - q.detach()).abs().max()) < 2e-2
+            assert torch.isfinite(p.data).all()
+
+
+def test_bf16_gradients_close_to_f32_path(dev):
+    """Same minibatch through both MFMA paths: parameter gradients agree to bf16
+    operand precision (cosine > 0.999 per tensor, relative L2 error < 3e-2)."""
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.types import LoggingLevel, Transition
+    from nnx_ppo_amd.networks.types import PPONetworkOutput
+    from nnx_ppo_amd.optim import Optimizer
+
+    T, B, O, A = 10, 256, 5, 1
+    net = _make(O, A, [64, 64], [256, 256])
+    net.to(dev)
+    opt = Optimizer(net, 1e-4, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    done = torch.rand(T, B, device=dev, generator=gen) < 0.1
+    extras = [rn(T, B, O), {"action": [None] * 3 + [rn(T, B, A)], "value": [None] * 3}]
+    mb = Transition(obs=extras[0], network_output=PPONetworkOutput(None, rn(T, B) - 1, None),
+                    rewards=rn(T, B), done=done, truncated=done & (rn(T, B) > 0),
+                    next_obs=rn(1, B, O), metrics={}, rollout_extras=extras)
+    grads = {}
+    for mode in ("f32", "bf16"):
+        with config.use_compute_dtype(mode):
+            for s in [m for m in net.modules() if hasattr(m, "advance_rng")]:
+                s._pending = 0  # same entropy noise for both passes
+            opt.begin()
+            ppo.ppo_loss(net, net.initialize_state(B), mb, 0.2, True, False, 0.99, 0.95, 1.0,
+                         LoggingLevel.LOSSES)
+            grads[mode] = [p.grad.clone() for p in net.parameters()]
+    for (name, _), a, b in zip(net.named_parameters(), grads["f32"], grads["bf16"]):
+        na = float(a.norm())
+        if na == 0:
+            continue
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        rel = float((a - b).norm() / a.norm())
+        assert cos > 0.999 and rel < 3e-2, (name, cos, rel)
