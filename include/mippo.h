@@ -242,6 +242,35 @@ int mi_select_rows(const uint8_t* mask, const void* on_true, int64_t true_row_st
                    const void* on_false, void* out, int64_t B, int64_t row_bytes,
                    mi_stream_t stream);
 
+/* Several tree_where leaves in one launch (n_leaves <= 16): host arrays of
+ * per-leaf pointers / strides / row sizes. */
+int mi_select_rows_multi(const uint8_t* mask, const void* const* on_true,
+                         const int64_t* true_row_stride_bytes, const void* const* on_false,
+                         void* const* out, const int64_t* row_bytes, int64_t n_leaves, int64_t B,
+                         mi_stream_t stream);
+
+/* ---- a4 / a18: integer keys and episode bookkeeping ----------------------- */
+
+/* Key expansion, the integer scheme of nnx_ppo_amd/random.py (splitmix64) in
+ * one launch: keys[n] -> out[n*m].  mode: 0 split (int64 children,
+ * `jax.random.split`), 1 bits (int64), 2 randint in [minval, maxval) (int64,
+ * `episode_wrapper.py:28-30`), 3 uniform [0,1) (fp32, 24 exact bits),
+ * 4 zero-mean unit-variance uniform (fp32). */
+int mi_key_expand(const int64_t* keys, void* out, int64_t n, int64_t m, int mode,
+                  int64_t minval, int64_t maxval, mi_stream_t stream);
+
+/* out[i] = mix(a[i] ^ mix(b[i] + GOLDEN)): fold a per-env integer into a key. */
+int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int64_t n,
+                mi_stream_t stream);
+
+/* EpisodeWrapper.step, `nnx_ppo/wrappers/episode_wrapper.py:12-22`:
+ * counter' = counter + 1; truncated = inner_truncated | counter' >= max_len;
+ * done = float(inner_done | truncated).  inner_done is uint8/bool or fp32
+ * (done_is_float); inner_truncated nullable. */
+int mi_episode_step(const int64_t* counter, const void* inner_done, int done_is_float,
+                    const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
+                    uint8_t* truncated_out, float* done_out, int64_t n, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

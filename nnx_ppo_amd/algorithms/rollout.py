@@ -20,17 +20,26 @@ def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
     reference's shared-field rule, 272-275).  One byte-exact select kernel per
     leaf (`mi_select_rows`)."""
     B = cond.shape[0]
+    pairs: list = []
 
-    def leaf(x, y):
+    def collect(x, y):
         if not isinstance(x, torch.Tensor) or x.dim() == 0 or x.shape[0] != B:
             return x
         if not isinstance(y, torch.Tensor):
             return x
         if y.dtype != x.dtype:
             y = y.to(x.dtype)
-        return ops.select_rows(cond, x.contiguous(), y.contiguous())
+        pairs.append((x.contiguous(), y.contiguous()))
+        return _Slot(len(pairs) - 1)
 
-    return tree_map(leaf, on_true, on_false)
+    skeleton = tree_map(collect, on_true, on_false)
+    outs = ops.select_rows_multi(cond, pairs)
+    return tree_map(lambda v: outs[v.i] if isinstance(v, _Slot) else v, skeleton)
+
+
+class _Slot:
+    def __init__(self, i: int):
+        self.i = i
 
 
 def _as_bool(x: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,132 @@
+// a4 / a18 — integer key derivation and episode bookkeeping as single launches.
+//
+// The reference threads jax.random keys through env resets, minibatch
+// permutations and the EpisodeWrapper's random initial step counter
+// (nnx_ppo/algorithms/ppo.py:271,284-294, rollout.py:57-59,
+//  wrappers/episode_wrapper.py:12-31).  Here keys are int64 mixed with
+// splitmix64; nnx_ppo_amd/random.py defines the scheme in integer torch ops
+// (bit-identical on CPU and GPU) and these kernels evaluate the same integer
+// expressions in ONE launch each instead of ~10 elementwise launches — at this
+// workload's size the iteration is launch-bound, not arithmetic-bound.
+// Integer work: bit-exact by construction (tests/test_keys_gpu.py).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t kM1 = 0xBF58476D1CE4E5B9ull;
+constexpr uint64_t kM2 = 0x94D049BB133111EBull;
+
+__device__ inline uint64_t mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * kM1;
+  z = (z ^ (z >> 27)) * kM2;
+  return z ^ (z >> 31);
+}
+
+enum { OUT_SPLIT = 0, OUT_BITS = 1, OUT_RANDINT = 2, OUT_UNIFORM = 3, OUT_UNIT_UNIFORM = 4 };
+
+// keys[n] -> out[n * m]; element (i, j):
+//   SPLIT        mix(k_i + (j+1) * GOLDEN)                         (random.split)
+//   BITS         mix(mix(k_i) ^ ((j+1) * M2))                      (random.bits)
+//   RANDINT      (BITS >> 1) % span + minval                       (random.randint)
+//   UNIFORM      (BITS >> 40) * 2^-24                               (random.uniform)
+//   UNIT_UNIFORM (UNIFORM - 0.5) * sqrt(12)                         (random.unit_uniform)
+__global__ void __launch_bounds__(kThreads)
+key_expand_kernel(const int64_t* __restrict__ keys, void* __restrict__ out, int64_t n, int64_t m,
+                  int mode, int64_t minval, int64_t span) {
+  const int64_t total = n * m;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = e / m, j = e % m;
+    const uint64_t k = (uint64_t)keys[i];
+    if (mode == OUT_SPLIT) {
+      static_cast<int64_t*>(out)[e] = (int64_t)mix(k + (uint64_t)(j + 1) * kGolden);
+      continue;
+    }
+    const uint64_t b = mix(mix(k) ^ ((uint64_t)(j + 1) * kM2));
+    if (mode == OUT_BITS) {
+      static_cast<int64_t*>(out)[e] = (int64_t)b;
+    } else if (mode == OUT_RANDINT) {
+      // torch: (b >>> 1) % span on non-negative int64
+      static_cast<int64_t*>(out)[e] = (int64_t)((b >> 1) % (uint64_t)span) + minval;
+    } else {
+      const float u = (float)(int64_t)(b >> 40) * (1.0f / 16777216.0f);
+      static_cast<float*>(out)[e] =
+          mode == OUT_UNIFORM ? u : (u - 0.5f) * 3.4641016151377544f;
+    }
+  }
+}
+
+// out[i] = mix(a[i] ^ mix(b[i] + GOLDEN))  — fold a per-env integer into a key
+__global__ void __launch_bounds__(kThreads)
+key_fold_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b,
+                int64_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kThreads)
+    out[i] = (int64_t)mix((uint64_t)a[i] ^ mix((uint64_t)b[i] + kGolden));
+}
+
+// EpisodeWrapper.step, episode_wrapper.py:12-22:
+//   counter' = counter + 1 ; truncated = inner_truncated | (counter' >= max_len)
+//   done = float(inner_done | truncated)
+__global__ void __launch_bounds__(kThreads)
+episode_step_kernel(const int64_t* __restrict__ counter, const void* __restrict__ inner_done,
+                    int done_is_float, const uint8_t* __restrict__ inner_trunc, int64_t max_len,
+                    int64_t* __restrict__ counter_out, uint8_t* __restrict__ trunc_out,
+                    float* __restrict__ done_out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t c = counter[i] + 1;
+    const bool d = done_is_float ? static_cast<const float*>(inner_done)[i] != 0.0f
+                                 : static_cast<const uint8_t*>(inner_done)[i] != 0;
+    const bool t = (inner_trunc ? inner_trunc[i] != 0 : false) || c >= max_len;
+    counter_out[i] = c;
+    trunc_out[i] = t ? 1 : 0;
+    done_out[i] = (d || t) ? 1.0f : 0.0f;
+  }
+}
+
+int stream_grid(int64_t n) {
+  int64_t g = mippo::ceil_div(n, kThreads);
+  if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int mi_key_expand(const int64_t* keys, void* out, int64_t n, int64_t m, int mode,
+                             int64_t minval, int64_t maxval, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && m >= 0 && mode >= OUT_SPLIT && mode <= OUT_UNIT_UNIFORM,
+             "mi_key_expand: bad arguments");
+  if (n == 0 || m == 0) return 0;
+  MI_REQUIRE(keys && out, "mi_key_expand: null pointer");
+  MI_REQUIRE(mode != OUT_RANDINT || maxval > minval, "mi_key_expand: empty randint range");
+  hipLaunchKernelGGL(key_expand_kernel, dim3(stream_grid(n * m)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), keys, out, n, m, mode, minval, maxval - minval);
+  return mippo::check_launch("mi_key_expand");
+}
+
+extern "C" int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int64_t n,
+                           mi_stream_t stream) {
+  MI_REQUIRE(n >= 0, "mi_key_fold: bad n");
+  if (n == 0) return 0;
+  MI_REQUIRE(a && b && out, "mi_key_fold: null pointer");
+  hipLaunchKernelGGL(key_fold_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), a, b, out, n);
+  return mippo::check_launch("mi_key_fold");
+}
+
+extern "C" int mi_episode_step(const int64_t* counter, const void* inner_done, int done_is_float,
+                               const uint8_t* inner_truncated, int64_t max_len,
+                               int64_t* counter_out, uint8_t* truncated_out, float* done_out,
+                               int64_t n, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0, "mi_episode_step: bad n");
+  if (n == 0) return 0;
+  MI_REQUIRE(counter && inner_done && counter_out && truncated_out && done_out,
+             "mi_episode_step: null pointer");
+  hipLaunchKernelGGL(episode_step_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), counter, inner_done, done_is_float, inner_truncated,
+                     max_len, counter_out, truncated_out, done_out, n);
+  return mippo::check_launch("mi_episode_step");
+}

@@ -41,6 +41,40 @@ select_rows_kernel(const uint8_t* __restrict__ mask, const T* __restrict__ on_tr
   }
 }
 
+// Several leaves in one launch (blockIdx.y = leaf): the carry / env state of a
+// rollout step has ~10 small leaves, and one launch per leaf is launch-bound.
+struct SelectLeaf {
+  const void* on_true;
+  const void* on_false;
+  void* out;
+  int64_t true_stride;  // in words; 0 = broadcast one on_true row
+  int64_t words;        // words per row
+  int word_bytes;       // 4 or 1
+};
+constexpr int kMaxSelectLeaves = 16;
+struct SelectTable {
+  SelectLeaf leaf[kMaxSelectLeaves];
+};
+
+__global__ void __launch_bounds__(kThreads)
+select_rows_multi_kernel(const uint8_t* __restrict__ mask, SelectTable tab, int64_t B) {
+  const SelectLeaf lf = tab.leaf[blockIdx.y];
+  const int64_t total = B * lf.words;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t b = i / lf.words, w = i % lf.words;
+    if (lf.word_bytes == 4) {
+      const uint32_t* t = static_cast<const uint32_t*>(lf.on_true);
+      const uint32_t* f = static_cast<const uint32_t*>(lf.on_false);
+      static_cast<uint32_t*>(lf.out)[i] = mask[b] ? t[b * lf.true_stride + w] : f[i];
+    } else {
+      const uint8_t* t = static_cast<const uint8_t*>(lf.on_true);
+      const uint8_t* f = static_cast<const uint8_t*>(lf.on_false);
+      static_cast<uint8_t*>(lf.out)[i] = mask[b] ? t[b * lf.true_stride + w] : f[i];
+    }
+  }
+}
+
 int stream_grid(int64_t n) {
   int64_t g = mippo::ceil_div(n, kThreads);
   if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
@@ -91,4 +125,38 @@ extern "C" int mi_select_rows(const uint8_t* mask, const void* on_true, int64_t 
                        static_cast<uint8_t*>(out), B, row_bytes);
   }
   return mippo::check_launch("mi_select_rows");
+}
+
+extern "C" int mi_select_rows_multi(const uint8_t* mask, const void* const* on_true,
+                                    const int64_t* true_row_stride_bytes,
+                                    const void* const* on_false, void* const* out,
+                                    const int64_t* row_bytes, int64_t n_leaves, int64_t B,
+                                    mi_stream_t stream) {
+  MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves && B >= 0,
+             "mi_select_rows_multi: 0 <= n_leaves <= %d", kMaxSelectLeaves);
+  if (n_leaves == 0 || B == 0) return 0;
+  MI_REQUIRE(mask && on_true && on_false && out && row_bytes && true_row_stride_bytes,
+             "mi_select_rows_multi: null pointer");
+  SelectTable tab = {};
+  int64_t max_words = 0;
+  for (int64_t l = 0; l < n_leaves; ++l) {
+    MI_REQUIRE(on_true[l] && on_false[l] && out[l] && row_bytes[l] >= 1,
+               "mi_select_rows_multi: bad leaf %lld", (long long)l);
+    MI_REQUIRE(true_row_stride_bytes[l] == 0 || true_row_stride_bytes[l] == row_bytes[l],
+               "mi_select_rows_multi: on_true stride must be 0 or row_bytes");
+    const bool w4 = row_bytes[l] % 4 == 0 && aligned4(on_true[l]) && aligned4(on_false[l]) &&
+                    aligned4(out[l]);
+    SelectLeaf& lf = tab.leaf[l];
+    lf.on_true = on_true[l];
+    lf.on_false = on_false[l];
+    lf.out = out[l];
+    lf.word_bytes = w4 ? 4 : 1;
+    lf.words = row_bytes[l] / lf.word_bytes;
+    lf.true_stride = true_row_stride_bytes[l] / lf.word_bytes;
+    if (lf.words > max_words) max_words = lf.words;
+  }
+  dim3 grid((unsigned)stream_grid(B * max_words), (unsigned)n_leaves);
+  hipLaunchKernelGGL(select_rows_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream),
+                     mask, tab, B);
+  return mippo::check_launch("mi_select_rows_multi");
 }

@@ -108,22 +108,40 @@ welford_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
   }
 }
 
-// One thread per column merges the G partials in block order.
+// One WAVE per column: lane l merges partials l, l+64, ... in order, then the 64
+// lane results are merged by a fixed butterfly (xor 32, 16, .. 1) — a fixed
+// order, so the statistics are bitwise reproducible run to run.
 // batch layout: [3][F] (n, mean, M2) — n is identical for every column.
 __global__ void __launch_bounds__(kThreads)
 welford_finalize_kernel(const float* __restrict__ partial, float* __restrict__ batch,
                         int64_t G, int64_t F) {
-  const int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (c >= F) return;
   Wf s = {0.0f, 0.0f, 0.0f};
-  for (int64_t g = 0; g < G; ++g) {
+  for (int64_t g = lane; g < G; g += 64) {
     const float* p = partial + g * 3 * F;
     Wf b = {p[c], p[F + c], p[2 * F + c]};
     wf_merge(s, b);
   }
-  batch[c] = s.n;
-  batch[F + c] = s.mean;
-  batch[2 * F + c] = s.m2;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Wf o = {__shfl_xor(s.n, off, 64), __shfl_xor(s.mean, off, 64), __shfl_xor(s.m2, off, 64)};
+    // lower lane keeps (self, other) order, upper lane (other, self): both halves of a pair
+    // compute the same merged value in the same operand order
+    if (lane & off) {
+      Wf t = o;
+      wf_merge(t, s);
+      s = t;
+    } else {
+      wf_merge(s, o);
+    }
+  }
+  if (lane == 0) {
+    batch[c] = s.n;
+    batch[F + c] = s.mean;
+    batch[2 * F + c] = s.m2;
+  }
 }
 
 // normalizer.py:110-136 with (n, batch_mean, batch_M2) given:
@@ -183,8 +201,8 @@ extern "C" int mi_normalize_bwd_f32(const float* g_out, const float* m2,
 }
 
 static int welford_chunks(int64_t M) {
-  int64_t g = mippo::ceil_div(M, 64);  // >= 64 rows per block-row-lane set
-  if (g > 1024) g = 1024;
+  int64_t g = mippo::ceil_div(M, 256);  // >= 256 rows per partial
+  if (g > 512) g = 512;
   return (int)(g < 1 ? 1 : g);
 }
 
@@ -209,9 +227,9 @@ extern "C" int mi_welford_batch_stats_f32(const float* x, float* batch_stats,
                      mippo::as_stream(stream), x, partial, M, F, CW, R);
   int rc = mippo::check_launch("mi_welford_batch_stats_f32(partial)");
   if (rc) return rc;
-  hipLaunchKernelGGL(welford_finalize_kernel, dim3((unsigned)mippo::ceil_div(F, kThreads)),
-                     dim3(kThreads), 0, mippo::as_stream(stream), partial, batch_stats,
-                     (int64_t)G, F);
+  hipLaunchKernelGGL(welford_finalize_kernel,
+                     dim3((unsigned)mippo::ceil_div(F, kThreads / 64)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), partial, batch_stats, (int64_t)G, F);
   return mippo::check_launch("mi_welford_batch_stats_f32(finalize)");
 }
 

@@ -26,11 +26,14 @@ class MockEnv:
         self.observation_size = obs_size
 
     def _obs(self, key: torch.Tensor, step: torch.Tensor) -> Any:
-        k = rnd._mix(key ^ rnd._mix(step + rnd._GOLDEN))
+        k = rnd.fold_key(key, step)
         if isinstance(self.obs_size, dict):
-            out = {}
-            for i, name in enumerate(sorted(self.obs_size)):
-                out[name] = rnd.unit_uniform(rnd._mix(k + i + 1), (self.obs_size[name],))
+            names = sorted(self.obs_size)
+            flat = rnd.unit_uniform(k, (sum(self.obs_size[n] for n in names),))
+            out, o = {}, 0
+            for name in names:
+                out[name] = flat[..., o:o + self.obs_size[name]].contiguous()
+                o += self.obs_size[name]
             return out
         return rnd.unit_uniform(k, (self.obs_size,))
 

@@ -7,6 +7,8 @@ to torch arithmetic: a CPU tensor or a missing library raises `MippoError`.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from ._lib import MippoError, check, lib, ptr, stream
@@ -417,3 +419,88 @@ def select_rows(mask: torch.Tensor, on_true: torch.Tensor, on_false: torch.Tenso
     check(lib().mi_select_rows(ptr(_as_u8(mask)), ptr(v(on_true)), stride, ptr(v(on_false)),
                                ptr(v(out)), B, row_bytes, stream()), "mi_select_rows")
     return out
+
+
+def select_rows_multi(mask: torch.Tensor, pairs: list) -> list:
+    """`select_rows` for several (on_true, on_false) leaves in ONE launch per 16
+    leaves.  Returns the list of outputs in order."""
+    B = mask.shape[0]
+    outs: list = [None] * len(pairs)
+    batch: list = []
+    v = lambda t: t.view(torch.uint8) if t.dtype == torch.bool else t
+
+    def flush():
+        if not batch:
+            return
+        n = len(batch)
+        P = ctypes.c_void_p * n
+        L = ctypes.c_int64 * n
+        check(lib().mi_select_rows_multi(
+            ptr(_as_u8(mask)), P(*[b[1] for b in batch]), L(*[b[2] for b in batch]),
+            P(*[b[3] for b in batch]), P(*[b[4] for b in batch]), L(*[b[5] for b in batch]), n, B,
+            stream()), "mi_select_rows_multi")
+        batch.clear()
+
+    for k, (on_true, on_false) in enumerate(pairs):
+        _need(on_false.shape[0] == B, "select_rows_multi: leading dim must equal the mask's")
+        _need(on_true.dtype == on_false.dtype, "select_rows_multi: dtype mismatch")
+        row_bytes = on_false.element_size()
+        for d in on_false.shape[1:]:
+            row_bytes *= d
+        if on_true.shape == on_false.shape:
+            stride = row_bytes
+        elif on_true.shape == on_false.shape[1:]:
+            stride = 0
+        else:
+            raise MippoError("select_rows_multi: on_true must match on_false or be one row")
+        out = torch.empty_like(on_false)
+        outs[k] = out
+        if row_bytes == 0 or B == 0:
+            continue
+        batch.append((k, ptr(v(on_true)), stride, ptr(v(on_false)), ptr(v(out)), row_bytes))
+        if len(batch) == 16:
+            flush()
+    flush()
+    return outs
+
+
+# ------------------------------------------------- a4 / a18: keys, episodes
+KEY_SPLIT, KEY_BITS, KEY_RANDINT, KEY_UNIFORM, KEY_UNIT_UNIFORM = 0, 1, 2, 3, 4
+
+
+def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: int = 0):
+    """keys (int64, any shape) -> `[*keys.shape, m]` children / bits / integers / floats."""
+    _need(keys.dtype == i64, "key_expand: keys must be int64")
+    k = keys if keys.is_contiguous() else keys.contiguous()
+    n = k.numel()
+    dt = f32 if mode in (KEY_UNIFORM, KEY_UNIT_UNIFORM) else i64
+    out = torch.empty((*k.shape, m), dtype=dt, device=k.device)
+    check(lib().mi_key_expand(ptr(k, i64), ptr(out), n, int(m), int(mode), int(minval),
+                              int(maxval), stream()), "mi_key_expand")
+    return out
+
+
+def key_fold(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need(a.dtype == i64 and b.dtype == i64 and a.shape == b.shape, "key_fold: int64 same shape")
+    a = a if a.is_contiguous() else a.contiguous()
+    b = b if b.is_contiguous() else b.contiguous()
+    out = torch.empty_like(a)
+    check(lib().mi_key_fold(ptr(a, i64), ptr(b, i64), ptr(out, i64), a.numel(), stream()),
+          "mi_key_fold")
+    return out
+
+
+def episode_step(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc, max_len: int):
+    """Returns (counter + 1, truncated (bool), done (float32)) — episode_wrapper.py:12-22."""
+    n = counter.numel()
+    _need(counter.dtype == i64 and inner_done.numel() == n, "episode_step: shapes")
+    is_float = inner_done.dtype == f32
+    d = inner_done if is_float else _as_u8(inner_done)
+    t = None if inner_trunc is None else _as_u8(inner_trunc)
+    c_out = torch.empty_like(counter)
+    t_out = torch.empty(counter.shape, dtype=torch.bool, device=counter.device)
+    d_out = torch.empty(counter.shape, dtype=f32, device=counter.device)
+    check(lib().mi_episode_step(ptr(counter, i64), ptr(d), int(is_float), ptr(t), int(max_len),
+                                ptr(c_out, i64), ptr(t_out.view(torch.uint8)), ptr(d_out, f32), n,
+                                stream()), "mi_episode_step")
+    return c_out, t_out, d_out

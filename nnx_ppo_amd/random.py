@@ -12,6 +12,13 @@ from __future__ import annotations
 
 import torch
 
+
+def _ops():
+    from . import ops  # deferred: ops imports torch + the C ABI binding
+
+    return ops
+
+
 _GOLDEN = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
 _M1 = -4658895280553007687  # 0xBF58476D1CE4E5B9
 _M2 = -7723592293110705685  # 0x94D049BB133111EB
@@ -43,6 +50,8 @@ def split(k: torch.Tensor, num=2) -> torch.Tensor:
     n = 1
     for s in shape:
         n *= s
+    if k.is_cuda:  # same integers, one launch (csrc/keys.hip)
+        return _ops().key_expand(k, n, 0).reshape(*k.shape, *shape)
     idx = torch.arange(1, n + 1, dtype=torch.int64, device=k.device)
     out = _mix(k.unsqueeze(-1) + idx * _GOLDEN)
     return out.reshape(*k.shape, *shape)
@@ -76,6 +85,8 @@ def bits(k: torch.Tensor, shape=()) -> torch.Tensor:
     n = 1
     for s in shape:
         n *= s
+    if k.is_cuda:
+        return _ops().key_expand(k, n, 1).reshape(*k.shape, *shape)
     idx = torch.arange(1, n + 1, dtype=torch.int64, device=k.device)
     out = _mix(_mix(k).unsqueeze(-1) ^ (idx * _M2))
     return out.reshape(*k.shape, *shape)
@@ -87,12 +98,17 @@ def randint(k: torch.Tensor, shape, minval: int, maxval: int) -> torch.Tensor:
     if span <= 0:
         return torch.full((*k.shape, *tuple(shape)), int(minval), dtype=torch.int64,
                           device=k.device)
+    if k.is_cuda:
+        return _ops().key_expand(k, _numel(shape), 2, minval, maxval).reshape(*k.shape,
+                                                                             *tuple(shape))
     b = _lsr(bits(k, shape), 1)  # non-negative 63-bit
     return b % span + int(minval)
 
 
 def uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor:
     """U[0,1) with 24 random bits — exact in fp32, identical on CPU and GPU."""
+    if k.is_cuda and dtype == torch.float32:
+        return _ops().key_expand(k, _numel(shape), 3).reshape(*k.shape, *tuple(shape))
     b = _lsr(bits(k, shape), 40)  # 24 bits
     return b.to(dtype) * (1.0 / (1 << 24))
 
@@ -102,8 +118,25 @@ def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor
     multiply after exact operands, so CPU and GPU agree bit for bit; synthetic
     envs use it where the reference's test envs draw `jax.random.normal`
     (`test_dummies/mock_env.py:41-52`)."""
+    if k.is_cuda and dtype == torch.float32:
+        return _ops().key_expand(k, _numel(shape), 4).reshape(*k.shape, *tuple(shape))
     u = uniform(k, shape, dtype)
     return (u - 0.5) * 3.4641016151377544
+
+
+def fold_key(k: torch.Tensor, data: torch.Tensor) -> torch.Tensor:
+    """Per-element fold of an int64 tensor into keys of the same shape:
+    mix(k ^ mix(data + GOLDEN))."""
+    if k.is_cuda:
+        return _ops().key_fold(k, data)
+    return _mix(k ^ _mix(data + _GOLDEN))
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s in tuple(shape):
+        n *= s
+    return n
 
 
 def permutation(k: torch.Tensor, n: int) -> torch.Tensor:

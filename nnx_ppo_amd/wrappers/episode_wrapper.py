@@ -16,6 +16,17 @@ class EpisodeWrapper:
 
     def step(self, state, action):
         next_state = self.env.step(state, action)
+        if state.info["step_counter"].is_cuda:
+            # the same integer / flag arithmetic in one launch (csrc/keys.hip)
+            from .. import ops
+
+            prev = next_state.info.get("truncated", None)
+            c, t, d = ops.episode_step(state.info["step_counter"], next_state.done,
+                                       prev if isinstance(prev, torch.Tensor) else None,
+                                       self.max_len)
+            next_state.info["step_counter"] = c
+            next_state.info["truncated"] = t
+            return next_state.replace(done=d)
         next_state.info["step_counter"] = state.info["step_counter"] + 1
         prev_trunc = next_state.info.get("truncated", False)
         over = next_state.info["step_counter"] >= self.max_len

@@ -1,0 +1,96 @@
+"""Integer key kernels and episode bookkeeping: the HIP kernels must reproduce
+the integer torch expressions of nnx_ppo_amd/random.py (evaluated on CPU) bit
+for bit — this is what makes env resets, minibatch permutations and episode
+counters identical between the CPU oracle run and the GPU run."""
+import pytest
+import torch
+
+from nnx_ppo_amd import random as keys
+
+pytestmark = pytest.mark.gpu
+
+
+def test_key_ops_bit_exact_vs_cpu(dev):
+    k = keys.key(1234)
+    kc = keys.split(k, 1000)            # CPU path
+    kg = keys.split(k.to(dev), 1000)    # HIP path
+    assert torch.equal(kg.cpu(), kc)
+    assert torch.equal(keys.split(kg, (3, 2)).cpu(), keys.split(kc, (3, 2)))
+    assert torch.equal(keys.bits(kg, (7,)).cpu(), keys.bits(kc, (7,)))
+    assert torch.equal(keys.randint(kg, (), 0, 500).cpu(), keys.randint(kc, (), 0, 500))
+    assert torch.equal(keys.randint(kg, (4,), -3, 11).cpu(), keys.randint(kc, (4,), -3, 11))
+    assert torch.equal(keys.uniform(kg, (5,)).cpu(), keys.uniform(kc, (5,)))
+    assert torch.equal(keys.unit_uniform(kg, (17,)).cpu(), keys.unit_uniform(kc, (17,)))
+    data = torch.arange(1000, dtype=torch.int64) * 7 - 3
+    assert torch.equal(keys.fold_key(kg, data.to(dev)).cpu(), keys.fold_key(kc, data))
+    assert int(keys.fold_in(k.to(dev), 5)) == int(keys.fold_in(k, 5))
+    p_g = keys.permutation(keys.fold_in(k.to(dev), 2), 4096)
+    assert torch.equal(p_g.cpu(), keys.permutation(keys.fold_in(k, 2), 4096))
+    # scalar key and empty shapes
+    assert torch.equal(keys.split(k.to(dev)).cpu(), keys.split(k))
+    assert keys.split(kg[:0], 3).shape == (0, 3)
+
+
+def test_envs_identical_on_cpu_and_gpu(dev):
+    from nnx_ppo_amd.envs import DummyCounterEnv, MockEnv, cheetah_shaped
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    for mk in (lambda: EpisodeWrapper(MockEnv(5, 1, max_steps=4), 9),
+               lambda: EpisodeWrapper(cheetah_shaped(max_steps=6), 7),
+               lambda: DummyCounterEnv()):
+        ec, eg = mk(), mk()
+        kc = keys.split(keys.key(3), 64)
+        sc, sg = ec.reset(kc), eg.reset(kc.to(dev))
+        for _ in range(12):
+            a = torch.zeros(64, 1)
+            sc, sg = ec.step(sc, a), eg.step(sg, a.to(dev))
+            lc = [x for x in _leaves(sc)]
+            lg = [x for x in _leaves(sg)]
+            assert len(lc) == len(lg)
+            for x, y in zip(lc, lg):
+                assert x.dtype == y.dtype and torch.equal(x, y.cpu())
+
+
+def _leaves(s):
+    from nnx_ppo_amd.tree import tree_leaves
+
+    return tree_leaves(s)
+
+
+def test_episode_step_kernel(dev):
+    from nnx_ppo_amd import ops
+
+    n = 1000
+    g = torch.Generator().manual_seed(0)
+    c = torch.randint(0, 12, (n,), generator=g)
+    d_f = (torch.rand(n, generator=g) < 0.2).float()
+    tr = torch.rand(n, generator=g) < 0.1
+    for done, trunc in ((d_f, None), (d_f != 0, tr), (d_f, tr)):
+        co, to, do = ops.episode_step(c.to(dev), done.to(dev),
+                                      None if trunc is None else trunc.to(dev), 10)
+        wc = c + 1
+        wt = (wc >= 10) | (trunc if trunc is not None else torch.zeros(n, dtype=torch.bool))
+        wd = ((done != 0) | wt).float()
+        assert torch.equal(co.cpu(), wc) and torch.equal(to.cpu(), wt) and torch.equal(do.cpu(), wd)
+        assert to.dtype == torch.bool and do.dtype == torch.float32
+
+
+def test_select_rows_multi(dev):
+    from nnx_ppo_amd import ops
+
+    B = 257
+    g = torch.Generator().manual_seed(2)
+    mask = torch.rand(B, generator=g) < 0.4
+    pairs = []
+    for i in range(19):  # > 16: exercises the batching
+        shape = [(B,), (B, 5), (B, 3, 2), (B, 64)][i % 4]
+        dt = [torch.float32, torch.int64, torch.bool, torch.uint8][i % 4]
+        mk = lambda: (torch.randn(shape, generator=g) * 50).to(dt)
+        a, b = mk(), mk()
+        if i % 5 == 4 and len(shape) > 1:
+            a = a[0].clone()  # broadcast row
+        pairs.append((a, b))
+    outs = ops.select_rows_multi(mask.to(dev), [(a.to(dev), b.to(dev)) for a, b in pairs])
+    for (a, b), o in zip(pairs, outs):
+        m = mask.reshape(B, *([1] * (b.dim() - 1)))
+        assert torch.equal(o.cpu(), torch.where(m, a if a.shape == b.shape else a.expand_as(b), b))
