@@ -190,6 +190,29 @@ int mi_dense_bwd_dw_bf16(const void* xt_bf, int64_t ldxt, const void* dzt_bf, in
                          float* g_w, float* g_b, void* workspace, int64_t M, int64_t K,
                          int64_t N, int accumulate, mi_stream_t stream);
 
+/* ---- a20: GRU carry (persistent T-loop) ------------------------------------ */
+
+/* GRU over a sequence with reset-on-done.  The reference has no GRU; the module
+ * contract is the LSTM wrapper's (`nnx_ppo/networks/recurrent.py:89-161`: zeros
+ * init, zeros-like reset, output = new hidden state) and the cell is flax's
+ * GRUCell (r, z, n gates; h' = (1-z) n + z h; hidden-side bias on n only).
+ * gi [T,B,3H] = x W_i + b_i (computed by the dense kernels); w_h [H,3H];
+ * b_hn [H]; h0 [B,H]; done [T,B] uint8 (nullable = never).  Outputs: h_out
+ * [T,B,H] (pre-reset h'), h_final [B,H] (post-reset carry); for training also
+ * h_prev_out [T,B,H] (state entering each step) and gates_out [T,B,4H]
+ * (r, z, n, gh_n + b_hn), both nullable. */
+int mi_gru_seq_fwd_f32(const float* gi, const float* w_h, const float* b_hn, const float* h0,
+                       const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out,
+                       float* h_final, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
+/* BPTT of the above: from g_h [T,B,H] (gradient w.r.t. h_out) to dgi [T,B,3H]
+ * (gradient w.r.t. gi) and dgh [T,B,3H] (gradient w.r.t. h W_h); dh0 [B,H]
+ * nullable.  dW_h = h_prev^T dgh, db_hn, dW_i, db_i, dx follow as time-batched
+ * GEMMs (dense kernels). */
+int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const float* h_prev,
+                       const float* w_h, const uint8_t* done, float* dgi, float* dgh, float* dh0,
+                       int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
 /* ---- a14: loss terms ---------------------------------------------------- */
 
 /* Advantage statistics for `ppo.py:477-480`: stats[3] = (sum, sum of squares,

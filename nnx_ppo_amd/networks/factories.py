@@ -10,6 +10,7 @@ from .adapter import PPOAdapter
 from .containers import Sequential
 from .feedforward import Dense
 from .normalizer import Normalizer
+from .recurrent import GRU
 from .sampling_layers import NormalTanhSampler
 from .types import Rngs, StatefulModule
 
@@ -52,6 +53,43 @@ def make_mlp_actor_critic(
     actor_layers = make_mlp_layers([obs_size] + list(actor_hidden_sizes) + [action_size * 2],
                                    rngs, activation, activation_last_layer=False,
                                    kernel_init=kernel_init)
+    critic = make_mlp([obs_size] + list(critic_hidden_sizes) + [1], rngs, activation,
+                      activation_last_layer=False, kernel_init=kernel_init)
+    sampler = NormalTanhSampler(rngs, entropy_weight=entropy_weight, min_std=min_std,
+                                std_scale=std_scale)
+    adapter = PPOAdapter(action=Sequential([*actor_layers, sampler]), value=critic)
+    if normalize_obs:
+        return Sequential([Normalizer(obs_size), adapter])
+    return adapter
+
+
+def make_gru_actor_critic(
+    obs_size: int,
+    action_size: int,
+    hidden_size: int,
+    critic_hidden_sizes: list[int],
+    rngs: Rngs,
+    activation: Union[Any, str] = activations.relu,
+    normalize_obs: bool = True,
+    initializer_scale: float = 1.0,
+    entropy_weight: float = 1e-2,
+    min_std: float = 1e-1,
+    std_scale: float = 1.0,
+) -> StatefulModule:
+    """Recurrent actor / feed-forward critic (BASELINE.json config 4).  The
+    reference has no recurrent factory; this composes the network the way its
+    tests hand-compose an LSTM actor (`recurrent_test.py:245-261`):
+    actor = Dense(obs -> H, act) -> GRU(H -> H) -> Dense(H -> 2A) -> sampler."""
+    if isinstance(activation, str):
+        activation = {"swish": activations.swish, "tanh": activations.tanh,
+                      "relu": activations.relu}[activation]
+    kernel_init = initializers.variance_scaling(initializer_scale, "fan_in", "uniform")
+    actor_layers = [
+        Dense(obs_size, hidden_size, rngs, activation=activation, kernel_init=kernel_init),
+        GRU(hidden_size, hidden_size, rngs, kernel_init=kernel_init,
+            recurrent_kernel_init=kernel_init),
+        Dense(hidden_size, action_size * 2, rngs, activation=None, kernel_init=kernel_init),
+    ]
     critic = make_mlp([obs_size] + list(critic_hidden_sizes) + [1], rngs, activation,
                       activation_last_layer=False, kernel_init=kernel_init)
     sampler = NormalTanhSampler(rngs, entropy_weight=entropy_weight, min_std=min_std,

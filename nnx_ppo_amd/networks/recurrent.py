@@ -1,0 +1,95 @@
+"""Recurrent modules (counterpart of `nnx_ppo/networks/recurrent.py`).
+
+The reference ships an LSTM wrapper only; BASELINE.json asks for a GRU carry, so
+`GRU` obeys that wrapper's StatefulModule contract (recurrent.py:89-161): state
+`[B, H]` zeros at `initialize_state`, zeros-like at `reset_state`, output = new
+hidden state, `regularization_loss = zeros(B)`, no rollout extras.  The cell is
+flax's GRUCell (third-party; arithmetic PARITY UNPINNED):
+
+    r = sigmoid(x W_ir + b_ir + h W_hr)
+    z = sigmoid(x W_iz + b_iz + h W_hz)
+    n = tanh(x W_in + b_in + r * (h W_hn + b_hn))
+    h' = (1 - z) n + z h
+
+Weights are packed `w_i [in, 3H]`, `b_i [3H]`, `w_h [H, 3H]`, `b_hn [H]` with gate
+order (r, z, n).  The input projection is one time-batched GEMM; the recurrence
+runs in a persistent kernel that keeps the carry in LDS across the T loop
+(csrc/gru.hip); BPTT is its mirror plus time-batched GEMMs for the weights."""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from .. import ops
+from . import initializers
+from .types import Parameter, Rngs, StatefulModule, StatefulModuleOutput
+
+
+class GRU(StatefulModule):
+    def __init__(self, in_features: int, hidden_features: int, rngs: Rngs, *, kernel_init=None,
+                 recurrent_kernel_init=None):
+        if hidden_features > 256:
+            raise ValueError("GRU: hidden_features <= 256 in this build")
+        self.in_features = in_features
+        self.hidden_features = hidden_features
+        gen = rngs.generator()
+        ki = kernel_init or initializers.lecun_normal()
+        kr = recurrent_kernel_init or initializers.lecun_normal()
+        H = hidden_features
+        import numpy as np
+
+        self.w_i = Parameter(np.concatenate([ki(gen, (in_features, H)) for _ in range(3)], axis=1))
+        self.b_i = Parameter(np.zeros(3 * H, dtype=np.float32))
+        self.w_h = Parameter(np.concatenate([kr(gen, (H, H)) for _ in range(3)], axis=1))
+        self.b_hn = Parameter(np.zeros(H, dtype=np.float32))
+
+    def _gi(self, x2: torch.Tensor) -> torch.Tensor:
+        return ops.dense_fwd(x2, self.w_i.data, self.b_i.data, ops.ACT_NONE)
+
+    def __call__(self, state: torch.Tensor, x: torch.Tensor,
+                 rollout_extras: Any = None) -> StatefulModuleOutput:
+        B = x.shape[0]
+        gi = self._gi(x.reshape(B, self.in_features)).view(1, B, 3 * self.hidden_features)
+        h_out, _, _, _ = ops.gru_seq_fwd(gi, self.w_h.data, self.b_hn.data, state.contiguous(),
+                                         None, train=False)
+        h = h_out[0]
+        return StatefulModuleOutput(next_state=h, output=h,
+                                    regularization_loss=torch.zeros(B, device=x.device),
+                                    metrics={}, rollout_extras=None)
+
+    def initialize_state(self, batch_size: int) -> torch.Tensor:
+        return torch.zeros(batch_size, self.hidden_features, dtype=torch.float32,
+                           device=self.device)
+
+    def reset_state(self, prev_state: torch.Tensor) -> torch.Tensor:
+        return torch.zeros_like(prev_state)
+
+    # ---- training protocol --------------------------------------------------------
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+        T, B, _ = x_seq.shape
+        H = self.hidden_features
+        x2 = x_seq.reshape(T * B, self.in_features)
+        gi = self._gi(x2).view(T, B, 3 * H)
+        h_out, h_prev, gates, h_final = ops.gru_seq_fwd(
+            gi, self.w_h.data, self.b_hn.data, state0.contiguous(), done_seq.contiguous(),
+            train=True)
+        ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad)
+        return ctx, h_out, None, h_final
+
+    def replay_backward(self, ctx, g_out, g_reg):
+        x2, h_prev, gates, done_seq, (T, B), need_input_grad = ctx
+        H = self.hidden_features
+        dgi, dgh = ops.gru_seq_bwd(g_out.contiguous(), gates, h_prev, self.w_h.data,
+                                   done_seq.contiguous())
+        dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)
+        gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
+        ops.dense_bwd_dw(h_prev.view(T * B, H), dgh2, None, self.w_h.grad, gb_h, ops.ACT_NONE,
+                         accumulate=True)
+        self.b_hn.grad += gb_h[2 * H:]
+        ops.dense_bwd_dw(x2, dgi2, None, self.w_i.grad, self.b_i.grad, ops.ACT_NONE,
+                         accumulate=True)
+        if not need_input_grad:
+            return None
+        g_x = ops.dense_bwd_dx(dgi2, None, self.w_i.data, ops.ACT_NONE)
+        return g_x.view(T, B, self.in_features)
