@@ -190,6 +190,18 @@ int mi_dense_bwd_dw_bf16(const void* xt_bf, int64_t ldxt, const void* dzt_bf, in
                          float* g_w, float* g_b, void* workspace, int64_t M, int64_t K,
                          int64_t N, int accumulate, mi_stream_t stream);
 
+/* A whole MLP trunk (L <= 8 Dense layers, widths <= 512) in ONE launch: each
+ * workgroup walks 64 rows through every layer with the activations resident in
+ * LDS; only weights stream (bf16 W^T shadows, `wt_bf[l]` = [N_l][pad8 K_l]).
+ * dims[L+1] = (K_0, N_0 = K_1, ..., N_{L-1}); acts[L]; bias[l] nullable.
+ * out: fp32 [M][N_{L-1}].  Training stores (arrays nullable, entries nullable):
+ * y_bf[l] [M][pad8 N_l], yt_bf[l] [N_l][pad8 M], pre_bf[l] [M][pad8 N_l];
+ * xt_bf [K_0][pad8 M] = transposed bf16 copy of the input. */
+int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
+                    const float* const* bias, const int64_t* dims, const int64_t* acts,
+                    float* out, void* const* y_bf, void* const* yt_bf, void* const* pre_bf,
+                    void* xt_bf, mi_stream_t stream);
+
 /* ---- a20: GRU carry (persistent T-loop) ------------------------------------ */
 
 /* GRU over a sequence with reset-on-done.  The reference has no GRU; the module

@@ -289,6 +289,163 @@ weights_to_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, int
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused MLP chain forward: up to 8 Dense layers in ONE launch.  A workgroup owns
+// 64 rows (envs / samples) and walks them through every layer; the activations
+// never leave LDS (two ping-pong [64][W] bf16 buffers), only the layer weights
+// stream through (bf16 W^T k-tiles from L2, register-staged + double-buffered as
+// in nt_gemm_kernel).  Per-layer launch latency and the HBM round trip of every
+// intermediate activation are what bound the per-layer path at this workload's
+// shapes (K, N <= 512, M = 1k..30k), not MFMA rate.
+// Inference: only the fp32 output of the last layer is stored.  Training: each
+// layer also stores y (bf16), y^T (bf16, the dW operand) and, for swish, the
+// pre-activation — exactly the buffers the per-layer backward kernels consume.
+constexpr int CH_BM = 64;
+constexpr int CH_BN = 64;
+constexpr int CH_MAXL = 8;
+
+struct ChainLayer {
+  const bf16_t* wt;     // [N][ldwt] bf16 W^T
+  const float* bias;    // [N] or null
+  bf16_t* y_bf;         // [M][ldy] or null
+  bf16_t* yt_bf;        // [N][ldyt] or null
+  bf16_t* pre_bf;       // [M][ldy] or null
+  int64_t ldwt, ldy, ldyt;
+  int K, N, act;
+};
+struct Chain {
+  ChainLayer layer[CH_MAXL];
+  const float* x;       // [M][K0] fp32
+  float* out;           // [M][N_last] fp32
+  bf16_t* xt_bf;        // [K0][ldxt] transposed bf16 copy of the input, or null
+  int64_t ldxt;
+  int64_t M;
+  int L;
+};
+
+template <int MAXW>
+__global__ void __launch_bounds__(kThreads)
+mlp_fwd_kernel(Chain c) {
+  constexpr int AROW = MAXW + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t act[2][CH_BM][AROW];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][CH_BN][LROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * CH_BM;
+  const int K0 = c.layer[0].K;
+  const int K0p = (K0 + 31) / 32 * 32;
+
+  // stage 0: input tile fp32 -> bf16 (zero padded to a multiple of 32 columns)
+  for (int i = tid; i < CH_BM * K0p; i += kThreads) {
+    const int row = i / K0p, k = i % K0p;
+    const int64_t gi = i0 + row;
+    const float v = (gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f;
+    act[0][row][k] = (bf16_t)v;
+    if (c.xt_bf && gi < c.M && k < K0) c.xt_bf[(int64_t)k * c.ldxt + gi] = (bf16_t)v;
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int l = 0; l < c.L; ++l) {
+    const ChainLayer ly = c.layer[l];
+    const int Kp = (ly.K + 31) / 32 * 32;
+    const int Np = (ly.N + 31) / 32 * 32;
+    const bool last = l == c.L - 1;
+    const int nxt = cur ^ 1;
+    // zero the padding columns of the output buffer (read as reduce elements by layer l+1)
+    if (!last && Np != ly.N) {
+      for (int i = tid; i < CH_BM * (Np - ly.N); i += kThreads)
+        act[nxt][i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
+    }
+    for (int n0 = 0; n0 < ly.N; n0 += CH_BN) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // B tile: CH_BN rows x 64 k = 512 chunks of 16 B, 2 per thread
+      u32x4 rb[2];
+      auto load_b = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int cidx = tid + p * kThreads;
+          const int row = cidx / 8, kc = cidx % 8;
+          const int64_t gj = n0 + row, gr = k0 + kc * 8;
+          rb[p] = u32x4{0u, 0u, 0u, 0u};
+          if (gj < ly.N && gr < ly.ldwt)
+            rb[p] = *reinterpret_cast<const u32x4*>(ly.wt + gj * ly.ldwt + gr);
+        }
+      };
+      auto store_b = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int cidx = tid + p * kThreads;
+          *reinterpret_cast<u32x4*>(&Bs[buf][cidx / 8][(cidx % 8) * 8]) = rb[p];
+        }
+      };
+      load_b(0);
+      store_b(0);
+      __syncthreads();
+      int buf = 0;
+      for (int k0 = 0; k0 < Kp; k0 += BK) {
+        const bool more = k0 + BK < Kp;
+        if (more) load_b(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+          if (k0 + ks * 32 < Kp) {
+            const int kof = ks * 32 + 8 * (lane >> 4);
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(
+                &act[cur][wave * 16 + (lane & 15)][k0 + kof]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const bf16x8 bfr =
+                  *reinterpret_cast<const bf16x8*>(&Bs[buf][b * 16 + (lane & 15)][kof]);
+              acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[b], 0, 0, 0);
+            }
+          }
+        }
+        if (more) store_b(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+      // epilogue of this n-tile
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = n0 + b * 16 + (lane & 15);
+        if (j >= ly.N) continue;
+        const float bj = ly.bias ? ly.bias[j] : 0.0f;
+        const int rb0 = wave * 16 + 4 * (lane >> 4);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = acc[b][e] + bj;
+          v[e] = act_fwd(z, ly.act);
+          const int64_t gi = i0 + rb0 + e;
+          if (!last) act[nxt][rb0 + e][j] = (bf16_t)v[e];
+          if (gi < c.M) {
+            if (ly.pre_bf) ly.pre_bf[gi * ly.ldy + j] = (bf16_t)z;
+            if (ly.y_bf) ly.y_bf[gi * ly.ldy + j] = (bf16_t)v[e];
+            if (last) c.out[gi * ly.N + j] = v[e];
+          }
+        }
+        if (ly.yt_bf) {
+          bf16_t* dst = ly.yt_bf + (int64_t)j * ly.ldyt + i0 + rb0;
+          if (i0 + rb0 + 3 < c.M) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(dst) = pk;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (i0 + rb0 + e < c.M) dst[e] = (bf16_t)v[e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+}
+
 int stream_grid(int64_t n) {
   int64_t g = mippo::ceil_div(n, kThreads);
   if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
@@ -459,4 +616,52 @@ extern "C" int mi_dense_bwd_dw_bf16(const void* xt_bf, int64_t ldxt, const void*
                              static_cast<const bf16_t*>(dzt_bf), lddzt, K, N, R, ep, S_eff, st);
   if (rc) return rc;
   return mippo::reduce_slabs(ep.slabs, g_w, g_b, S_eff, K * N, N, accumulate, st);
+}
+
+extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
+                               const float* const* bias, const int64_t* dims,
+                               const int64_t* acts, float* out, void* const* y_bf,
+                               void* const* yt_bf, void* const* pre_bf, void* xt_bf,
+                               mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && L >= 1 && L <= CH_MAXL, "mi_mlp_fwd_bf16: 1 <= L <= %d", CH_MAXL);
+  if (M == 0) return 0;
+  MI_REQUIRE(x && wt_bf && dims && acts && out, "mi_mlp_fwd_bf16: null pointer");
+  Chain c = {};
+  c.x = x;
+  c.out = out;
+  c.M = M;
+  c.L = (int)L;
+  c.xt_bf = static_cast<bf16_t*>(xt_bf);
+  const int64_t Mp = mippo::ceil_div(M, 8) * 8;
+  c.ldxt = Mp;
+  int maxw = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t K = dims[l], N = dims[l + 1];
+    MI_REQUIRE(K >= 1 && N >= 1 && K <= 512 && N <= 512,
+               "mi_mlp_fwd_bf16: layer widths must be in [1, 512]");
+    MI_REQUIRE(acts[l] >= MI_ACT_NONE && acts[l] <= MI_ACT_SWISH, "mi_mlp_fwd_bf16: bad act");
+    MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "mi_mlp_fwd_bf16: weights must be 16-byte aligned");
+    ChainLayer& ly = c.layer[l];
+    ly.wt = static_cast<const bf16_t*>(wt_bf[l]);
+    ly.ldwt = mippo::ceil_div(K, 8) * 8;
+    ly.bias = bias ? bias[l] : nullptr;
+    ly.K = (int)K;
+    ly.N = (int)N;
+    ly.act = (int)acts[l];
+    ly.ldy = mippo::ceil_div(N, 8) * 8;
+    ly.ldyt = Mp;
+    ly.y_bf = y_bf ? static_cast<bf16_t*>(y_bf[l]) : nullptr;
+    ly.yt_bf = yt_bf ? static_cast<bf16_t*>(yt_bf[l]) : nullptr;
+    ly.pre_bf = pre_bf ? static_cast<bf16_t*>(pre_bf[l]) : nullptr;
+    const int w = (int)(mippo::ceil_div(K > N ? K : N, 32) * 32);
+    if (w > maxw) maxw = w;
+  }
+  dim3 grid((unsigned)mippo::ceil_div(M, CH_BM));
+  hipStream_t st = mippo::as_stream(stream);
+  if (maxw <= 256) {
+    hipLaunchKernelGGL(mlp_fwd_kernel<256>, grid, dim3(kThreads), 0, st, c);
+  } else {
+    hipLaunchKernelGGL(mlp_fwd_kernel<512>, grid, dim3(kThreads), 0, st, c);
+  }
+  return mippo::check_launch("mi_mlp_fwd_bf16");
 }

@@ -41,8 +41,28 @@ def _bias(layer):
     return layer.bias.data if layer.bias is not None else None
 
 
+FUSED_MAX_LAYERS = 8
+FUSED_MAX_WIDTH = 512
+
+
+def _fusable(layers) -> bool:
+    return len(layers) <= FUSED_MAX_LAYERS and all(
+        l.in_features <= FUSED_MAX_WIDTH and l.out_features <= FUSED_MAX_WIDTH for l in layers)
+
+
+def _chain_args(layers):
+    wts = [_shadows(l)[1] for l in layers]
+    biases = [_bias(l) for l in layers]
+    dims = [layers[0].in_features] + [l.out_features for l in layers]
+    acts = [l.act_code for l in layers]
+    return wts, biases, dims, acts
+
+
 def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
     """fp32 [M, K0] -> fp32 [M, N_last]; no activations are kept."""
+    if _fusable(layers):
+        out, _ = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=False)
+        return out
     x_bf, _ = ops.cast_pad_bf16(x2, want_t=False)
     y = None
     for i, layer in enumerate(layers):
@@ -58,6 +78,10 @@ def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
 def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
     """Returns (ctx, fp32 output [M, N_last])."""
     M = x2.shape[0]
+    if _fusable(layers):
+        y, sv = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=True)
+        saved = [(xt, aux, _shadows(l)[0]) for (xt, aux), l in zip(sv, layers)]
+        return (saved, M, need_input_grad), y
     x_bf, xt_bf = ops.cast_pad_bf16(x2, want_t=True)
     saved = []
     y = None

@@ -314,6 +314,49 @@ def dense_bwd_dw_bf16(xt_bf, dzt_bf, g_w, g_b, M: int, accumulate: bool = True) 
                                      N, int(bool(accumulate)), stream()), "mi_dense_bwd_dw_bf16")
 
 
+def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
+                 train: bool):
+    """Fused MLP trunk forward.  Returns (out_f32 [M, N_last], saved) where `saved`
+    (training only) is a list per layer of (xt_bf, aux_bf) — the transposed input
+    of the layer and the tensor its activation derivative is evaluated on."""
+    M, K0 = x.shape
+    L = len(wts)
+    _need(len(dims) == L + 1 and dims[0] == K0 and len(acts) == L, "mlp_fwd_bf16: dims/acts")
+    dev = x.device
+    out = torch.empty(M, dims[-1], dtype=f32, device=dev)
+    P = ctypes.c_void_p * L
+    I = ctypes.c_int64 * (L + 1)
+    y_bf = [None] * L
+    yt_bf = [None] * L
+    pre_bf = [None] * L
+    xt = None
+    if train:
+        xt = _bf_buf(K0, M, dev)
+        for l in range(L):
+            last = l == L - 1
+            N = dims[l + 1]
+            if (not last) or acts[l] != ACT_NONE:
+                y_bf[l] = _bf_buf(M, N, dev)
+            if not last:
+                yt_bf[l] = _bf_buf(N, M, dev)
+            if acts[l] == ACT_SWISH:
+                pre_bf[l] = _bf_buf(M, N, dev)
+    arr = lambda ts: P(*[ptr(t) for t in ts])
+    check(lib().mi_mlp_fwd_bf16(
+        ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
+        (ctypes.c_int64 * L)(*[int(a) for a in acts]), ptr(out, f32),
+        arr(y_bf) if train else None, arr(yt_bf) if train else None,
+        arr(pre_bf) if train else None, ptr(xt), stream()), "mi_mlp_fwd_bf16")
+    if not train:
+        return out, None
+    saved = []
+    for l in range(L):
+        xt_l = xt if l == 0 else yt_bf[l - 1]
+        aux = pre_bf[l] if acts[l] == ACT_SWISH else y_bf[l]
+        saved.append((xt_l, aux))
+    return out, saved
+
+
 # ------------------------------------------------------------- a14: loss
 def _loss_ws(device):
     return workspace(device, "loss", lib().mi_ppo_loss_workspace_bytes(1))

@@ -177,3 +177,48 @@ def test_bf16_gradients_close_to_f32_path(dev):
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         rel = float((a - b).norm() / a.norm())
         assert cos > 0.99 and rel < 0.15, (name, cos, rel)
+
+
+@pytest.mark.parametrize("dims", [[5, 64, 64, 64, 64, 2], [5, 256, 256, 1], [17, 256, 256, 256, 256, 12],
+                                  [17, 512, 512, 1], [33, 40, 129, 7], [3, 8]])
+@pytest.mark.parametrize("M", [1, 1000, 4096])
+@pytest.mark.parametrize("act", ["relu", "swish"])
+def test_fused_mlp_forward_matches_per_layer_path(dev, dims, M, act):
+    """The one-launch MLP trunk must reproduce the per-layer bf16 kernels (same
+    MFMA, same k-order, same bf16 rounding points): outputs equal to fp32
+    round-off, stored activations (y, y^T, pre-activation, x^T) identical."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(M + len(dims))
+    L = len(dims) - 1
+    code = ops.ACT_CODES[act]
+    acts = [code] * (L - 1) + [ops.ACT_NONE]
+    x = torch.as_tensor(rng.normal(size=(M, dims[0])).astype(np.float32)).to(dev)
+    wts, wbs, biases = [], [], []
+    for l in range(L):
+        K, N = dims[l], dims[l + 1]
+        w = torch.as_tensor((rng.normal(size=(K, N)) / math.sqrt(K)).astype(np.float32)).to(dev)
+        w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
+        wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
+        ops.weights_to_bf16(w, w_bf, wt_bf)
+        wts.append(wt_bf)
+        wbs.append(w_bf)
+        biases.append(torch.as_tensor(rng.normal(size=N).astype(np.float32)).to(dev))
+    out, saved = ops.mlp_fwd_bf16(x, wts, biases, dims, acts, train=True)
+    out_i, none = ops.mlp_fwd_bf16(x, wts, biases, dims, acts, train=False)
+    assert none is None and torch.equal(out, out_i)
+    # per-layer reference path
+    x_bf, xt_bf = ops.cast_pad_bf16(x, want_t=True)
+    assert torch.equal(saved[0][0], xt_bf)
+    y = None
+    for l in range(L):
+        last = l == L - 1
+        y, y_bf, yt_bf, pre = ops.dense_fwd_bf16(x_bf, wts[l], biases[l], dims[l], dims[l + 1],
+                                                 acts[l], want_f32=True, want_bf=True,
+                                                 want_t=True, want_preact=acts[l] == ops.ACT_SWISH)
+        if not last:
+            aux = pre if acts[l] == ops.ACT_SWISH else y_bf
+            assert torch.equal(saved[l][1][:, :dims[l + 1]], aux[:, :dims[l + 1]]), l
+            assert torch.equal(saved[l + 1][0][:, :M], yt_bf[:, :M]), l
+        x_bf = y_bf
+    assert torch.allclose(out, y, rtol=1e-5, atol=1e-5)
