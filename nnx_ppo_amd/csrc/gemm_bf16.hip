@@ -323,18 +323,71 @@ struct Chain {
   int L;
 };
 
+struct Step {
+  int l, n0, k0;
+};
+
+__device__ inline bool step_valid(const Chain& c, const Step& s) { return s.l < c.L; }
+
+// (layer, n-tile, k-tile) in execution order: k fastest, then n, then layer.
+__device__ inline Step step_next(const Chain& c, Step s) {
+  const int Kp = (c.layer[s.l].K + 31) / 32 * 32;
+  s.k0 += BK;
+  if (s.k0 >= Kp) {
+    s.k0 = 0;
+    s.n0 += CH_BN;
+    if (s.n0 >= c.layer[s.l].N) {
+      s.n0 = 0;
+      s.l += 1;
+    }
+  }
+  return s;
+}
+
+// The whole trunk is ONE software pipeline over its flattened (layer, n-tile,
+// k-tile) steps: the weight tile of step i+2 is in flight (global -> registers)
+// while step i computes, and is parked in a 3-slot LDS ring one step later — so
+// the L2 latency of a weight fetch is covered by two steps of MFMA work even
+// across n-tile and LAYER boundaries (weights do not depend on activations).
 template <int MAXW>
 __global__ void __launch_bounds__(kThreads)
 mlp_fwd_kernel(Chain c) {
   constexpr int AROW = MAXW + 8;
+  constexpr int NSLOT = 3;
   __shared__ __attribute__((aligned(16))) bf16_t act[2][CH_BM][AROW];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][CH_BN][LROW];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[NSLOT][CH_BN][LROW];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int64_t i0 = (int64_t)blockIdx.x * CH_BM;
   const int K0 = c.layer[0].K;
   const int K0p = (K0 + 31) / 32 * 32;
+
+  auto load_b = [&](const Step& s, u32x4 (&r)[2]) {
+    const ChainLayer& ly = c.layer[s.l];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int cidx = tid + p * kThreads;
+      const int row = cidx / 8, kc = cidx % 8;
+      const int64_t gj = s.n0 + row, gr = s.k0 + kc * 8;
+      r[p] = u32x4{0u, 0u, 0u, 0u};
+      if (gj < ly.N && gr < ly.ldwt)
+        r[p] = *reinterpret_cast<const u32x4*>(ly.wt + gj * ly.ldwt + gr);
+    }
+  };
+  auto store_b = [&](int slot, const u32x4 (&r)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int cidx = tid + p * kThreads;
+      *reinterpret_cast<u32x4*>(&Bs[slot][cidx / 8][(cidx % 8) * 8]) = r[p];
+    }
+  };
+
+  Step s0 = {0, 0, 0};
+  Step s1 = step_next(c, s0);
+  u32x4 ra[2], rb[2];
+  load_b(s0, ra);
+  if (step_valid(c, s1)) load_b(s1, rb);
 
   // stage 0: input tile fp32 -> bf16 (zero padded to a multiple of 32 columns)
   for (int i = tid; i < CH_BM * K0p; i += kThreads) {
@@ -344,105 +397,96 @@ mlp_fwd_kernel(Chain c) {
     act[0][row][k] = (bf16_t)v;
     if (c.xt_bf && gi < c.M && k < K0) c.xt_bf[(int64_t)k * c.ldxt + gi] = (bf16_t)v;
   }
+  store_b(0, ra);
   __syncthreads();
 
-  int cur = 0;
-  for (int l = 0; l < c.L; ++l) {
-    const ChainLayer ly = c.layer[l];
+  f32x4 acc[4];
+  // one pipeline step: compute `s` from ring slot `slot`; `ld` receives the tile of
+  // step s+2, `st` (loaded one step ago, tile of step s+1) is parked in slot+1.
+  auto run_step = [&](const Step& s, int slot, u32x4 (&ld)[2], const u32x4 (&st)[2]) {
+    const ChainLayer& ly = c.layer[s.l];
     const int Kp = (ly.K + 31) / 32 * 32;
-    const int Np = (ly.N + 31) / 32 * 32;
-    const bool last = l == c.L - 1;
-    const int nxt = cur ^ 1;
-    // zero the padding columns of the output buffer (read as reduce elements by layer l+1)
-    if (!last && Np != ly.N) {
-      for (int i = tid; i < CH_BM * (Np - ly.N); i += kThreads)
-        act[nxt][i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
-    }
-    for (int n0 = 0; n0 < ly.N; n0 += CH_BN) {
-      f32x4 acc[4];
+    const int cur = s.l & 1, nxt = cur ^ 1;
+    const bool last = s.l == c.L - 1;
+    const Step s1n = step_next(c, s);
+    const Step s2n = step_valid(c, s1n) ? step_next(c, s1n) : s1n;
+    if (step_valid(c, s1n) && step_valid(c, s2n)) load_b(s2n, ld);
+    if (s.k0 == 0) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // B tile: CH_BN rows x 64 k = 512 chunks of 16 B, 2 per thread
-      u32x4 rb[2];
-      auto load_b = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int cidx = tid + p * kThreads;
-          const int row = cidx / 8, kc = cidx % 8;
-          const int64_t gj = n0 + row, gr = k0 + kc * 8;
-          rb[p] = u32x4{0u, 0u, 0u, 0u};
-          if (gj < ly.N && gr < ly.ldwt)
-            rb[p] = *reinterpret_cast<const u32x4*>(ly.wt + gj * ly.ldwt + gr);
+      if (s.n0 == 0 && !last) {
+        const int Np = (ly.N + 31) / 32 * 32;
+        if (Np != ly.N) {
+          for (int i = tid; i < CH_BM * (Np - ly.N); i += kThreads)
+            act[nxt][i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
         }
-      };
-      auto store_b = [&](int buf) {
+      }
+    }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int cidx = tid + p * kThreads;
-          *reinterpret_cast<u32x4*>(&Bs[buf][cidx / 8][(cidx % 8) * 8]) = rb[p];
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      if (s.k0 + ks * 32 < Kp) {
+        const int kof = ks * 32 + 8 * (lane >> 4);
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(
+            &act[cur][wave * 16 + (lane & 15)][s.k0 + kof]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bf16x8 bfr =
+              *reinterpret_cast<const bf16x8*>(&Bs[slot][b * 16 + (lane & 15)][kof]);
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[b], 0, 0, 0);
         }
-      };
-      load_b(0);
-      store_b(0);
-      __syncthreads();
-      int buf = 0;
-      for (int k0 = 0; k0 < Kp; k0 += BK) {
-        const bool more = k0 + BK < Kp;
-        if (more) load_b(k0 + BK);
+      }
+    }
+    if (s.k0 + BK >= Kp) {  // last k-tile of this n-tile: epilogue
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-          if (k0 + ks * 32 < Kp) {
-            const int kof = ks * 32 + 8 * (lane >> 4);
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(
-                &act[cur][wave * 16 + (lane & 15)][k0 + kof]);
+      for (int b = 0; b < 4; ++b) {
+        const int j = s.n0 + b * 16 + (lane & 15);
+        if (j < ly.N) {
+          const float bj = ly.bias ? ly.bias[j] : 0.0f;
+          const int rb0 = wave * 16 + 4 * (lane >> 4);
+          float v[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const bf16x8 bfr =
-                  *reinterpret_cast<const bf16x8*>(&Bs[buf][b * 16 + (lane & 15)][kof]);
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[b], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            const float z = acc[b][e] + bj;
+            v[e] = act_fwd(z, ly.act);
+            const int64_t gi = i0 + rb0 + e;
+            if (!last) act[nxt][rb0 + e][j] = (bf16_t)v[e];
+            if (gi < c.M) {
+              if (ly.pre_bf) ly.pre_bf[gi * ly.ldy + j] = (bf16_t)z;
+              if (ly.y_bf) ly.y_bf[gi * ly.ldy + j] = (bf16_t)v[e];
+              if (last) c.out[gi * ly.N + j] = v[e];
+            }
+          }
+          if (ly.yt_bf) {
+            bf16_t* dst = ly.yt_bf + (int64_t)j * ly.ldyt + i0 + rb0;
+            if (i0 + rb0 + 3 < c.M) {
+              typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+              bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              *reinterpret_cast<bf16x4*>(dst) = pk;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (i0 + rb0 + e < c.M) dst[e] = (bf16_t)v[e];
             }
           }
         }
-        if (more) store_b(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-      }
-      // epilogue of this n-tile
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = n0 + b * 16 + (lane & 15);
-        if (j >= ly.N) continue;
-        const float bj = ly.bias ? ly.bias[j] : 0.0f;
-        const int rb0 = wave * 16 + 4 * (lane >> 4);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = acc[b][e] + bj;
-          v[e] = act_fwd(z, ly.act);
-          const int64_t gi = i0 + rb0 + e;
-          if (!last) act[nxt][rb0 + e][j] = (bf16_t)v[e];
-          if (gi < c.M) {
-            if (ly.pre_bf) ly.pre_bf[gi * ly.ldy + j] = (bf16_t)z;
-            if (ly.y_bf) ly.y_bf[gi * ly.ldy + j] = (bf16_t)v[e];
-            if (last) c.out[gi * ly.N + j] = v[e];
-          }
-        }
-        if (ly.yt_bf) {
-          bf16_t* dst = ly.yt_bf + (int64_t)j * ly.ldyt + i0 + rb0;
-          if (i0 + rb0 + 3 < c.M) {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *reinterpret_cast<bf16x4*>(dst) = pk;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (i0 + rb0 + e < c.M) dst[e] = (bf16_t)v[e];
-          }
-        }
       }
     }
+    if (step_valid(c, s1n)) store_b((slot + 1) % NSLOT, st);
     __syncthreads();
-    cur = nxt;
+  };
+
+  // steps alternate between the two register sets: (load -> ra, park rb), then
+  // (load -> rb, park ra); at entry rb holds the tile of step 1.
+  Step s = s0;
+  int slot = 0;
+  while (step_valid(c, s)) {
+    run_step(s, slot, ra, rb);
+    s = step_next(c, s);
+    slot = (slot + 1) % NSLOT;
+    if (!step_valid(c, s)) break;
+    run_step(s, slot, rb, ra);
+    s = step_next(c, s);
+    slot = (slot + 1) % NSLOT;
   }
 }
 

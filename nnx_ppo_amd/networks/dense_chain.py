@@ -43,10 +43,15 @@ def _bias(layer):
 
 FUSED_MAX_LAYERS = 8
 FUSED_MAX_WIDTH = 512
+# Measured on MI355X (profiles/r01_*): the one-launch trunk wins while the grid
+# underfills the chip (rollout / bootstrap, M <= 8k rows: 28 us vs ~80 us of
+# per-layer launches); at M = 30 720 the per-layer NT kernels (up to 184 TF/s on
+# the 256x256 layer) are ahead of the trunk kernel's per-block latency chain.
+FUSED_MAX_ROWS = 8192
 
 
-def _fusable(layers) -> bool:
-    return len(layers) <= FUSED_MAX_LAYERS and all(
+def _fusable(layers, M: int) -> bool:
+    return M <= FUSED_MAX_ROWS and len(layers) <= FUSED_MAX_LAYERS and all(
         l.in_features <= FUSED_MAX_WIDTH and l.out_features <= FUSED_MAX_WIDTH for l in layers)
 
 
@@ -60,7 +65,7 @@ def _chain_args(layers):
 
 def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
     """fp32 [M, K0] -> fp32 [M, N_last]; no activations are kept."""
-    if _fusable(layers):
+    if _fusable(layers, x2.shape[0]):
         out, _ = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=False)
         return out
     x_bf, _ = ops.cast_pad_bf16(x2, want_t=False)
@@ -78,7 +83,7 @@ def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
 def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
     """Returns (ctx, fp32 output [M, N_last])."""
     M = x2.shape[0]
-    if _fusable(layers):
+    if _fusable(layers, M):
         y, sv = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=True)
         saved = [(xt, aux, _shadows(l)[0]) for (xt, aux), l in zip(sv, layers)]
         return (saved, M, need_input_grad), y
