@@ -7,7 +7,9 @@ from __future__ import annotations
 
 from typing import Any
 
-from ..tree import tree_map
+import torch
+
+from ..tree import tree_leaves, tree_map
 from .types import (ModuleState, PPONetworkOutput, StatefulModule, StatefulModuleOutput,
                     add_reg)
 
@@ -24,6 +26,53 @@ def _squeeze_trailing_one(v: Any) -> Any:
     return v
 
 
+class _Fork:
+    """Run the value port on a second HIP stream while the action port runs on the
+    current one.  The two ports are independent (both read the same input,
+    adapter.py:75-117), and at this workload's sizes neither fills the chip, so
+    overlapping them shortens the critical path; inside a captured HIP graph the
+    fork/join become parallel branches.  Tensors that cross streams are
+    registered with the caching allocator (`record_stream`)."""
+
+    def __init__(self, *inputs):
+        self.main = torch.cuda.current_stream()
+        dev = self.main.device
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        self.side = side
+        self.inputs = [t for x in inputs for t in tree_leaves(x) if isinstance(t, torch.Tensor)]
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        for t in self.inputs:
+            t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        self.main.wait_stream(self.side)
+        for x in outputs:
+            for t in tree_leaves(x):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(self.main)
+
+
+_SIDE_STREAMS: dict = {}
+OVERLAP_PORTS = True
+
+
+def _can_fork(x) -> bool:
+    leaves = tree_leaves(x)
+    return OVERLAP_PORTS and bool(leaves) and isinstance(leaves[0], torch.Tensor) \
+        and leaves[0].is_cuda
+
+
 class PPOAdapter(StatefulModule):
     def __init__(self, action: StatefulModule, value: StatefulModule):
         self.action = action
@@ -36,8 +85,16 @@ class PPOAdapter(StatefulModule):
         else:
             a_re = rollout_extras["action"]
             v_re = rollout_extras["value"]
-        a_out = self.action(state["action"], x, a_re)
-        v_out = self.value(state["value"], x, v_re)
+        if _can_fork(x):
+            fork = _Fork(x, state["value"], v_re)
+            with fork:
+                v_out = self.value(state["value"], x, v_re)
+            a_out = self.action(state["action"], x, a_re)
+            fork.join(v_out.output, v_out.next_state, v_out.rollout_extras,
+                      v_out.regularization_loss)
+        else:
+            a_out = self.action(state["action"], x, a_re)
+            v_out = self.value(state["value"], x, v_re)
         actions = tree_map(lambda d: d["action"], a_out.output, is_leaf=_is_sampler_dict)
         loglikelihoods = tree_map(lambda d: d["log_likelihood"], a_out.output,
                                   is_leaf=_is_sampler_dict)
@@ -67,10 +124,19 @@ class PPOAdapter(StatefulModule):
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
         a_re = None if extras_seq is None else extras_seq["action"]
         v_re = None if extras_seq is None else extras_seq["value"]
-        a_ctx, a_out, a_reg, a_fs = self.action.replay(state0["action"], x_seq, done_seq, a_re,
-                                                       need_input_grad)
-        v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], x_seq, done_seq, v_re,
-                                                      need_input_grad)
+        if _can_fork(x_seq):
+            fork = _Fork(x_seq, state0["value"], v_re, done_seq)
+            with fork:
+                v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], x_seq, done_seq,
+                                                              v_re, need_input_grad)
+            a_ctx, a_out, a_reg, a_fs = self.action.replay(state0["action"], x_seq, done_seq,
+                                                           a_re, need_input_grad)
+            fork.join(v_out, v_reg, v_fs)
+        else:
+            a_ctx, a_out, a_reg, a_fs = self.action.replay(state0["action"], x_seq, done_seq,
+                                                           a_re, need_input_grad)
+            v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], x_seq, done_seq, v_re,
+                                                          need_input_grad)
         actions = tree_map(lambda d: d["action"], a_out, is_leaf=_is_sampler_dict)
         loglik = tree_map(lambda d: d["log_likelihood"], a_out, is_leaf=_is_sampler_dict)
         values = tree_map(_squeeze_trailing_one, v_out)
@@ -89,8 +155,15 @@ class PPOAdapter(StatefulModule):
                            g_out.loglikelihoods, is_leaf=_is_sampler_dict)
         g_v = tree_map(lambda g, sq: g.unsqueeze(-1) if sq else g, g_out.value_estimates,
                        squeezed)
-        gx_a = self.action.replay_backward(a_ctx, g_a, g_reg)
-        gx_v = self.value.replay_backward(v_ctx, g_v, g_reg)
+        if _can_fork(g_v):
+            fork = _Fork(g_v)
+            with fork:
+                gx_v = self.value.replay_backward(v_ctx, g_v, g_reg)
+            gx_a = self.action.replay_backward(a_ctx, g_a, g_reg)
+            fork.join(gx_v)
+        else:
+            gx_a = self.action.replay_backward(a_ctx, g_a, g_reg)
+            gx_v = self.value.replay_backward(v_ctx, g_v, g_reg)
         if gx_a is None and gx_v is None:
             return None
         if gx_a is None:

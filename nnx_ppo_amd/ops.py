@@ -22,13 +22,14 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "tanh": ACT_TANH,
              "swish": ACT_SWISH}
 
-# Workspaces are keyed by (device, tag, bytes) and never freed or regrown, so a
-# pointer baked into a captured HIP graph stays valid for the process lifetime.
+# Workspaces are keyed by (device, stream, tag, bytes) and never freed or regrown,
+# so a pointer baked into a captured HIP graph stays valid for the process
+# lifetime, and kernels running concurrently on two streams never share one.
 _workspaces: dict = {}
 
 
 def workspace(device, tag: str, nbytes: int) -> torch.Tensor:
-    key = (str(device), tag, int(nbytes))
+    key = (str(device), stream(), tag, int(nbytes))
     ws = _workspaces.get(key)
     if ws is None:
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
