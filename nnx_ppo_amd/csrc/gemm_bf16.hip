@@ -490,6 +490,144 @@ mlp_fwd_kernel(Chain c) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Latency-optimised trunk for SMALL M (rollout step / bootstrap: 1k-8k rows).
+// With so few rows the chip is filled by giving each workgroup only 16 rows (one
+// MFMA row tile) and splitting every layer's OUTPUT COLUMNS over the 4 waves.
+// A wave's weight fragments are then used by exactly one MFMA row tile, so they
+// go global -> VGPR directly (no LDS staging, no per-k-tile barrier); they do not
+// depend on activations, so the next chunk's fragments — across layer boundaries
+// too — are in flight while the current chunk computes.  Activations (16 x W
+// bf16, 8 KB) ping-pong in LDS; ONE barrier per layer.
+constexpr int IF_BM = 16;
+constexpr int IF_KC = 128;   // reduce elements per pipeline step (4 MFMA k-steps)
+
+struct IStep {
+  int l, p, kc;  // layer, column pass (256 columns per pass), k-chunk
+};
+
+__device__ inline IStep istep_next(const Chain& c, IStep s) {
+  const int Kp = (c.layer[s.l].K + 31) / 32 * 32;
+  s.kc += IF_KC;
+  if (s.kc >= Kp) {
+    s.kc = 0;
+    s.p += 1;
+    if (s.p * 256 >= c.layer[s.l].N) {
+      s.p = 0;
+      s.l += 1;
+    }
+  }
+  return s;
+}
+
+struct BFrags {
+  bf16x8 f[4][4];  // [k-step][column tile]
+};
+
+template <int MAXW>
+__global__ void __launch_bounds__(kThreads)
+mlp_infer_kernel(Chain c) {
+  constexpr int AROW = MAXW + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t act[2][IF_BM][AROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * IF_BM;
+  const int K0 = c.layer[0].K;
+  const int K0p = (K0 + 31) / 32 * 32;
+
+  // column tile b of this wave in pass p starts at column ((p*4 + b)*4 + wave) * 16
+  auto load_frags = [&](const IStep& s, BFrags& B) {
+    const ChainLayer& ly = c.layer[s.l];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = ((s.p * 4 + b) * 4 + wave) * 16 + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int k = s.kc + ks * 32 + 8 * (lane >> 4);
+        u32x4 r = u32x4{0u, 0u, 0u, 0u};
+        if (col < ly.N && k < ly.ldwt)
+          r = *reinterpret_cast<const u32x4*>(ly.wt + (int64_t)col * ly.ldwt + k);
+        B.f[ks][b] = __builtin_bit_cast(bf16x8, r);
+      }
+    }
+  };
+
+  IStep s = {0, 0, 0};
+  BFrags Ba, Bb;
+  load_frags(s, Ba);
+
+  for (int i = tid; i < IF_BM * K0p; i += kThreads) {
+    const int row = i / K0p, k = i % K0p;
+    const int64_t gi = i0 + row;
+    act[0][row][k] = (bf16_t)((gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f);
+  }
+  __syncthreads();
+
+  f32x4 acc[4];
+  auto run_step = [&](const IStep& st, const BFrags& B, BFrags& Bnext) {
+    const ChainLayer& ly = c.layer[st.l];
+    const int Kp = (ly.K + 31) / 32 * 32;
+    const int cur = st.l & 1, nxt = cur ^ 1;
+    const bool last = st.l == c.L - 1;
+    const IStep sn = istep_next(c, st);
+    if (sn.l < c.L) load_frags(sn, Bnext);
+    if (st.kc == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (st.kc + ks * 32 < Kp) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(
+            &act[cur][lane & 15][st.kc + ks * 32 + 8 * (lane >> 4)]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (((st.p * 4 + b) * 4 + wave) * 16 < ly.N)
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, B.f[ks][b], acc[b], 0, 0, 0);
+        }
+      }
+    }
+    if (st.kc + IF_KC >= Kp) {  // this wave's columns of this pass are complete
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = ((st.p * 4 + b) * 4 + wave) * 16 + (lane & 15);
+        if (j < ly.N) {
+          const float bj = ly.bias ? ly.bias[j] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = 4 * (lane >> 4) + e;
+            const float v = act_fwd(acc[b][e] + bj, ly.act);
+            if (!last) {
+              act[nxt][row][j] = (bf16_t)v;
+            } else if (i0 + row < c.M) {
+              c.out[(i0 + row) * ly.N + j] = v;
+            }
+          }
+        }
+      }
+      if (sn.l != st.l) {  // layer finished: zero the pad columns, then publish the buffer
+        if (!last) {
+          const int Np = (ly.N + 31) / 32 * 32;
+          if (Np != ly.N) {
+            for (int i = tid; i < IF_BM * (Np - ly.N); i += kThreads)
+              act[nxt][i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  };
+
+  while (s.l < c.L) {
+    run_step(s, Ba, Bb);
+    s = istep_next(c, s);
+    if (s.l >= c.L) break;
+    run_step(s, Bb, Ba);
+    s = istep_next(c, s);
+  }
+}
+
 int stream_grid(int64_t n) {
   int64_t g = mippo::ceil_div(n, kThreads);
   if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
@@ -700,8 +838,19 @@ extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void*
     const int w = (int)(mippo::ceil_div(K > N ? K : N, 32) * 32);
     if (w > maxw) maxw = w;
   }
-  dim3 grid((unsigned)mippo::ceil_div(M, CH_BM));
   hipStream_t st = mippo::as_stream(stream);
+  const bool training = y_bf || yt_bf || pre_bf || xt_bf;
+  if (!training && M <= 16384) {
+    // inference at small M: the latency-optimised 16-row kernel
+    dim3 igrid((unsigned)mippo::ceil_div(M, IF_BM));
+    if (maxw <= 256) {
+      hipLaunchKernelGGL(mlp_infer_kernel<256>, igrid, dim3(kThreads), 0, st, c);
+    } else {
+      hipLaunchKernelGGL(mlp_infer_kernel<512>, igrid, dim3(kThreads), 0, st, c);
+    }
+    return mippo::check_launch("mi_mlp_fwd_bf16(infer)");
+  }
+  dim3 grid((unsigned)mippo::ceil_div(M, CH_BM));
   if (maxw <= 256) {
     hipLaunchKernelGGL(mlp_fwd_kernel<256>, grid, dim3(kThreads), 0, st, c);
   } else {
