@@ -148,59 +148,59 @@ int mi_dense_bwd_dw_f32(const float* x, const float* g_y, const float* aux, floa
 
 /* ---- a9 (bf16 path): Dense layer on bf16 MFMA, fp32 accumulate --------- */
 
-/* Operand conventions: every bf16 operand is a dense row-major matrix whose
+/* Operand conventions: every bf16 operand is a dense ROW-MAJOR matrix whose
  * leading dimension `ld*` is a multiple of 8 elements (16 bytes) with the
- * padding ZERO-filled, 16-byte-aligned base.  fp32 master weights stay in the
- * optimiser arena; `mi_weights_to_bf16` refreshes the two bf16 shadows
- * (w_bf [K][ldw] for dX, wt_bf [N][ldwt] = W^T for the forward).  Activations
- * are kept as bf16 plus a TRANSPOSED bf16 copy (the dW operand), both written
- * by the producing kernel's epilogue. */
+ * padding ZERO-filled (kernels that produce a bf16 matrix write the padding),
+ * 16-byte-aligned base.  fp32 master weights stay in the optimiser arena;
+ * `mi_weights_to_bf16` refreshes the two bf16 shadows (w_bf [K][ldw] for dX,
+ * wt_bf [N][ldwt] = W^T for the forward).  Activations are kept once, as bf16
+ * [M][pad8 N]; the dW kernel transposes on the fly with ds_read_b64_tr_b16. */
 
 /* fp32 x[M][F] (times act'(aux_bf[M][ldaux]) if act != MI_ACT_NONE) -> bf16
- * out[M][ld] (zero padded, nullable) and bf16 out_t[F][ldt] (nullable). */
+ * out[M][ld] (zero padded). */
 int mi_cast_pad_bf16(const float* x, const void* aux_bf, int64_t ldaux, int act, void* out,
-                     int64_t ld, void* out_t, int64_t ldt, int64_t M, int64_t F,
-                     mi_stream_t stream);
+                     int64_t ld, int64_t M, int64_t F, mi_stream_t stream);
 
 int mi_weights_to_bf16(const float* w, void* w_bf, int64_t ldw, void* wt_bf, int64_t ldwt,
                        int64_t K, int64_t N, mi_stream_t stream);
 
 /* y = act(x @ w + bias) (`feedforward.py:42-51`).  Outputs (each nullable, at
- * least one of y_f32 / y_bf): y_f32 [M][N], y_bf [M][ldy], yt_bf [N][ldyt]
- * (transposed), preact_bf [M][ldy] (pre-activation, for the swish backward). */
+ * least one of y_f32 / y_bf): y_f32 [M][N], y_bf [M][ldy], preact_bf [M][ldy]
+ * (pre-activation, for the swish backward). */
 int mi_dense_fwd_bf16(const void* x_bf, int64_t ldx, const void* wt_bf, int64_t ldwt,
-                      const float* bias, float* y_f32, void* y_bf, int64_t ldy, void* yt_bf,
-                      int64_t ldyt, void* preact_bf, int64_t M, int64_t K, int64_t N, int act,
+                      const float* bias, float* y_f32, void* y_bf, int64_t ldy,
+                      void* preact_bf, int64_t M, int64_t K, int64_t N, int act,
                       mi_stream_t stream);
 
-/* gx = (dz @ w^T) ⊙ prev_act'(prev): the gradient w.r.t. the PREVIOUS layer's
+/* gx = (dz @ w^T) (.) prev_act'(prev): the gradient w.r.t. the PREVIOUS layer's
  * pre-activation when `prev_bf` is that layer's output (its pre-activation for
  * swish), or the plain input gradient with prev_act = MI_ACT_NONE.
- * Outputs (nullable): gx_f32 [M][K], gx_bf [M][ldgx], gxt_bf [K][ldgxt]. */
+ * Outputs (nullable): gx_f32 [M][K], gx_bf [M][ldgx]. */
 int mi_dense_bwd_dx_bf16(const void* dz_bf, int64_t lddz, const void* w_bf, int64_t ldw,
                          const void* prev_bf, int64_t ldprev, int prev_act, float* gx_f32,
-                         void* gx_bf, int64_t ldgx, void* gxt_bf, int64_t ldgxt, int64_t M,
-                         int64_t K, int64_t N, mi_stream_t stream);
+                         void* gx_bf, int64_t ldgx, int64_t M, int64_t K, int64_t N,
+                         mi_stream_t stream);
 
-/* g_w[K][N] (+)= x^T dz, g_b[N] (+)= column sums of dz, from the transposed
- * copies xt_bf [K][ldxt], dzt_bf [N][lddzt]; split over M into fp32 slabs in
+/* g_w[K][N] (+)= x^T dz, g_b[N] (+)= column sums of dz, from the row-major
+ * x_bf [M][ldx] and dz_bf [M][lddz]; split over M into fp32 slabs in
  * `workspace`, reduced in fixed order. */
 int64_t mi_dense_bwd_dw_bf16_workspace_bytes(int64_t M, int64_t K, int64_t N);
-int mi_dense_bwd_dw_bf16(const void* xt_bf, int64_t ldxt, const void* dzt_bf, int64_t lddzt,
+int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* dz_bf, int64_t lddz,
                          float* g_w, float* g_b, void* workspace, int64_t M, int64_t K,
                          int64_t N, int accumulate, mi_stream_t stream);
 
-/* A whole MLP trunk (L <= 8 Dense layers, widths <= 512) in ONE launch: each
- * workgroup walks 64 rows through every layer with the activations resident in
- * LDS; only weights stream (bf16 W^T shadows, `wt_bf[l]` = [N_l][pad8 K_l]).
+/* A whole MLP trunk (L <= 8 Dense layers, widths <= 512) in ONE launch; only
+ * weights stream (bf16 W^T shadows, `wt_bf[l]` = [N_l][pad8 K_l]).
  * dims[L+1] = (K_0, N_0 = K_1, ..., N_{L-1}); acts[L]; bias[l] nullable.
- * out: fp32 [M][N_{L-1}].  Training stores (arrays nullable, entries nullable):
- * y_bf[l] [M][pad8 N_l], yt_bf[l] [N_l][pad8 M], pre_bf[l] [M][pad8 N_l];
- * xt_bf [K_0][pad8 M] = transposed bf16 copy of the input. */
+ * out: fp32 [M][N_{L-1}].  Inference (no training stores) at M <= 16384 runs the
+ * latency-optimised kernel: 16 rows per workgroup, output columns split over the
+ * waves, weight fragments global -> VGPR, one barrier per layer.  Training
+ * stores (arrays nullable, entries nullable): y_bf[l] [M][pad8 N_l], pre_bf[l]
+ * [M][pad8 N_l]; x_bf [M][pad8 K_0] = bf16 copy of the input. */
 int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
                     const float* const* bias, const int64_t* dims, const int64_t* acts,
-                    float* out, void* const* y_bf, void* const* yt_bf, void* const* pre_bf,
-                    void* xt_bf, mi_stream_t stream);
+                    float* out, void* const* y_bf, void* const* pre_bf, void* x_bf,
+                    mi_stream_t stream);
 
 /* ---- a20: GRU carry (persistent T-loop) ------------------------------------ */
 

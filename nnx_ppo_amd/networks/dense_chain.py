@@ -5,12 +5,13 @@ A `Sequential` hands every maximal run of `Dense` layers to this module when
 epilogue produce exactly what the next kernels consume, so no activation makes a
 separate cast / transpose / activation-derivative pass through HBM:
 
-  forward   layer l:  x_bf [M,K] . Wt_l  -> (+bias, act) -> y_bf [M,N] (next A operand,
-            act' input) and yt_bf [N,M] (dW operand of layer l+1); the last layer
-            also writes the fp32 chain output.
-  backward  layer l:  dW_l, db_l from (xt_bf_l, dzt_bf_l);  then
-            dz_{l-1} = (dz_l . W_l^T) ⊙ act'_{l-1}(y_{l-1}) written as bf16 and bf16
-            transposed by the dX kernel's epilogue.
+  forward   layer l:  x_bf [M,K] . Wt_l  -> (+bias, act) -> y_bf [M,N] (next layer's
+            operand, act' input and dW operand); the last layer also writes the
+            fp32 chain output.
+  backward  layer l:  dW_l, db_l from (x_bf_l, dz_bf_l) — both row-major, transposed
+            on the fly inside the kernel;  then
+            dz_{l-1} = (dz_l . W_l^T) ⊙ act'_{l-1}(y_{l-1}) written as bf16 by the
+            dX kernel's epilogue.
 
 Math per layer is `nnx_ppo/networks/feedforward.py:42-51` and its derivative;
 products are bf16 x bf16 with fp32 accumulation, master weights stay fp32.
@@ -68,26 +69,27 @@ def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
     if _fusable(layers, x2.shape[0]):
         out, _ = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=False)
         return out
-    x_bf, _ = ops.cast_pad_bf16(x2, want_t=False)
+    x_bf = ops.cast_pad_bf16(x2)
     y = None
     for i, layer in enumerate(layers):
         last = i == len(layers) - 1
         _, wt = _shadows(layer)
-        y, y_bf, _, _ = ops.dense_fwd_bf16(x_bf, wt, _bias(layer), layer.in_features,
-                                           layer.out_features, layer.act_code, want_f32=last,
-                                           want_bf=not last, want_t=False)
+        y, y_bf, _ = ops.dense_fwd_bf16(x_bf, wt, _bias(layer), layer.in_features,
+                                        layer.out_features, layer.act_code, want_f32=last,
+                                        want_bf=not last)
         x_bf = y_bf
     return y
 
 
 def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
-    """Returns (ctx, fp32 output [M, N_last])."""
+    """Returns (ctx, fp32 output [M, N_last]).  ctx keeps, per layer, the bf16 input
+    (dW operand), the tensor its act' is evaluated on, and the bf16 W shadow."""
     M = x2.shape[0]
     if _fusable(layers, M):
         y, sv = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=True)
-        saved = [(xt, aux, _shadows(l)[0]) for (xt, aux), l in zip(sv, layers)]
+        saved = [(xb, aux, _shadows(l)[0]) for (xb, aux), l in zip(sv, layers)]
         return (saved, M, need_input_grad), y
-    x_bf, xt_bf = ops.cast_pad_bf16(x2, want_t=True)
+    x_bf = ops.cast_pad_bf16(x2)
     saved = []
     y = None
     for i, layer in enumerate(layers):
@@ -95,12 +97,11 @@ def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
         act = layer.act_code
         swish = act == ops.ACT_SWISH
         w_bf, wt = _shadows(layer)
-        y, y_bf, yt_bf, pre = ops.dense_fwd_bf16(
+        y, y_bf, pre = ops.dense_fwd_bf16(
             x_bf, wt, _bias(layer), layer.in_features, layer.out_features, act,
-            want_f32=last, want_bf=(not last) or act != ops.ACT_NONE, want_t=not last,
-            want_preact=swish)
-        saved.append((xt_bf, pre if swish else y_bf, w_bf))
-        x_bf, xt_bf = y_bf, yt_bf
+            want_f32=last, want_bf=(not last) or act != ops.ACT_NONE, want_preact=swish)
+        saved.append((x_bf, pre if swish else y_bf, w_bf))
+        x_bf = y_bf
     return (saved, M, need_input_grad), y
 
 
@@ -110,24 +111,23 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     saved, M, need_input_grad = ctx
     L = len(layers)
     last = layers[-1]
-    dz_bf, dzt_bf = ops.cast_pad_bf16(g_out2, want_t=True, aux=saved[-1][1]
-                                      if last.act_code != ops.ACT_NONE else None,
-                                      act=last.act_code)
+    dz_bf = ops.cast_pad_bf16(g_out2, aux=saved[-1][1] if last.act_code != ops.ACT_NONE else None,
+                              act=last.act_code)
     g_in = None
     for i in range(L - 1, -1, -1):
         layer = layers[i]
-        xt_bf, _, w_bf = saved[i]
-        ops.dense_bwd_dw_bf16(xt_bf, dzt_bf, layer.kernel.grad,
-                              layer.bias.grad if layer.bias is not None else None, M,
+        x_bf, _, w_bf = saved[i]
+        ops.dense_bwd_dw_bf16(x_bf, dz_bf, layer.kernel.grad,
+                              layer.bias.grad if layer.bias is not None else None,
                               accumulate=True)
         if i == 0:
             if need_input_grad:
-                g_in, _, _ = ops.dense_bwd_dx_bf16(dz_bf, w_bf, None, ops.ACT_NONE,
-                                                   layer.in_features, layer.out_features,
-                                                   want_f32=True, want_bf=False, want_t=False)
+                g_in, _ = ops.dense_bwd_dx_bf16(dz_bf, w_bf, None, ops.ACT_NONE,
+                                                layer.in_features, layer.out_features,
+                                                want_f32=True, want_bf=False)
             break
         prev = layers[i - 1]
-        _, dz_bf, dzt_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, saved[i - 1][1], prev.act_code,
-                                                 layer.in_features, layer.out_features,
-                                                 want_f32=False, want_bf=True, want_t=True)
+        _, dz_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, saved[i - 1][1], prev.act_code,
+                                         layer.in_features, layer.out_features,
+                                         want_f32=False, want_bf=True)
     return g_in

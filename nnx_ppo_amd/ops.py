@@ -241,23 +241,18 @@ def pad8(n: int) -> int:
 
 
 def _bf_buf(rows: int, cols: int, device) -> torch.Tensor:
-    """bf16 [rows][pad8(cols)] operand buffer; the padding must read as zero."""
-    ld = pad8(cols)
-    if ld != cols:
-        return torch.zeros(rows, ld, dtype=bf16, device=device)
-    return torch.empty(rows, ld, dtype=bf16, device=device)
+    """bf16 [rows][pad8(cols)] operand buffer (producers write the zero padding)."""
+    return torch.empty(rows, pad8(cols), dtype=bf16, device=device)
 
 
-def cast_pad_bf16(x: torch.Tensor, want_t: bool, aux=None, act: int = ACT_NONE):
-    """fp32 [M, F] -> (bf16 [M, pad8(F)], bf16 transposed [F, pad8(M)] or None)."""
+def cast_pad_bf16(x: torch.Tensor, aux=None, act: int = ACT_NONE) -> torch.Tensor:
+    """fp32 [M, F] (x act'(aux)) -> bf16 [M, pad8(F)], zero padded."""
     M, F = x.shape
-    out = torch.empty(M, pad8(F), dtype=bf16, device=x.device)
-    out_t = _bf_buf(F, M, x.device) if want_t else None
+    out = _bf_buf(M, F, x.device)
     check(lib().mi_cast_pad_bf16(ptr(x, f32), ptr(aux), aux.shape[1] if aux is not None else 0,
-                                 int(act), ptr(out), out.shape[1], ptr(out_t),
-                                 out_t.shape[1] if out_t is not None else 0, M, F, stream()),
+                                 int(act), ptr(out), out.shape[1], M, F, stream()),
           "mi_cast_pad_bf16")
-    return out, out_t
+    return out
 
 
 def weights_to_bf16(w: torch.Tensor, w_bf: torch.Tensor, wt_bf: torch.Tensor) -> None:
@@ -268,58 +263,57 @@ def weights_to_bf16(w: torch.Tensor, w_bf: torch.Tensor, wt_bf: torch.Tensor) ->
 
 
 def dense_fwd_bf16(x_bf, wt_bf, bias, K: int, N: int, act: int, *, want_f32: bool,
-                   want_bf: bool, want_t: bool, want_preact: bool = False):
-    """Returns (y_f32 | None, y_bf | None, yt_bf | None, preact_bf | None)."""
+                   want_bf: bool, want_preact: bool = False):
+    """Returns (y_f32 | None, y_bf | None, preact_bf | None)."""
     M = x_bf.shape[0]
     _need(x_bf.dtype == bf16 and x_bf.shape[1] == pad8(K), "dense_fwd_bf16: x_bf must be [M, pad8(K)]")
     _need(wt_bf.shape == (N, pad8(K)), "dense_fwd_bf16: wt_bf must be [N, pad8(K)]")
     dev = x_bf.device
     y_f32 = torch.empty(M, N, dtype=f32, device=dev) if want_f32 else None
     y_bf = _bf_buf(M, N, dev) if want_bf else None
-    yt_bf = _bf_buf(N, M, dev) if want_t else None
     pre = _bf_buf(M, N, dev) if want_preact else None
     check(lib().mi_dense_fwd_bf16(
         ptr(x_bf, bf16), x_bf.shape[1], ptr(wt_bf, bf16), wt_bf.shape[1], ptr(bias, f32),
-        ptr(y_f32, f32), ptr(y_bf), pad8(N), ptr(yt_bf), pad8(M), ptr(pre), M, K, N, int(act),
-        stream()), "mi_dense_fwd_bf16")
-    return y_f32, y_bf, yt_bf, pre
+        ptr(y_f32, f32), ptr(y_bf), pad8(N), ptr(pre), M, K, N, int(act), stream()),
+        "mi_dense_fwd_bf16")
+    return y_f32, y_bf, pre
 
 
 def dense_bwd_dx_bf16(dz_bf, w_bf, prev_bf, prev_act: int, K: int, N: int, *, want_f32: bool,
-                      want_bf: bool, want_t: bool):
-    """Returns (gx_f32 | None, gx_bf | None, gxt_bf | None)."""
+                      want_bf: bool):
+    """Returns (gx_f32 | None, gx_bf | None)."""
     M = dz_bf.shape[0]
     _need(dz_bf.shape[1] == pad8(N) and w_bf.shape == (K, pad8(N)), "dense_bwd_dx_bf16: shapes")
     dev = dz_bf.device
     gx_f32 = torch.empty(M, K, dtype=f32, device=dev) if want_f32 else None
     gx_bf = _bf_buf(M, K, dev) if want_bf else None
-    gxt_bf = _bf_buf(K, M, dev) if want_t else None
     if prev_act != ACT_NONE:
         _need(prev_bf is not None and prev_bf.shape == (M, pad8(K)), "dense_bwd_dx_bf16: prev")
     check(lib().mi_dense_bwd_dx_bf16(
         ptr(dz_bf, bf16), dz_bf.shape[1], ptr(w_bf, bf16), w_bf.shape[1],
         ptr(prev_bf) if prev_act != ACT_NONE else None, pad8(K), int(prev_act), ptr(gx_f32, f32),
-        ptr(gx_bf), pad8(K), ptr(gxt_bf), pad8(M), M, K, N, stream()), "mi_dense_bwd_dx_bf16")
-    return gx_f32, gx_bf, gxt_bf
+        ptr(gx_bf), pad8(K), M, K, N, stream()), "mi_dense_bwd_dx_bf16")
+    return gx_f32, gx_bf
 
 
-def dense_bwd_dw_bf16(xt_bf, dzt_bf, g_w, g_b, M: int, accumulate: bool = True) -> None:
+def dense_bwd_dw_bf16(x_bf, dz_bf, g_w, g_b, accumulate: bool = True) -> None:
     K, N = g_w.shape
-    _need(xt_bf.shape == (K, pad8(M)) and dzt_bf.shape == (N, pad8(M)),
-          "dense_bwd_dw_bf16: transposed operands must be [K, pad8(M)] / [N, pad8(M)]")
+    M = x_bf.shape[0]
+    _need(x_bf.shape == (M, pad8(K)) and dz_bf.shape == (M, pad8(N)),
+          "dense_bwd_dw_bf16: operands must be [M, pad8(K)] / [M, pad8(N)]")
     nbytes = lib().mi_dense_bwd_dw_bf16_workspace_bytes(M, K, N)
     _need(nbytes >= 0, "mi_dense_bwd_dw_bf16_workspace_bytes failed")
     ws = workspace(g_w.device, "dense_dw_bf16", nbytes)
-    check(lib().mi_dense_bwd_dw_bf16(ptr(xt_bf, bf16), xt_bf.shape[1], ptr(dzt_bf, bf16),
-                                     dzt_bf.shape[1], ptr(g_w, f32), ptr(g_b, f32), ptr(ws), M, K,
+    check(lib().mi_dense_bwd_dw_bf16(ptr(x_bf, bf16), x_bf.shape[1], ptr(dz_bf, bf16),
+                                     dz_bf.shape[1], ptr(g_w, f32), ptr(g_b, f32), ptr(ws), M, K,
                                      N, int(bool(accumulate)), stream()), "mi_dense_bwd_dw_bf16")
 
 
 def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
                  train: bool):
     """Fused MLP trunk forward.  Returns (out_f32 [M, N_last], saved) where `saved`
-    (training only) is a list per layer of (xt_bf, aux_bf) — the transposed input
-    of the layer and the tensor its activation derivative is evaluated on."""
+    (training only) is a list per layer of (x_bf, aux_bf) — the bf16 input of the
+    layer and the tensor its activation derivative is evaluated on."""
     M, K0 = x.shape
     L = len(wts)
     _need(len(dims) == L + 1 and dims[0] == K0 and len(acts) == L, "mlp_fwd_bf16: dims/acts")
@@ -328,33 +322,30 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
     P = ctypes.c_void_p * L
     I = ctypes.c_int64 * (L + 1)
     y_bf = [None] * L
-    yt_bf = [None] * L
     pre_bf = [None] * L
-    xt = None
+    x_bf = None
     if train:
-        xt = _bf_buf(K0, M, dev)
+        x_bf = _bf_buf(M, K0, dev)
         for l in range(L):
             last = l == L - 1
             N = dims[l + 1]
             if (not last) or acts[l] != ACT_NONE:
                 y_bf[l] = _bf_buf(M, N, dev)
-            if not last:
-                yt_bf[l] = _bf_buf(N, M, dev)
             if acts[l] == ACT_SWISH:
                 pre_bf[l] = _bf_buf(M, N, dev)
     arr = lambda ts: P(*[ptr(t) for t in ts])
     check(lib().mi_mlp_fwd_bf16(
         ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
         (ctypes.c_int64 * L)(*[int(a) for a in acts]), ptr(out, f32),
-        arr(y_bf) if train else None, arr(yt_bf) if train else None,
-        arr(pre_bf) if train else None, ptr(xt), stream()), "mi_mlp_fwd_bf16")
+        arr(y_bf) if train else None, arr(pre_bf) if train else None, ptr(x_bf), stream()),
+        "mi_mlp_fwd_bf16")
     if not train:
         return out, None
     saved = []
     for l in range(L):
-        xt_l = xt if l == 0 else yt_bf[l - 1]
+        x_l = x_bf if l == 0 else y_bf[l - 1]
         aux = pre_bf[l] if acts[l] == ACT_SWISH else y_bf[l]
-        saved.append((xt_l, aux))
+        saved.append((x_l, aux))
     return out, saved
 
 

@@ -42,55 +42,68 @@ def test_dense_bf16_kernels(dev, M, K, N, act):
     b = rng.normal(size=N).astype(np.float32)
     code = ops.ACT_CODES[act]
     g = lambda a: torch.as_tensor(a).to(dev)
-    x_bf, xt_bf = ops.cast_pad_bf16(g(x), want_t=True)
-    assert x_bf.shape == (M, ops.pad8(K)) and xt_bf.shape == (K, ops.pad8(M))
+    x_bf = ops.cast_pad_bf16(g(x))
+    assert x_bf.shape == (M, ops.pad8(K))
     assert torch.equal(x_bf[:, :K].cpu(), torch.as_tensor(x).to(BF))
-    assert torch.equal(xt_bf[:, :M].cpu(), torch.as_tensor(x).to(BF).t())
-    assert float(x_bf[:, K:].float().abs().sum()) == 0 and float(xt_bf[:, M:].float().abs().sum()) == 0
+    assert float(x_bf[:, K:].float().abs().sum()) == 0
     w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
     wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
     ops.weights_to_bf16(g(w), w_bf, wt_bf)
     assert torch.equal(w_bf[:, :N].cpu(), torch.as_tensor(w).to(BF))
     assert torch.equal(wt_bf[:, :K].cpu(), torch.as_tensor(w).to(BF).t())
 
-    y, y_bf, yt_bf, pre = ops.dense_fwd_bf16(x_bf, wt_bf, g(b), K, N, code, want_f32=True,
-                                             want_bf=True, want_t=True,
-                                             want_preact=(act == "swish"))
+    y, y_bf, pre = ops.dense_fwd_bf16(x_bf, wt_bf, g(b), K, N, code, want_f32=True,
+                                      want_bf=True, want_preact=(act == "swish"))
     z64 = _r(x) @ _r(w) + torch.as_tensor(b, dtype=D)
     y64 = _act(z64, act)
     assert np.allclose(y.cpu().numpy(), y64.numpy(), rtol=1e-4, atol=1e-4)
-    assert np.allclose(y_bf[:, :N].float().cpu().numpy(), y64.numpy(), rtol=1e-2, atol=1e-2)
-    assert torch.equal(yt_bf[:, :M].cpu(), y_bf[:, :N].t().cpu())  # same rounding, transposed
+    assert torch.equal(y_bf[:, :N], y.to(BF))          # bf16 image = rounding of the fp32 output
+    assert float(y_bf[:, N:].float().abs().sum()) == 0  # producers write the zero padding
     if act == "swish":
         assert np.allclose(pre[:, :N].float().cpu().numpy(), z64.numpy(), rtol=1e-2, atol=1e-2)
+        assert float(pre[:, N:].float().abs().sum()) == 0
 
     # dX of THIS layer given dz (bf16), times act' of a previous layer's output `prev`
     dz = rng.normal(size=(M, N)).astype(np.float32)
     prev = rng.normal(size=(M, K)).astype(np.float32)
-    dz_bf, dzt_bf = ops.cast_pad_bf16(g(dz), want_t=True)
-    prev_bf, _ = ops.cast_pad_bf16(g(prev), want_t=False)
-    gx, gx_bf, gxt_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, prev_bf, code, K, N, want_f32=True,
-                                              want_bf=True, want_t=True)
+    dz_bf = ops.cast_pad_bf16(g(dz))
+    prev_bf = ops.cast_pad_bf16(g(prev))
+    gx, gx_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, prev_bf, code, K, N, want_f32=True,
+                                      want_bf=True)
     p64 = _r(prev)
     dact = {"none": torch.ones_like(p64), "relu": (p64 > 0).to(D), "tanh": 1 - p64 * p64,
             "swish": torch.sigmoid(p64) * (1 + p64 * (1 - torch.sigmoid(p64)))}[act]
     gx64 = (_r(dz) @ _r(w).t()) * dact
     assert np.allclose(gx.cpu().numpy(), gx64.numpy(), rtol=1e-4, atol=1e-4)
-    assert np.allclose(gx_bf[:, :K].float().cpu().numpy(), gx64.numpy(), rtol=1e-2, atol=1e-2)
-    assert torch.equal(gxt_bf[:, :M].cpu(), gx_bf[:, :K].t().cpu())
+    assert torch.equal(gx_bf[:, :K], gx.to(BF))
+    assert float(gx_bf[:, K:].float().abs().sum()) == 0
 
-    # dW, db from the transposed copies
+    # dW, db from the row-major operands (transposed on the fly by ds_read_b64_tr_b16)
     gw = torch.zeros(K, N, device=dev)
     gb = torch.zeros(N, device=dev)
-    ops.dense_bwd_dw_bf16(xt_bf, dzt_bf, gw, gb, M, accumulate=True)
+    ops.dense_bwd_dw_bf16(x_bf, dz_bf, gw, gb, accumulate=True)
     gw64 = _r(x).t() @ _r(dz)
     gb64 = _r(dz).sum(0)
     s = math.sqrt(M)
     assert np.allclose(gw.cpu().numpy(), gw64.numpy(), rtol=1e-4, atol=2e-5 * s)
     assert np.allclose(gb.cpu().numpy(), gb64.numpy(), rtol=1e-4, atol=2e-5 * s)
     gw2 = torch.zeros(K, N, device=dev)
-    ops.dense_bwd_dw_bf16(xt_bf, dzt_bf, gw2, None, M, accumulate=False)
+    ops.dense_bwd_dw_bf16(x_bf, dz_bf, gw2, None, accumulate=False)
     assert torch.equal(gw2, gw)  # bitwise reproducible
+
+
+def test_dw_asymmetric_layout(dev):
+    """x = I (padded) against an asymmetric dz pins the transposing fragment
+    gather: gW must equal dz's leading rows exactly, not its transpose."""
+    from nnx_ppo_amd import ops
+
+    M, K, N = 192, 70, 40
+    x = torch.zeros(M, K, device=dev)
+    x[:K, :K] = torch.eye(K, device=dev)
+    dz = (torch.arange(M * N, device=dev, dtype=torch.float32).reshape(M, N) % 251) - 125
+    gw = torch.zeros(K, N, device=dev)
+    ops.dense_bwd_dw_bf16(ops.cast_pad_bf16(x), ops.cast_pad_bf16(dz), gw, None, accumulate=False)
+    assert torch.equal(gw, dz[:K].to(BF).float())
 
 
 def test_cast_pad_with_activation_derivative(dev):
@@ -99,10 +112,10 @@ def test_cast_pad_with_activation_derivative(dev):
     M, F = 100, 12
     g = torch.randn(M, F, device=dev)
     y = torch.randn(M, F, device=dev)
-    y_bf, _ = ops.cast_pad_bf16(y, want_t=False)
-    dz, dzt = ops.cast_pad_bf16(g, want_t=True, aux=y_bf, act=ops.ACT_TANH)
+    y_bf = ops.cast_pad_bf16(y)
+    dz = ops.cast_pad_bf16(g, aux=y_bf, act=ops.ACT_TANH)
     want = (g * (1 - y_bf[:, :F].float() ** 2)).to(BF)
-    assert torch.equal(dz[:, :F], want) and torch.equal(dzt[:, :M], want.t())
+    assert torch.equal(dz[:, :F], want) and float(dz[:, F:].float().abs().sum()) == 0
 
 
 def _make(obs, act, ah, ch, activation="relu", seed=17):
@@ -186,7 +199,7 @@ def test_bf16_gradients_close_to_f32_path(dev):
 def test_fused_mlp_forward_matches_per_layer_path(dev, dims, M, act):
     """The one-launch MLP trunk must reproduce the per-layer bf16 kernels (same
     MFMA, same k-order, same bf16 rounding points): outputs equal to fp32
-    round-off, stored activations (y, y^T, pre-activation, x^T) identical."""
+    round-off, stored activations (y, pre-activation, bf16 input) identical."""
     from nnx_ppo_amd import ops
 
     rng = np.random.default_rng(M + len(dims))
@@ -208,17 +221,17 @@ def test_fused_mlp_forward_matches_per_layer_path(dev, dims, M, act):
     out_i, none = ops.mlp_fwd_bf16(x, wts, biases, dims, acts, train=False)
     assert none is None and torch.allclose(out, out_i, rtol=1e-5, atol=1e-5)
     # per-layer reference path
-    x_bf, xt_bf = ops.cast_pad_bf16(x, want_t=True)
-    assert torch.equal(saved[0][0], xt_bf)
+    x_bf = ops.cast_pad_bf16(x)
+    assert torch.equal(saved[0][0], x_bf)
     y = None
     for l in range(L):
         last = l == L - 1
-        y, y_bf, yt_bf, pre = ops.dense_fwd_bf16(x_bf, wts[l], biases[l], dims[l], dims[l + 1],
-                                                 acts[l], want_f32=True, want_bf=True,
-                                                 want_t=True, want_preact=acts[l] == ops.ACT_SWISH)
+        y, y_bf, pre = ops.dense_fwd_bf16(x_bf, wts[l], biases[l], dims[l], dims[l + 1], acts[l],
+                                          want_f32=True, want_bf=True,
+                                          want_preact=acts[l] == ops.ACT_SWISH)
         if not last:
             aux = pre if acts[l] == ops.ACT_SWISH else y_bf
-            assert torch.equal(saved[l][1][:, :dims[l + 1]], aux[:, :dims[l + 1]]), l
-            assert torch.equal(saved[l + 1][0][:, :M], yt_bf[:, :M]), l
+            assert torch.equal(saved[l][1], aux), l
+            assert torch.equal(saved[l + 1][0], y_bf), l
         x_bf = y_bf
     assert torch.allclose(out, y, rtol=1e-5, atol=1e-5)
