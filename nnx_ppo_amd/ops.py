@@ -329,10 +329,16 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
         for l in range(L):
             last = l == L - 1
             N = dims[l + 1]
-            if (not last) or acts[l] != ACT_NONE:
+            # hidden y_bf is copied out of LDS with its zero padding; the last layer's
+            # y_bf and every pre_bf are element stores, so their padding is zeroed here
+            zpad = (lambda r, c: torch.zeros(r, pad8(c), dtype=bf16, device=dev)
+                    if pad8(c) != c else _bf_buf(r, c, dev))
+            if not last:
                 y_bf[l] = _bf_buf(M, N, dev)
+            elif acts[l] != ACT_NONE:
+                y_bf[l] = zpad(M, N)
             if acts[l] == ACT_SWISH:
-                pre_bf[l] = _bf_buf(M, N, dev)
+                pre_bf[l] = zpad(M, N)
     arr = lambda ts: P(*[ptr(t) for t in ts])
     check(lib().mi_mlp_fwd_bf16(
         ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
