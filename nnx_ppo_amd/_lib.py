@@ -88,6 +88,7 @@ class Profiler:
     def __init__(self):
         self.active = False
         self.records: list = []
+        self.next_flops = None  # set by a wrapper that knows the work of its next call
 
     def __enter__(self):
         self.records = []
@@ -101,12 +102,14 @@ class Profiler:
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out: dict = {}
-        for name, ints, e0, e1 in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": []})
+        for name, ints, e0, e1, flops in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": [], "flops": 0.0})
             d["calls"] += 1
             ms = e0.elapsed_time(e1)
             d["ms"] += ms
             d["args"].append((ints, ms))
+            if flops is not None:
+                d["flops"] += flops
         for d in out.values():
             d["avg_ms"] = d["ms"] / max(d["calls"], 1)
         return out
@@ -134,7 +137,8 @@ class _Proxy:
             rc = fn(*args)
             e1.record()
             ints = tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 40))
-            profiler.records.append((name, ints, e0, e1))
+            profiler.records.append((name, ints, e0, e1, profiler.next_flops))
+            profiler.next_flops = None
             return rc
 
         return timed

@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from ._lib import MippoError, check, lib, ptr, stream
+from ._lib import MippoError, check, lib, profiler, ptr, stream
 
 f32 = torch.float32
 f64 = torch.float64
@@ -340,6 +340,8 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
             if acts[l] == ACT_SWISH:
                 pre_bf[l] = zpad(M, N)
     arr = lambda ts: P(*[ptr(t) for t in ts])
+    if profiler.active:
+        profiler.next_flops = 2.0 * M * sum(dims[l] * dims[l + 1] for l in range(L))
     check(lib().mi_mlp_fwd_bf16(
         ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
         (ctypes.c_int64 * L)(*[int(a) for a in acts]), ptr(out, f32),
