@@ -164,6 +164,11 @@ int mi_cast_pad_bf16(const float* x, const void* aux_bf, int64_t ldaux, int act,
 int mi_weights_to_bf16(const float* w, void* w_bf, int64_t ldw, void* wt_bf, int64_t ldwt,
                        int64_t K, int64_t N, mi_stream_t stream);
 
+/* The same for up to 16 layers in one launch (ld = pad8 of N / K as above). */
+int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w, void* const* w_bf,
+                             void* const* wt_bf, const int64_t* K, const int64_t* N,
+                             mi_stream_t stream);
+
 /* y = act(x @ w + bias) (`feedforward.py:42-51`).  Outputs (each nullable, at
  * least one of y_f32 / y_bf): y_f32 [M][N], y_bf [M][ldy], preact_bf [M][ldy]
  * (pre-activation, for the swish backward). */
@@ -284,15 +289,22 @@ int mi_select_rows_multi(const uint8_t* mask, const void* const* on_true,
                          void* const* out, const int64_t* row_bytes, int64_t n_leaves, int64_t B,
                          mi_stream_t stream);
 
+/* The minibatch gather for several leaves in one launch (n_leaves <= 16); leaf l
+ * is time-major [T[l], N, row_bytes[l]]. */
+int mi_gather_cols_multi(const void* const* src, void* const* dst, const int64_t* T,
+                         const int64_t* row_bytes, int64_t n_leaves, const int64_t* idx,
+                         int64_t N, int64_t L, mi_stream_t stream);
+
 /* ---- a4 / a18: integer keys and episode bookkeeping ----------------------- */
 
 /* Key expansion, the integer scheme of nnx_ppo_amd/random.py (splitmix64) in
  * one launch: keys[n] -> out[n*m].  mode: 0 split (int64 children,
  * `jax.random.split`), 1 bits (int64), 2 randint in [minval, maxval) (int64,
  * `episode_wrapper.py:28-30`), 3 uniform [0,1) (fp32, 24 exact bits),
- * 4 zero-mean unit-variance uniform (fp32). */
+ * 4 zero-mean unit-variance uniform (fp32).  child_major != 0 lays the output out
+ * as [m][n] (each child set contiguous) instead of [n][m]. */
 int mi_key_expand(const int64_t* keys, void* out, int64_t n, int64_t m, int mode,
-                  int64_t minval, int64_t maxval, mi_stream_t stream);
+                  int64_t minval, int64_t maxval, int child_major, mi_stream_t stream);
 
 /* out[i] = mix(a[i] ^ mix(b[i] + GOLDEN)): fold a per-env integer into a key. */
 int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int64_t n,

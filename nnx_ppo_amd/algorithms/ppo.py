@@ -241,10 +241,14 @@ def ppo_step(
 
     for i in range(total_iterations):
         inds = all_indices[i].contiguous()
-        minibatch = tree_map(lambda x: ops.gather_cols(x, inds), loss_view)
-        net_state_subset = tree_map(
-            lambda x: ops.gather_cols(x.unsqueeze(0), inds).squeeze(0),
-            training_state.network_states)
+        # minibatch gather x[:, inds] (ppo.py:297-300): every leaf in one launch
+        mb_leaves = tree_leaves(loss_view)
+        st_leaves = tree_leaves(training_state.network_states)
+        gathered = ops.gather_cols_multi(mb_leaves + [x.unsqueeze(0) for x in st_leaves], inds)
+        it = iter(gathered)
+        minibatch = tree_map(lambda x: next(it), loss_view)
+        net_state_subset = tree_map(lambda x: next(it).squeeze(0),
+                                    training_state.network_states)
         optimizer.begin()
         ppo_loss(networks, net_state_subset, minibatch, clip_range, normalize_advantages,
                  combine_advantages, discounting_factor, gae_lambda, critic_loss_weight,
@@ -398,7 +402,10 @@ def new_training_state(
     ks = rnd.split(key)
     key, training_key = ks[0], ks[1]
     env_init_keys = rnd.split(key, n_envs)
-    env_states = env.reset(env_init_keys)
+    # cloned: envs may hand out shared read-only constants (envs/constants.py) and
+    # these leaves become the static, written-in-place buffers of a captured graph
+    env_states = tree_map(lambda x: x.clone() if isinstance(x, torch.Tensor) else x,
+                          env.reset(env_init_keys))
     networks.to(device)
     network_states = networks.initialize_state(n_envs)
     optimizer = Optimizer(networks, learning_rate, gradient_clipping, weight_decay,

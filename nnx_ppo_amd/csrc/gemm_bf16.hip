@@ -375,6 +375,34 @@ weights_to_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, int
   }
 }
 
+struct WLeaf {
+  const float* w;
+  bf16_t* wb;
+  bf16_t* wt;
+  int64_t K, N, ldw, ldwt;
+};
+struct WTable {
+  WLeaf leaf[16];
+};
+
+// all layers of a network in one launch (blockIdx.y = layer)
+__global__ void __launch_bounds__(kThreads)
+weights_to_bf16_multi_kernel(WTable tab) {
+  const WLeaf lf = tab.leaf[blockIdx.y];
+  const int64_t n1 = lf.K * lf.ldw, n2 = lf.N * lf.ldwt;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n1 + n2;
+       i += (int64_t)gridDim.x * kThreads) {
+    if (i < n1) {
+      const int64_t k = i / lf.ldw, n = i % lf.ldw;
+      lf.wb[i] = (bf16_t)(n < lf.N ? lf.w[k * lf.N + n] : 0.0f);
+    } else {
+      const int64_t q = i - n1;
+      const int64_t n = q / lf.ldwt, k = q % lf.ldwt;
+      lf.wt[q] = (bf16_t)(k < lf.K ? lf.w[k * lf.N + n] : 0.0f);
+    }
+  }
+}
+
 // Tile configuration by output width J: wide outputs get 128x128 (2x2 waves of
 // 4x4 tiles), medium 128x64, narrow heads (J <= 16) 128x16.
 template <int EPI>
@@ -535,4 +563,32 @@ extern "C" int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* d
   int rc = mippo::check_launch("mi_dense_bwd_dw_bf16");
   if (rc) return rc;
   return mippo::reduce_slabs(slabs, g_w, g_b, S_eff, K * N, N, accumulate, st);
+}
+
+extern "C" int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w, void* const* w_bf,
+                                        void* const* wt_bf, const int64_t* K, const int64_t* N,
+                                        mi_stream_t stream) {
+  MI_REQUIRE(n_layers >= 0 && n_layers <= 16, "mi_weights_to_bf16_multi: 0 <= n_layers <= 16");
+  if (n_layers == 0) return 0;
+  MI_REQUIRE(w && w_bf && wt_bf && K && N, "mi_weights_to_bf16_multi: null pointer");
+  WTable tab = {};
+  int64_t max_total = 0;
+  for (int64_t l = 0; l < n_layers; ++l) {
+    MI_REQUIRE(w[l] && w_bf[l] && wt_bf[l] && K[l] >= 1 && N[l] >= 1,
+               "mi_weights_to_bf16_multi: bad layer %lld", (long long)l);
+    WLeaf& lf = tab.leaf[l];
+    lf.w = w[l];
+    lf.wb = static_cast<bf16_t*>(w_bf[l]);
+    lf.wt = static_cast<bf16_t*>(wt_bf[l]);
+    lf.K = K[l];
+    lf.N = N[l];
+    lf.ldw = mippo::ceil_div(N[l], 8) * 8;
+    lf.ldwt = mippo::ceil_div(K[l], 8) * 8;
+    const int64_t tot = lf.K * lf.ldw + lf.N * lf.ldwt;
+    if (tot > max_total) max_total = tot;
+  }
+  dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_layers);
+  hipLaunchKernelGGL(weights_to_bf16_multi_kernel, grid, dim3(kThreads), 0,
+                     mippo::as_stream(stream), tab);
+  return mippo::check_launch("mi_weights_to_bf16_multi");
 }

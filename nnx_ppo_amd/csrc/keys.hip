@@ -34,11 +34,13 @@ enum { OUT_SPLIT = 0, OUT_BITS = 1, OUT_RANDINT = 2, OUT_UNIFORM = 3, OUT_UNIT_U
 //   UNIT_UNIFORM (UNIFORM - 0.5) * sqrt(12)                         (random.unit_uniform)
 __global__ void __launch_bounds__(kThreads)
 key_expand_kernel(const int64_t* __restrict__ keys, void* __restrict__ out, int64_t n, int64_t m,
-                  int mode, int64_t minval, int64_t span) {
+                  int mode, int64_t minval, int64_t span, int child_major) {
   const int64_t total = n * m;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * kThreads) {
-    const int64_t i = e / m, j = e % m;
+    // key-major: out[i*m + j]; child-major: out[j*n + i] (each child set contiguous)
+    const int64_t i = child_major ? e % n : e / m;
+    const int64_t j = child_major ? e / n : e % m;
     const uint64_t k = (uint64_t)keys[i];
     if (mode == OUT_SPLIT) {
       static_cast<int64_t*>(out)[e] = (int64_t)mix(k + (uint64_t)(j + 1) * kGolden);
@@ -96,14 +98,16 @@ int stream_grid(int64_t n) {
 }  // namespace
 
 extern "C" int mi_key_expand(const int64_t* keys, void* out, int64_t n, int64_t m, int mode,
-                             int64_t minval, int64_t maxval, mi_stream_t stream) {
+                             int64_t minval, int64_t maxval, int child_major,
+                             mi_stream_t stream) {
   MI_REQUIRE(n >= 0 && m >= 0 && mode >= OUT_SPLIT && mode <= OUT_UNIT_UNIFORM,
              "mi_key_expand: bad arguments");
   if (n == 0 || m == 0) return 0;
   MI_REQUIRE(keys && out, "mi_key_expand: null pointer");
   MI_REQUIRE(mode != OUT_RANDINT || maxval > minval, "mi_key_expand: empty randint range");
   hipLaunchKernelGGL(key_expand_kernel, dim3(stream_grid(n * m)), dim3(kThreads), 0,
-                     mippo::as_stream(stream), keys, out, n, m, mode, minval, maxval - minval);
+                     mippo::as_stream(stream), keys, out, n, m, mode, minval, maxval - minval,
+                     child_major);
   return mippo::check_launch("mi_key_expand");
 }
 

@@ -17,6 +17,10 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kMaxBlocks = 256;
+// up to this many elements one block does the whole reduction in ONE launch (the
+// workload's minibatch is 30 720 elements; a second launch costs more than the
+// serial tail it removes)
+constexpr int64_t kSingleBlockMax = 65536;
 
 __device__ inline double block_sum(double v, double* scratch) {
   // wave reduce (64 lanes) then across the 16 waves of the block
@@ -52,6 +56,25 @@ adv_stats_partial_kernel(const float* __restrict__ adv, int64_t n, double* parti
   }
 }
 
+// Small-n fast path: one 1024-thread block computes the final triple directly.
+__global__ void __launch_bounds__(kThreads)
+adv_stats_single_kernel(const float* __restrict__ adv, int64_t n, double* stats) {
+  __shared__ double scratch[kThreads / 64];
+  double s = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+    const double a = adv[i];
+    s += a;
+    s2 += a * a;
+  }
+  const double ts = block_sum(s, scratch);
+  const double ts2 = block_sum(s2, scratch);
+  if (threadIdx.x == 0) {
+    stats[0] = ts;
+    stats[1] = ts2;
+    stats[2] = (double)n;
+  }
+}
+
 // stats: [3] = (sum, sum of squares, count)
 __global__ void adv_stats_finalize_kernel(const double* partials, int G, int64_t n,
                                           double* stats) {
@@ -72,7 +95,8 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
                 const float* __restrict__ adv, const float* __restrict__ values,
                 const float* __restrict__ reg, const double* __restrict__ stats,
                 float clip, float critic_weight, float* __restrict__ g_ll,
-                float* __restrict__ g_v, double* __restrict__ partials, int64_t n) {
+                float* __restrict__ g_v, double* __restrict__ partials,
+                float* __restrict__ loss_out, int64_t n) {
   __shared__ double scratch[kThreads / 64];
   float mean = 0.0f, denom = 1.0f;
   if (stats) {
@@ -111,11 +135,19 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
   const double t2 = block_sum(s_reg, scratch);
   const double t3 = block_sum(s_clip, scratch);
   if (threadIdx.x == 0) {
-    double* p = partials + 4 * blockIdx.x;
-    p[0] = t0;
-    p[1] = t1;
-    p[2] = t2;
-    p[3] = t3;
+    if (loss_out) {  // single-block launch: finalize in place
+      const double dn = (double)n;
+      loss_out[0] = (float)(-t0 / dn);
+      loss_out[1] = (float)(0.5 * t1 / dn);
+      loss_out[2] = (float)(t2 / dn);
+      loss_out[3] = (float)(t3 / dn);
+    } else {
+      double* p = partials + 4 * blockIdx.x;
+      p[0] = t0;
+      p[1] = t1;
+      p[2] = t2;
+      p[3] = t3;
+    }
   }
 }
 
@@ -150,9 +182,13 @@ extern "C" int mi_adv_stats_f32(const float* adv, int64_t n, double* stats, void
                                 mi_stream_t stream) {
   MI_REQUIRE(n >= 1, "mi_adv_stats_f32: n must be >= 1");
   MI_REQUIRE(adv && stats && workspace, "mi_adv_stats_f32: null pointer");
+  hipStream_t st = mippo::as_stream(stream);
+  if (n <= kSingleBlockMax) {
+    hipLaunchKernelGGL(adv_stats_single_kernel, dim3(1), dim3(kThreads), 0, st, adv, n, stats);
+    return mippo::check_launch("mi_adv_stats_f32(single)");
+  }
   const int G = grid_for(n);
   double* partials = static_cast<double*>(workspace);
-  hipStream_t st = mippo::as_stream(stream);
   hipLaunchKernelGGL(adv_stats_partial_kernel, dim3(G), dim3(kThreads), 0, st, adv, n, partials);
   int rc = mippo::check_launch("mi_adv_stats_f32(partial)");
   if (rc) return rc;
@@ -168,11 +204,17 @@ extern "C" int mi_ppo_loss_f32(const float* ll_new, const float* ll_old, const f
   MI_REQUIRE(n >= 1, "mi_ppo_loss_f32: n must be >= 1");
   MI_REQUIRE(ll_new && ll_old && adv && values && g_ll && g_v && loss_out && workspace,
              "mi_ppo_loss_f32: null pointer");
-  const int G = grid_for(n);
   double* partials = static_cast<double*>(workspace);
   hipStream_t st = mippo::as_stream(stream);
+  if (n <= kSingleBlockMax) {
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(kThreads), 0, st, ll_new, ll_old, adv, values,
+                       reg, adv_stats, clip_range, critic_weight, g_ll, g_v, partials, loss_out, n);
+    return mippo::check_launch("mi_ppo_loss_f32(single)");
+  }
+  const int G = grid_for(n);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(G), dim3(kThreads), 0, st, ll_new, ll_old, adv, values,
-                     reg, adv_stats, clip_range, critic_weight, g_ll, g_v, partials, n);
+                     reg, adv_stats, clip_range, critic_weight, g_ll, g_v, partials,
+                     (float*)nullptr, n);
   int rc = mippo::check_launch("mi_ppo_loss_f32");
   if (rc) return rc;
   hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, partials, G, n, loss_out);

@@ -75,6 +75,34 @@ select_rows_multi_kernel(const uint8_t* __restrict__ mask, SelectTable tab, int6
   }
 }
 
+struct GatherLeaf {
+  const void* src;
+  void* dst;
+  int64_t T;      // time steps of this leaf
+  int64_t words;  // words per row
+  int word_bytes;
+};
+struct GatherTable {
+  GatherLeaf leaf[kMaxSelectLeaves];
+};
+
+__global__ void __launch_bounds__(kThreads)
+gather_cols_multi_kernel(GatherTable tab, const int64_t* __restrict__ idx, int64_t N, int64_t L) {
+  const GatherLeaf lf = tab.leaf[blockIdx.y];
+  const int64_t total = lf.T * L * lf.words;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t w = i % lf.words;
+    const int64_t j = (i / lf.words) % L;
+    const int64_t t = i / (lf.words * L);
+    const int64_t s = (t * N + idx[j]) * lf.words + w;
+    if (lf.word_bytes == 4)
+      static_cast<uint32_t*>(lf.dst)[i] = static_cast<const uint32_t*>(lf.src)[s];
+    else
+      static_cast<uint8_t*>(lf.dst)[i] = static_cast<const uint8_t*>(lf.src)[s];
+  }
+}
+
 int stream_grid(int64_t n) {
   int64_t g = mippo::ceil_div(n, kThreads);
   if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
@@ -159,4 +187,33 @@ extern "C" int mi_select_rows_multi(const uint8_t* mask, const void* const* on_t
   hipLaunchKernelGGL(select_rows_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream),
                      mask, tab, B);
   return mippo::check_launch("mi_select_rows_multi");
+}
+
+extern "C" int mi_gather_cols_multi(const void* const* src, void* const* dst, const int64_t* T,
+                                    const int64_t* row_bytes, int64_t n_leaves,
+                                    const int64_t* idx, int64_t N, int64_t L,
+                                    mi_stream_t stream) {
+  MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves && N >= 1 && L >= 0,
+             "mi_gather_cols_multi: 0 <= n_leaves <= %d", kMaxSelectLeaves);
+  if (n_leaves == 0 || L == 0) return 0;
+  MI_REQUIRE(src && dst && T && row_bytes && idx, "mi_gather_cols_multi: null pointer");
+  GatherTable tab = {};
+  int64_t max_total = 0;
+  for (int64_t l = 0; l < n_leaves; ++l) {
+    MI_REQUIRE(src[l] && dst[l] && T[l] >= 1 && row_bytes[l] >= 1,
+               "mi_gather_cols_multi: bad leaf %lld", (long long)l);
+    const bool w4 = row_bytes[l] % 4 == 0 && aligned4(src[l]) && aligned4(dst[l]);
+    GatherLeaf& lf = tab.leaf[l];
+    lf.src = src[l];
+    lf.dst = dst[l];
+    lf.T = T[l];
+    lf.word_bytes = w4 ? 4 : 1;
+    lf.words = row_bytes[l] / lf.word_bytes;
+    const int64_t tot = lf.T * L * lf.words;
+    if (tot > max_total) max_total = tot;
+  }
+  dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_leaves);
+  hipLaunchKernelGGL(gather_cols_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream),
+                     tab, idx, N, L);
+  return mippo::check_launch("mi_gather_cols_multi");
 }

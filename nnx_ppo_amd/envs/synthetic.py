@@ -9,6 +9,7 @@ import torch
 
 from .. import random as rnd
 from ..algorithms.types import State
+from .constants import constant
 
 
 class MockEnv:
@@ -39,12 +40,12 @@ class MockEnv:
 
     def reset(self, rng: torch.Tensor) -> State:
         n = rng.shape
-        zero = torch.zeros(n, dtype=torch.int64, device=rng.device)
+        zero = constant(n, torch.int64, 0, rng.device)
         return State(
             data={"key": rng, "step_count": zero},
             obs=self._obs(rng, zero),
-            reward=torch.zeros(n, dtype=torch.float32, device=rng.device),
-            done=torch.zeros(n, dtype=torch.bool, device=rng.device),
+            reward=constant(n, torch.float32, 0.0, rng.device),
+            done=constant(n, torch.bool, 0, rng.device),
             metrics={}, info={})
 
     def step(self, state: State, action: torch.Tensor) -> State:
@@ -53,7 +54,7 @@ class MockEnv:
         return State(
             data={"key": key, "step_count": step},
             obs=self._obs(key, step),
-            reward=torch.ones(step.shape, dtype=torch.float32, device=step.device),
+            reward=constant(step.shape, torch.float32, 1.0, step.device),
             done=step >= self.max_steps,
             metrics={}, info={})
 

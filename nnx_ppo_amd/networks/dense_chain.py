@@ -24,17 +24,34 @@ from .. import ops
 from .types import param_epoch
 
 
+def _stale(layer) -> bool:
+    w = layer.kernel.data
+    return (getattr(layer, "_shadow_epoch", None) != param_epoch()
+            or getattr(layer, "_w_bf", None) is None or layer._w_bf.device != w.device)
+
+
+def refresh(layers) -> None:
+    """Refresh the bf16 shadows of every stale layer of a chain in one launch."""
+    stale = [l for l in layers if _stale(l)]
+    if not stale:
+        return
+    for l in stale:
+        w = l.kernel.data
+        K, N = w.shape
+        if getattr(l, "_w_bf", None) is None or l._w_bf.device != w.device:
+            l._w_bf = torch.zeros(K, ops.pad8(N), dtype=torch.bfloat16, device=w.device)
+            l._wt_bf = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=w.device)
+    ops.weights_to_bf16_multi([l.kernel.data for l in stale], [l._w_bf for l in stale],
+                              [l._wt_bf for l in stale])
+    for l in stale:
+        l._shadow_epoch = param_epoch()
+
+
 def _shadows(layer):
     """bf16 shadows (W [K, pad8 N], W^T [N, pad8 K]) of a Dense layer's fp32
     master kernel, refreshed when the parameters have changed."""
-    w = layer.kernel.data
-    if getattr(layer, "_shadow_epoch", None) != param_epoch() or layer._w_bf.device != w.device:
-        K, N = w.shape
-        if getattr(layer, "_w_bf", None) is None or layer._w_bf.device != w.device:
-            layer._w_bf = torch.zeros(K, ops.pad8(N), dtype=torch.bfloat16, device=w.device)
-            layer._wt_bf = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=w.device)
-        ops.weights_to_bf16(w, layer._w_bf, layer._wt_bf)
-        layer._shadow_epoch = param_epoch()
+    if _stale(layer):
+        refresh([layer])
     return layer._w_bf, layer._wt_bf
 
 
@@ -57,6 +74,7 @@ def _fusable(layers, M: int) -> bool:
 
 
 def _chain_args(layers):
+    refresh(layers)
     wts = [_shadows(l)[1] for l in layers]
     biases = [_bias(l) for l in layers]
     dims = [layers[0].in_features] + [l.out_features for l in layers]
@@ -69,6 +87,7 @@ def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
     if _fusable(layers, x2.shape[0]):
         out, _ = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=False)
         return out
+    refresh(layers)
     x_bf = ops.cast_pad_bf16(x2)
     y = None
     for i, layer in enumerate(layers):
@@ -89,6 +108,7 @@ def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
         y, sv = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=True)
         saved = [(xb, aux, _shadows(l)[0]) for (xb, aux), l in zip(sv, layers)]
         return (saved, M, need_input_grad), y
+    refresh(layers)
     x_bf = ops.cast_pad_bf16(x2)
     saved = []
     y = None

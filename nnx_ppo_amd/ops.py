@@ -262,6 +262,19 @@ def weights_to_bf16(w: torch.Tensor, w_bf: torch.Tensor, wt_bf: torch.Tensor) ->
                                    wt_bf.shape[1], K, N, stream()), "mi_weights_to_bf16")
 
 
+def weights_to_bf16_multi(ws: list, w_bfs: list, wt_bfs: list) -> None:
+    """Refresh the bf16 shadows of up to 16 layers per launch."""
+    for i in range(0, len(ws), 16):
+        w, wb, wt = ws[i:i + 16], w_bfs[i:i + 16], wt_bfs[i:i + 16]
+        n = len(w)
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int64 * n
+        check(lib().mi_weights_to_bf16_multi(
+            n, P(*[ptr(t, f32) for t in w]), P(*[ptr(t, bf16) for t in wb]),
+            P(*[ptr(t, bf16) for t in wt]), I(*[t.shape[0] for t in w]),
+            I(*[t.shape[1] for t in w]), stream()), "mi_weights_to_bf16_multi")
+
+
 def dense_fwd_bf16(x_bf, wt_bf, bias, K: int, N: int, act: int, *, want_f32: bool,
                    want_bf: bool, want_preact: bool = False):
     """Returns (y_f32 | None, y_bf | None, preact_bf | None)."""
@@ -439,6 +452,47 @@ def gather_cols(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def gather_cols_multi(leaves: list, idx: torch.Tensor) -> list:
+    """`gather_cols` for several time-major `[T_l, N, ...]` leaves with ONE launch per
+    16 leaves (all leaves share N and the index vector)."""
+    _need(idx.dim() == 1 and idx.dtype == i64, "gather_cols_multi: idx must be int64 [L]")
+    L = idx.numel()
+    outs: list = [None] * len(leaves)
+    batch: list = []
+    N = None
+
+    def flush():
+        if not batch:
+            return
+        n = len(batch)
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int64 * n
+        check(lib().mi_gather_cols_multi(P(*[b[0] for b in batch]), P(*[b[1] for b in batch]),
+                                         I(*[b[2] for b in batch]), I(*[b[3] for b in batch]), n,
+                                         ptr(idx, i64), N, L, stream()), "mi_gather_cols_multi")
+        batch.clear()
+
+    for k, src in enumerate(leaves):
+        _need(src.dim() >= 2, "gather_cols_multi: leaves must be [T, N, ...]")
+        if N is None:
+            N = src.shape[1]
+        _need(src.shape[1] == N, "gather_cols_multi: leaves must share N")
+        row_bytes = src.element_size()
+        for d in src.shape[2:]:
+            row_bytes *= d
+        dst = torch.empty((src.shape[0], L, *src.shape[2:]), dtype=src.dtype, device=src.device)
+        outs[k] = dst
+        if row_bytes == 0 or L == 0 or src.shape[0] == 0:
+            continue
+        s_ = src.view(torch.uint8) if src.dtype == torch.bool else src
+        d_ = dst.view(torch.uint8) if dst.dtype == torch.bool else dst
+        batch.append((ptr(s_), ptr(d_), src.shape[0], row_bytes))
+        if len(batch) == 16:
+            flush()
+    flush()
+    return outs
+
+
 def select_rows(mask: torch.Tensor, on_true: torch.Tensor, on_false: torch.Tensor,
                 out: torch.Tensor | None = None) -> torch.Tensor:
     """`where(mask[:, None...], on_true, on_false)` over the leading axis; `on_true`
@@ -511,15 +565,18 @@ def select_rows_multi(mask: torch.Tensor, pairs: list) -> list:
 KEY_SPLIT, KEY_BITS, KEY_RANDINT, KEY_UNIFORM, KEY_UNIT_UNIFORM = 0, 1, 2, 3, 4
 
 
-def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: int = 0):
-    """keys (int64, any shape) -> `[*keys.shape, m]` children / bits / integers / floats."""
+def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: int = 0,
+               child_major: bool = False):
+    """keys (int64, any shape) -> `[*keys.shape, m]` children / bits / integers / floats
+    (`[m, *keys.shape]` when child_major: each child set is contiguous)."""
     _need(keys.dtype == i64, "key_expand: keys must be int64")
     k = keys if keys.is_contiguous() else keys.contiguous()
     n = k.numel()
     dt = f32 if mode in (KEY_UNIFORM, KEY_UNIT_UNIFORM) else i64
-    out = torch.empty((*k.shape, m), dtype=dt, device=k.device)
+    shape = (m, *k.shape) if child_major else (*k.shape, m)
+    out = torch.empty(shape, dtype=dt, device=k.device)
     check(lib().mi_key_expand(ptr(k, i64), ptr(out), n, int(m), int(mode), int(minval),
-                              int(maxval), stream()), "mi_key_expand")
+                              int(maxval), int(bool(child_major)), stream()), "mi_key_expand")
     return out
 
 

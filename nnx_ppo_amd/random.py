@@ -57,6 +57,16 @@ def split(k: torch.Tensor, num=2) -> torch.Tensor:
     return out.reshape(*k.shape, *shape)
 
 
+def split2(k: torch.Tensor):
+    """`a, b = split(k)` as two CONTIGUOUS tensors of k's shape (one launch on the
+    GPU; same integers as `split(k)[..., 0]`, `split(k)[..., 1]`)."""
+    if k.is_cuda:
+        out = _ops().key_expand(k, 2, 0, child_major=True)
+        return out[0], out[1]
+    s = split(k, 2)
+    return s[..., 0].contiguous(), s[..., 1].contiguous()
+
+
 def _to_i64(v: int) -> int:
     v &= 0xFFFFFFFFFFFFFFFF
     return v - (1 << 64) if v >= (1 << 63) else v

@@ -7,6 +7,7 @@ from __future__ import annotations
 import torch
 
 from .. import random as rnd
+from ..envs.constants import constant
 
 
 class EpisodeWrapper:
@@ -36,11 +37,10 @@ class EpisodeWrapper:
         return next_state.replace(done=done.to(torch.float32))
 
     def reset(self, rng: torch.Tensor):
-        keys = rnd.split(rng)  # [..., 2]: base_rng, step_counter_rng
-        base_rng, step_counter_rng = keys[..., 0], keys[..., 1]
+        base_rng, step_counter_rng = rnd.split2(rng)
         next_state = self.env.reset(base_rng)
         next_state.info["step_counter"] = rnd.randint(step_counter_rng, (), 0, self.max_len // 2)
-        next_state.info["truncated"] = torch.zeros(rng.shape, dtype=torch.bool, device=rng.device)
+        next_state.info["truncated"] = constant(rng.shape, torch.bool, 0, rng.device)
         return next_state
 
     @property

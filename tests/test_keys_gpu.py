@@ -94,3 +94,26 @@ def test_select_rows_multi(dev):
     for (a, b), o in zip(pairs, outs):
         m = mask.reshape(B, *([1] * (b.dim() - 1)))
         assert torch.equal(o.cpu(), torch.where(m, a if a.shape == b.shape else a.expand_as(b), b))
+
+
+def test_split2_and_gather_multi(dev):
+    from nnx_ppo_amd import ops
+
+    k = keys.split(keys.key(5), 300)
+    a_c, b_c = keys.split2(k)
+    a_g, b_g = keys.split2(k.to(dev))
+    assert a_g.is_contiguous() and b_g.is_contiguous()
+    assert torch.equal(a_g.cpu(), a_c) and torch.equal(b_g.cpu(), b_c)
+    assert torch.equal(a_c, keys.split(k)[..., 0]) and torch.equal(b_c, keys.split(k)[..., 1])
+    g = torch.Generator().manual_seed(0)
+    N, L = 200, 48
+    leaves = []
+    for i in range(19):
+        T = [7, 1, 3][i % 3]
+        feat = [(), (5,), (2, 3), (64,)][i % 4]
+        dt = [torch.float32, torch.bool, torch.int64, torch.uint8][i % 4]
+        leaves.append((torch.randn(T, N, *feat, generator=g) * 40).to(dt))
+    idx = torch.randperm(N, generator=g)[:L]
+    outs = ops.gather_cols_multi([x.to(dev) for x in leaves], idx.to(dev))
+    for x, o in zip(leaves, outs):
+        assert torch.equal(o.cpu(), x[:, idx])
