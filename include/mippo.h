@@ -194,6 +194,17 @@ int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* dz_bf, int64
                          float* g_w, float* g_b, void* workspace, int64_t M, int64_t K,
                          int64_t N, int accumulate, mi_stream_t stream);
 
+/* The dW / db of up to 8 layers that share M (an MLP trunk) in at most three
+ * launches (one per tile class) plus one grouped reduction: the per-layer dW
+ * GEMMs are independent once every dz exists, and side by side they fill the
+ * chip.  x_bf[l] [M][pad8 K_l], dz_bf[l] [M][pad8 N_l]; g_b / its entries nullable. */
+int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const int64_t* K,
+                                                     const int64_t* N, int64_t M);
+int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf, const void* const* dz_bf,
+                                 float* const* g_w, float* const* g_b, const int64_t* K,
+                                 const int64_t* N, int64_t M, void* workspace, int accumulate,
+                                 mi_stream_t stream);
+
 /* A whole MLP trunk (L <= 8 Dense layers, widths <= 512) in ONE launch; only
  * weights stream (bf16 W^T shadows, `wt_bf[l]` = [N_l][pad8 K_l]).
  * dims[L+1] = (K_0, N_0 = K_1, ..., N_{L-1}); acts[L]; bias[l] nullable.

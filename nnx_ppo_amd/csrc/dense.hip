@@ -258,7 +258,60 @@ int64_t dw_splits(int64_t M, int64_t K, int64_t N) {
 
 }  // namespace
 
+namespace {
+struct RedProblem {
+  const float* slabs;
+  float* gw;
+  float* gb;
+  int64_t S, KN, N;
+};
+struct RedTable {
+  RedProblem p[8];
+};
+
+// blockIdx.y = problem; same fixed-order sum as reduce_slabs_kernel.
+__global__ void __launch_bounds__(kThreads)
+reduce_slabs_grouped_kernel(RedTable tab, int accumulate) {
+  const RedProblem pr = tab.p[blockIdx.y];
+  const int64_t stride = pr.KN + pr.N;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < stride;
+       i += (int64_t)gridDim.x * kThreads) {
+    float v = 0.0f;
+    int64_t s = 0;
+    for (; s + 8 <= pr.S; s += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = pr.slabs[(s + u) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < pr.S; ++s) v += pr.slabs[s * stride + i];
+    if (i < pr.KN) {
+      pr.gw[i] = accumulate ? pr.gw[i] + v : v;
+    } else if (pr.gb) {
+      pr.gb[i - pr.KN] = accumulate ? pr.gb[i - pr.KN] + v : v;
+    }
+  }
+}
+}  // namespace
+
 namespace mippo {
+int reduce_slabs_grouped(int n, const float* const* slabs, const int64_t* S, const int64_t* KN,
+                         const int64_t* N, float* const* g_w, float* const* g_b, int accumulate,
+                         hipStream_t st) {
+  RedTable tab = {};
+  int64_t max_stride = 0;
+  for (int l = 0; l < n; ++l) {
+    tab.p[l] = RedProblem{slabs[l], g_w[l], g_b ? g_b[l] : nullptr, S[l], KN[l], N[l]};
+    if (KN[l] + N[l] > max_stride) max_stride = KN[l] + N[l];
+  }
+  int64_t gx = ceil_div(max_stride, kThreads);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(reduce_slabs_grouped_kernel, dim3((unsigned)gx, (unsigned)n), dim3(kThreads),
+                     0, st, tab, accumulate);
+  return check_launch("reduce_slabs_grouped");
+}
+
 int reduce_slabs(const float* slabs, float* g_w, float* g_b, int64_t S, int64_t KN, int64_t N,
                  int accumulate, hipStream_t st) {
   const int64_t total = KN + N;

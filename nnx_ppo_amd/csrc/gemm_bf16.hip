@@ -208,12 +208,41 @@ nt_gemm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 
 // dW: C[i][j] = sum_m A[m][i] * B[m][j] over the split's rows; A = X [M][lda],
 // B = dZ [M][ldb], both reduce-major.  Slab layout: [S][I*J + J].
+// One dW problem of a grouped launch.  All layers of an MLP trunk (of one tile
+// class) go out in ONE launch: their dW GEMMs are independent once the dX chain
+// has produced every dZ, and together they fill the chip (a single 64x64 layer
+// only makes 60 workgroups).
+struct DwProblem {
+  const bf16_t* A;   // X  [M][lda]
+  const bf16_t* B;   // dZ [M][ldb]
+  float* slabs;      // [S][I*J + J]
+  int64_t lda, ldb, I, J;
+  int z_begin;       // first blockIdx.z of this problem (its splits follow)
+};
+constexpr int kMaxDwProblems = 8;
+struct DwTable {
+  DwProblem p[kMaxDwProblems];
+  int n;
+  int64_t M, rows_per_split;
+};
+
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(kThreads)
-tn_gemm_dw_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
-                  int64_t ldb, int64_t I, int64_t J, int64_t M, float* __restrict__ slabs,
-                  int64_t rows_per_split) {
+tn_gemm_dw_kernel(DwTable tab) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxDwProblems; ++q)
+    if (q < tab.n && (int)blockIdx.z >= tab.p[q].z_begin) pi = q;
+  const DwProblem pr = tab.p[pi];
+  const bf16_t* __restrict__ A = pr.A;
+  const bf16_t* __restrict__ B = pr.B;
+  const int64_t lda = pr.lda, ldb = pr.ldb, I = pr.I, J = pr.J, M = tab.M;
+  const int64_t rows_per_split = tab.rows_per_split;
+  float* __restrict__ slabs = pr.slabs;
+  const int zsplit = (int)blockIdx.z - pr.z_begin;
+  if ((int64_t)blockIdx.x * (WM * TM * 16) >= I || (int64_t)blockIdx.y * (WN * TN * 16) >= J)
+    return;  // this problem has fewer tiles than the group's grid
   constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
   constexpr int AROW = BM + 16;  // LDS rows are the reduce index: [BK][BM + pad]
@@ -231,7 +260,7 @@ tn_gemm_dw_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __res
   const int wm = wave / WN, wn = wave % WN;
   const int64_t i0 = (int64_t)blockIdx.x * BM;
   const int64_t j0 = (int64_t)blockIdx.y * BN;
-  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  const int64_t r_begin = (int64_t)zsplit * rows_per_split;
   const int64_t r_end = r_begin + rows_per_split < M ? r_begin + rows_per_split : M;
 
   f32x4 acc[TM][TN];
@@ -326,7 +355,7 @@ tn_gemm_dw_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __res
     buf ^= 1;
   }
 
-  float* slab = slabs + (int64_t)blockIdx.z * (I * J + J);
+  float* slab = slabs + (int64_t)zsplit * (I * J + J);
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -426,16 +455,6 @@ int launch_nt(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int64_
 
 int64_t dw_tile_n(int64_t N) { return N > 64 ? 128 : (N > 16 ? 64 : 16); }
 
-int64_t dw_splits_bf16(int64_t M, int64_t K, int64_t N) {
-  const int64_t tiles = mippo::ceil_div(K, 128) * mippo::ceil_div(N, dw_tile_n(N));
-  int64_t s = mippo::ceil_div((int64_t)2 * mippo::kNumCU, tiles);
-  const int64_t max_s = mippo::ceil_div(M, 512);
-  if (s > max_s) s = max_s;
-  if (s < 1) s = 1;
-  if (s > 1024) s = 1024;
-  return s;
-}
-
 }  // namespace
 
 namespace mippo {
@@ -526,9 +545,110 @@ extern "C" int mi_dense_bwd_dx_bf16(const void* dz_bf, int64_t lddz, const void*
                            mippo::as_stream(stream));
 }
 
+// rows per split / number of splits shared by every problem of a launch (they
+// share M): enough workgroups to cover the chip about twice, >= 128 rows each.
+static void dw_split_plan(int64_t M, int64_t total_tiles, int64_t* rows, int64_t* S) {
+  int64_t s = mippo::ceil_div((int64_t)2 * mippo::kNumCU, total_tiles < 1 ? 1 : total_tiles);
+  const int64_t max_s = mippo::ceil_div(M, 128);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  *rows = mippo::ceil_div(mippo::ceil_div(M, s), 64) * 64;
+  *S = mippo::ceil_div(M, *rows);
+}
+
+static int64_t dw_tiles(int64_t K, int64_t N) {
+  return mippo::ceil_div(K, 128) * mippo::ceil_div(N, dw_tile_n(N));
+}
+
+namespace mippo {
+int reduce_slabs_grouped(int n, const float* const* slabs, const int64_t* S, const int64_t* KN,
+                         const int64_t* N, float* const* g_w, float* const* g_b, int accumulate,
+                         hipStream_t st);
+}
+
+extern "C" int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const int64_t* K,
+                                                               const int64_t* N, int64_t M) {
+  if (n < 1 || n > kMaxDwProblems || !K || !N || M < 1) return -EINVAL;
+  // worst case: every problem alone in its launch
+  int64_t total = 0;
+  for (int64_t l = 0; l < n; ++l) {
+    int64_t rows, S;
+    dw_split_plan(M, dw_tiles(K[l], N[l]), &rows, &S);
+    total += S * (K[l] * N[l] + N[l]);
+  }
+  return total * (int64_t)sizeof(float);
+}
+
+extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
+                                            const void* const* dz_bf, float* const* g_w,
+                                            float* const* g_b, const int64_t* K,
+                                            const int64_t* N, int64_t M, void* workspace,
+                                            int accumulate, mi_stream_t stream) {
+  MI_REQUIRE(n >= 1 && n <= kMaxDwProblems && M >= 1,
+             "mi_dense_bwd_dw_grouped_bf16: 1 <= n <= %d", kMaxDwProblems);
+  MI_REQUIRE(x_bf && dz_bf && g_w && K && N && workspace,
+             "mi_dense_bwd_dw_grouped_bf16: null pointer");
+  hipStream_t st = mippo::as_stream(stream);
+  float* ws = static_cast<float*>(workspace);
+  const float* slab_ptr[kMaxDwProblems];
+  int64_t Sv[kMaxDwProblems], KNv[kMaxDwProblems];
+  for (int64_t l = 0; l < n; ++l) {
+    MI_REQUIRE(x_bf[l] && dz_bf[l] && g_w[l] && K[l] >= 1 && N[l] >= 1 && al16(x_bf[l]) &&
+                   al16(dz_bf[l]),
+               "mi_dense_bwd_dw_grouped_bf16: bad problem %lld", (long long)l);
+    KNv[l] = K[l] * N[l];
+  }
+  // one launch per tile class (by output width), problems of a class side by side
+  for (int cls = 0; cls < 3; ++cls) {
+    DwTable tab = {};
+    int idx[kMaxDwProblems];
+    int64_t tiles = 0, gx = 0, gy = 0;
+    for (int64_t l = 0; l < n; ++l) {
+      const int c = N[l] > 64 ? 0 : (N[l] > 16 ? 1 : 2);
+      if (c != cls) continue;
+      idx[tab.n++] = (int)l;
+      tiles += dw_tiles(K[l], N[l]);
+      const int64_t tx = mippo::ceil_div(K[l], 128), ty = mippo::ceil_div(N[l], dw_tile_n(N[l]));
+      if (tx > gx) gx = tx;
+      if (ty > gy) gy = ty;
+    }
+    if (tab.n == 0) continue;
+    int64_t rows, S;
+    dw_split_plan(M, tiles, &rows, &S);
+    tab.M = M;
+    tab.rows_per_split = rows;
+    for (int q = 0; q < tab.n; ++q) {
+      const int l = idx[q];
+      DwProblem& pr = tab.p[q];
+      pr.A = static_cast<const bf16_t*>(x_bf[l]);
+      pr.B = static_cast<const bf16_t*>(dz_bf[l]);
+      pr.lda = mippo::ceil_div(K[l], 8) * 8;
+      pr.ldb = mippo::ceil_div(N[l], 8) * 8;
+      pr.I = K[l];
+      pr.J = N[l];
+      pr.slabs = ws;
+      pr.z_begin = (int)(q * S);
+      slab_ptr[l] = ws;
+      Sv[l] = S;
+      ws += S * (KNv[l] + N[l]);
+    }
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(tab.n * S));
+    if (cls == 0) {
+      hipLaunchKernelGGL((tn_gemm_dw_kernel<2, 2, 4, 4>), grid, dim3(kThreads), 0, st, tab);
+    } else if (cls == 1) {
+      hipLaunchKernelGGL((tn_gemm_dw_kernel<4, 1, 2, 4>), grid, dim3(kThreads), 0, st, tab);
+    } else {
+      hipLaunchKernelGGL((tn_gemm_dw_kernel<4, 1, 2, 1>), grid, dim3(kThreads), 0, st, tab);
+    }
+    int rc = mippo::check_launch("mi_dense_bwd_dw_grouped_bf16");
+    if (rc) return rc;
+  }
+  return mippo::reduce_slabs_grouped((int)n, slab_ptr, Sv, KNv, N, g_w, g_b, accumulate, st);
+}
+
 extern "C" int64_t mi_dense_bwd_dw_bf16_workspace_bytes(int64_t M, int64_t K, int64_t N) {
-  if (M < 0 || K < 1 || N < 1) return -EINVAL;
-  return dw_splits_bf16(M, K, N) * (K * N + N) * (int64_t)sizeof(float);
+  return mi_dense_bwd_dw_grouped_bf16_workspace_bytes(1, &K, &N, M);
 }
 
 extern "C" int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* dz_bf,
@@ -536,59 +656,8 @@ extern "C" int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* d
                                     int64_t M, int64_t K, int64_t N, int accumulate,
                                     mi_stream_t stream) {
   MI_REQUIRE(M >= 1 && K >= 1 && N >= 1, "mi_dense_bwd_dw_bf16: bad shape");
-  MI_REQUIRE(ldx % 8 == 0 && lddz % 8 == 0 && ldx >= K && lddz >= N,
-             "mi_dense_bwd_dw_bf16: operand ld must be a multiple of 8 and >= K / N");
-  MI_REQUIRE(x_bf && dz_bf && g_w && workspace, "mi_dense_bwd_dw_bf16: null pointer");
-  MI_REQUIRE(al16(x_bf) && al16(dz_bf), "mi_dense_bwd_dw_bf16: operands must be 16-byte aligned");
-  hipStream_t st = mippo::as_stream(stream);
-  const int64_t S = dw_splits_bf16(M, K, N);
-  const int64_t rows = mippo::ceil_div(mippo::ceil_div(M, S), 64) * 64;
-  const int64_t S_eff = mippo::ceil_div(M, rows);
-  float* slabs = static_cast<float*>(workspace);
-  const bf16_t* A = static_cast<const bf16_t*>(x_bf);
-  const bf16_t* B = static_cast<const bf16_t*>(dz_bf);
-  if (N > 64) {
-    dim3 grid((unsigned)mippo::ceil_div(K, 128), (unsigned)mippo::ceil_div(N, 128), (unsigned)S_eff);
-    hipLaunchKernelGGL((tn_gemm_dw_kernel<2, 2, 4, 4>), grid, dim3(kThreads), 0, st, A, ldx, B,
-                       lddz, K, N, M, slabs, rows);
-  } else if (N > 16) {
-    dim3 grid((unsigned)mippo::ceil_div(K, 128), (unsigned)mippo::ceil_div(N, 64), (unsigned)S_eff);
-    hipLaunchKernelGGL((tn_gemm_dw_kernel<4, 1, 2, 4>), grid, dim3(kThreads), 0, st, A, ldx, B,
-                       lddz, K, N, M, slabs, rows);
-  } else {
-    dim3 grid((unsigned)mippo::ceil_div(K, 128), 1, (unsigned)S_eff);
-    hipLaunchKernelGGL((tn_gemm_dw_kernel<4, 1, 2, 1>), grid, dim3(kThreads), 0, st, A, ldx, B,
-                       lddz, K, N, M, slabs, rows);
-  }
-  int rc = mippo::check_launch("mi_dense_bwd_dw_bf16");
-  if (rc) return rc;
-  return mippo::reduce_slabs(slabs, g_w, g_b, S_eff, K * N, N, accumulate, st);
-}
-
-extern "C" int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w, void* const* w_bf,
-                                        void* const* wt_bf, const int64_t* K, const int64_t* N,
-                                        mi_stream_t stream) {
-  MI_REQUIRE(n_layers >= 0 && n_layers <= 16, "mi_weights_to_bf16_multi: 0 <= n_layers <= 16");
-  if (n_layers == 0) return 0;
-  MI_REQUIRE(w && w_bf && wt_bf && K && N, "mi_weights_to_bf16_multi: null pointer");
-  WTable tab = {};
-  int64_t max_total = 0;
-  for (int64_t l = 0; l < n_layers; ++l) {
-    MI_REQUIRE(w[l] && w_bf[l] && wt_bf[l] && K[l] >= 1 && N[l] >= 1,
-               "mi_weights_to_bf16_multi: bad layer %lld", (long long)l);
-    WLeaf& lf = tab.leaf[l];
-    lf.w = w[l];
-    lf.wb = static_cast<bf16_t*>(w_bf[l]);
-    lf.wt = static_cast<bf16_t*>(wt_bf[l]);
-    lf.K = K[l];
-    lf.N = N[l];
-    lf.ldw = mippo::ceil_div(N[l], 8) * 8;
-    lf.ldwt = mippo::ceil_div(K[l], 8) * 8;
-    const int64_t tot = lf.K * lf.ldw + lf.N * lf.ldwt;
-    if (tot > max_total) max_total = tot;
-  }
-  dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_layers);
-  hipLaunchKernelGGL(weights_to_bf16_multi_kernel, grid, dim3(kThreads), 0,
-                     mippo::as_stream(stream), tab);
-  return mippo::check_launch("mi_weights_to_bf16_multi");
+  MI_REQUIRE(ldx == mippo::ceil_div(K, 8) * 8 && lddz == mippo::ceil_div(N, 8) * 8,
+             "mi_dense_bwd_dw_bf16: operand ld must be pad8(K) / pad8(N)");
+  return mi_dense_bwd_dw_grouped_bf16(1, &x_bf, &dz_bf, &g_w, &g_b, &K, &N, M, workspace,
+                                      accumulate, stream);
 }

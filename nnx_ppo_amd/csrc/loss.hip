@@ -17,10 +17,12 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kMaxBlocks = 256;
-// up to this many elements one block does the whole reduction in ONE launch (the
-// workload's minibatch is 30 720 elements; a second launch costs more than the
-// serial tail it removes)
+// Up to this many elements one block does the whole reduction in ONE launch.
+// Measured on MI355X at the workload's minibatch (30 720 elements): the statistics
+// pass is cheap enough for one block (8 us vs two launches), the loss pass (exp,
+// four fp64 reductions) is not (34 us on one CU vs 7 + 5 us on 30 CUs).
 constexpr int64_t kSingleBlockMax = 65536;
+constexpr int64_t kLossSingleBlockMax = 4096;
 
 __device__ inline double block_sum(double v, double* scratch) {
   // wave reduce (64 lanes) then across the 16 waves of the block
@@ -206,7 +208,7 @@ extern "C" int mi_ppo_loss_f32(const float* ll_new, const float* ll_old, const f
              "mi_ppo_loss_f32: null pointer");
   double* partials = static_cast<double*>(workspace);
   hipStream_t st = mippo::as_stream(stream);
-  if (n <= kSingleBlockMax) {
+  if (n <= kLossSingleBlockMax) {
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(kThreads), 0, st, ll_new, ll_old, adv, values,
                        reg, adv_stats, clip_range, critic_weight, g_ll, g_v, partials, loss_out, n);
     return mippo::check_launch("mi_ppo_loss_f32(single)");

@@ -127,19 +127,22 @@ def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
 
 def backward(layers, ctx, g_out2: torch.Tensor):
     """g_out2: fp32 [M, N_last] gradient of the chain output.  Accumulates weight /
-    bias gradients; returns the fp32 input gradient [M, K0] or None."""
+    bias gradients; returns the fp32 input gradient [M, K0] or None.
+
+    The dX chain runs first (it is sequential by nature) and keeps every dz; the
+    dW / db of ALL layers then go out as one grouped launch per tile class."""
     saved, M, need_input_grad = ctx
     L = len(layers)
     last = layers[-1]
     dz_bf = ops.cast_pad_bf16(g_out2, aux=saved[-1][1] if last.act_code != ops.ACT_NONE else None,
                               act=last.act_code)
     g_in = None
+    problems = []
     for i in range(L - 1, -1, -1):
         layer = layers[i]
         x_bf, _, w_bf = saved[i]
-        ops.dense_bwd_dw_bf16(x_bf, dz_bf, layer.kernel.grad,
-                              layer.bias.grad if layer.bias is not None else None,
-                              accumulate=True)
+        problems.append((x_bf, dz_bf, layer.kernel.grad,
+                         layer.bias.grad if layer.bias is not None else None))
         if i == 0:
             if need_input_grad:
                 g_in, _ = ops.dense_bwd_dx_bf16(dz_bf, w_bf, None, ops.ACT_NONE,
@@ -150,4 +153,5 @@ def backward(layers, ctx, g_out2: torch.Tensor):
         _, dz_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, saved[i - 1][1], prev.act_code,
                                          layer.in_features, layer.out_features,
                                          want_f32=False, want_bf=True)
+    ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
     return g_in

@@ -322,6 +322,29 @@ def dense_bwd_dw_bf16(x_bf, dz_bf, g_w, g_b, accumulate: bool = True) -> None:
                                      N, int(bool(accumulate)), stream()), "mi_dense_bwd_dw_bf16")
 
 
+def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
+    """dW / db of several layers that share M: `problems` = [(x_bf, dz_bf, g_w, g_b)]."""
+    for i in range(0, len(problems), 8):
+        grp = problems[i:i + 8]
+        n = len(grp)
+        M = grp[0][0].shape[0]
+        Ks = [g[2].shape[0] for g in grp]
+        Ns = [g[2].shape[1] for g in grp]
+        for (x_bf, dz_bf, g_w, g_b), K, N in zip(grp, Ks, Ns):
+            _need(x_bf.shape == (M, pad8(K)) and dz_bf.shape == (M, pad8(N)),
+                  "dense_bwd_dw_grouped_bf16: operands must be [M, pad8(K)] / [M, pad8(N)]")
+        P = ctypes.c_void_p * n
+        I = ctypes.c_int64 * n
+        Kc, Nc = I(*Ks), I(*Ns)
+        nbytes = lib().mi_dense_bwd_dw_grouped_bf16_workspace_bytes(n, Kc, Nc, M)
+        _need(nbytes >= 0, "mi_dense_bwd_dw_grouped_bf16_workspace_bytes failed")
+        ws = workspace(grp[0][2].device, "dense_dw_grouped", nbytes)
+        check(lib().mi_dense_bwd_dw_grouped_bf16(
+            n, P(*[ptr(g[0], bf16) for g in grp]), P(*[ptr(g[1], bf16) for g in grp]),
+            P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]), Kc, Nc, M,
+            ptr(ws), int(bool(accumulate)), stream()), "mi_dense_bwd_dw_grouped_bf16")
+
+
 def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
                  train: bool):
     """Fused MLP trunk forward.  Returns (out_f32 [M, N_last], saved) where `saved`

@@ -235,3 +235,30 @@ def test_fused_mlp_forward_matches_per_layer_path(dev, dims, M, act):
             assert torch.equal(saved[l + 1][0], y_bf), l
         x_bf = y_bf
     assert torch.allclose(out, y, rtol=1e-5, atol=1e-5)
+
+
+def test_grouped_dw_matches_per_layer(dev):
+    """All layers of a trunk in one grouped dW launch per tile class == the
+    per-layer kernel, bit for bit (same tiles, same k-order, fixed-order slabs
+    — only the number of splits differs, so compare to fp32 round-off)."""
+    from nnx_ppo_amd import ops
+
+    M = 3000
+    rng = np.random.default_rng(0)
+    shapes = [(5, 64), (64, 64), (64, 64), (64, 2), (5, 256), (256, 256), (256, 1), (17, 12)]
+    problems, singles = [], []
+    for K, N in shapes:
+        x = ops.cast_pad_bf16(torch.as_tensor(rng.normal(size=(M, K)).astype(np.float32)).to(dev))
+        dz = ops.cast_pad_bf16(torch.as_tensor(rng.normal(size=(M, N)).astype(np.float32)).to(dev))
+        gw, gb = torch.zeros(K, N, device=dev), torch.zeros(N, device=dev)
+        problems.append((x, dz, gw, gb if N != 12 else None))
+        gw1, gb1 = torch.zeros(K, N, device=dev), torch.zeros(N, device=dev)
+        ops.dense_bwd_dw_bf16(x, dz, gw1, gb1, accumulate=False)
+        singles.append((gw1, gb1))
+    ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
+    for (x, dz, gw, gb), (gw1, gb1), (K, N) in zip(problems, singles, shapes):
+        want = x[:, :K].double().t() @ dz[:, :N].double()
+        assert torch.allclose(gw.double(), want, rtol=1e-4, atol=2e-3), (K, N)
+        assert torch.allclose(gw, gw1, rtol=1e-4, atol=2e-3), (K, N)
+        if gb is not None:
+            assert torch.allclose(gb, gb1, rtol=1e-4, atol=2e-3), (K, N)
