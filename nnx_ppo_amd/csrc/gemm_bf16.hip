@@ -661,3 +661,31 @@ extern "C" int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* d
   return mi_dense_bwd_dw_grouped_bf16(1, &x_bf, &dz_bf, &g_w, &g_b, &K, &N, M, workspace,
                                       accumulate, stream);
 }
+
+extern "C" int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w, void* const* w_bf,
+                                        void* const* wt_bf, const int64_t* K, const int64_t* N,
+                                        mi_stream_t stream) {
+  MI_REQUIRE(n_layers >= 0 && n_layers <= 16, "mi_weights_to_bf16_multi: 0 <= n_layers <= 16");
+  if (n_layers == 0) return 0;
+  MI_REQUIRE(w && w_bf && wt_bf && K && N, "mi_weights_to_bf16_multi: null pointer");
+  WTable tab = {};
+  int64_t max_total = 0;
+  for (int64_t l = 0; l < n_layers; ++l) {
+    MI_REQUIRE(w[l] && w_bf[l] && wt_bf[l] && K[l] >= 1 && N[l] >= 1,
+               "mi_weights_to_bf16_multi: bad layer %lld", (long long)l);
+    WLeaf& lf = tab.leaf[l];
+    lf.w = w[l];
+    lf.wb = static_cast<bf16_t*>(w_bf[l]);
+    lf.wt = static_cast<bf16_t*>(wt_bf[l]);
+    lf.K = K[l];
+    lf.N = N[l];
+    lf.ldw = mippo::ceil_div(N[l], 8) * 8;
+    lf.ldwt = mippo::ceil_div(K[l], 8) * 8;
+    const int64_t tot = lf.K * lf.ldw + lf.N * lf.ldwt;
+    if (tot > max_total) max_total = tot;
+  }
+  dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_layers);
+  hipLaunchKernelGGL(weights_to_bf16_multi_kernel, grid, dim3(kThreads), 0,
+                     mippo::as_stream(stream), tab);
+  return mippo::check_launch("mi_weights_to_bf16_multi");
+}
