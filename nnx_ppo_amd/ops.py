@@ -339,6 +339,8 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
         nbytes = lib().mi_dense_bwd_dw_grouped_bf16_workspace_bytes(n, Kc, Nc, M)
         _need(nbytes >= 0, "mi_dense_bwd_dw_grouped_bf16_workspace_bytes failed")
         ws = workspace(grp[0][2].device, "dense_dw_grouped", nbytes)
+        if profiler.active:
+            profiler.next_flops = 2.0 * M * sum(K * N for K, N in zip(Ks, Ns))
         check(lib().mi_dense_bwd_dw_grouped_bf16(
             n, P(*[ptr(g[0], bf16) for g in grp]), P(*[ptr(g[1], bf16) for g in grp]),
             P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]), Kc, Nc, M,
