@@ -327,9 +327,10 @@ def ppo_loss(
     ctx, out, reg_seq, final_state = networks.replay(
         network_state, rollout_data.obs, done, rollout_data.rollout_extras,
         need_input_grad=False)
-    # bootstrap value at T (ppo.py:433-437): fresh forward on the last next_obs
+    # bootstrap value at T (ppo.py:433-437): forward on the last next_obs; only the
+    # value estimate is used, so only the value port is evaluated
     last_obs = tree_map(lambda x: x[-1], rollout_data.next_obs)
-    out_last = networks(final_state, last_obs).output
+    last_values = networks.forward_value(final_state, last_obs)
 
     rewards = rollout_data.rewards
     values = out.value_estimates
@@ -344,7 +345,7 @@ def ppo_loss(
     del combine_advantages  # single reward key: nothing to combine
 
     values = values.contiguous()
-    adv = ops.gae(rewards.contiguous(), values, out_last.value_estimates.contiguous(),
+    adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
                   done.contiguous(), truncated.contiguous(), discounting_factor, gae_lambda)
     stats = None
     if normalize_advantages:

@@ -108,6 +108,10 @@ class PPOAdapter(StatefulModule):
             rollout_extras={"action": a_out.rollout_extras, "value": v_out.rollout_extras},
         )
 
+    def forward_value(self, state: dict[str, ModuleState], x: Any) -> Any:
+        v_out = self.value(state["value"], x, None)
+        return tree_map(_squeeze_trailing_one, v_out.output)
+
     def initialize_state(self, batch_size: int) -> dict[str, ModuleState]:
         return {"action": self.action.initialize_state(batch_size),
                 "value": self.value.initialize_state(batch_size)}

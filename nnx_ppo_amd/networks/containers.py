@@ -76,6 +76,12 @@ class Sequential(StatefulModule):
                 i += 1
         return runs
 
+    def forward_value(self, network_state: list[ModuleState], obs: Any) -> Any:
+        x = obs
+        for layer, layer_state in zip(self.layers[:-1], network_state[:-1]):
+            x = layer(layer_state, x, None).output
+        return self.layers[-1].forward_value(network_state[-1], x)
+
     def initialize_state(self, batch_size: int) -> list[ModuleState]:
         return [layer.initialize_state(batch_size) for layer in self.layers]
 

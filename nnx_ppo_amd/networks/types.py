@@ -131,6 +131,13 @@ class StatefulModule:
         del rollout_extras
         return None
 
+    def forward_value(self, module_state: ModuleState, obs: Any) -> Any:
+        """Value estimates only, for the bootstrap query V(s_T) of the loss
+        (`ppo.py:433-437`).  The reference evaluates the whole network there and
+        XLA drops the unused action branch; containers override this to skip the
+        action port explicitly (no sampler call, so no noise offset is consumed)."""
+        return self(module_state, obs).output.value_estimates
+
     # ---- sequence-level training protocol -------------------------------------
     def replay(self, state0: ModuleState, x_seq: Any, done_seq: torch.Tensor,
                extras_seq: Any, need_input_grad: bool = True):

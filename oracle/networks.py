@@ -54,6 +54,13 @@ class Module:
     def __call__(self, state, obs, extras=None) -> Out:
         raise NotImplementedError
 
+    def forward_value(self, state, obs):
+        """Value estimates of the bootstrap query (ppo.py:433-437).  Only the value
+        branch is evaluated — the reference's action sample at this point is dead
+        code — so no sampler noise offset is consumed (scheme shared with the
+        product; RNG stream alignment is unpinned by the reference)."""
+        return self(state, obs).output.value_estimates
+
     def initialize_state(self, batch_size: int):
         return ()
 
@@ -143,6 +150,12 @@ class Sequential(Module):
             metrics[len(metrics)] = out.metrics
         return Out(new_state, x, reg, metrics, new_extras)
 
+    def forward_value(self, state, obs):
+        x = obs
+        for layer, st in zip(self.layers[:-1], state[:-1]):
+            x = layer(st, x, None).output
+        return self.layers[-1].forward_value(state[-1], x)
+
     def initialize_state(self, batch_size):
         return [l.initialize_state(batch_size) for l in self.layers]
 
@@ -176,6 +189,10 @@ class PPOAdapter(Module):
                    a.regularization_loss + v.regularization_loss,
                    {"action": a.metrics, "value": v.metrics},
                    {"action": a.rollout_extras, "value": v.rollout_extras})
+
+    def forward_value(self, state, x):
+        val = self.value(state["value"], x, None).output
+        return val.squeeze(-1) if val.shape and val.shape[-1] == 1 else val
 
     def initialize_state(self, batch_size):
         return {"action": self.action.initialize_state(batch_size),

@@ -139,10 +139,10 @@ def ppo_loss(networks: Module, network_state, mb: Transition, clip_range, normal
     reg = torch.stack([r.expand(values.shape[1]) if r.dim() == 0 else r for r in regs], 0)
 
     last_obs = _map(lambda x: x[-1], mb.next_obs)
-    out_last = networks(state, last_obs)  # ppo.py:433-437 (fresh sample: extras None)
+    last_values = networks.forward_value(state, last_obs)  # ppo.py:433-437, value branch only
 
     dt = values.dtype
-    adv = gae(mb.rewards.to(dt), values.detach(), out_last.output.value_estimates.detach(),
+    adv = gae(mb.rewards.to(dt), values.detach(), last_values.detach(),
               mb.done, mb.truncated, gae_lambda, discounting_factor)
     target = (values + adv).detach()  # ppo.py:456-458
     a = adv
