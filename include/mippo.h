@@ -208,15 +208,28 @@ int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf, const void*
 /* A whole MLP trunk (L <= 8 Dense layers, widths <= 512) in ONE launch; only
  * weights stream (bf16 W^T shadows, `wt_bf[l]` = [N_l][pad8 K_l]).
  * dims[L+1] = (K_0, N_0 = K_1, ..., N_{L-1}); acts[L]; bias[l] nullable.
- * out: fp32 [M][N_{L-1}].  Inference (no training stores) at M <= 16384 runs the
- * latency-optimised kernel: 16 rows per workgroup, output columns split over the
- * waves, weight fragments global -> VGPR, one barrier per layer.  Training
+ * out: fp32 [M][N_{L-1}].  A workgroup walks 16 (M <= 8192) or 64 rows through
+ * every layer with the activations resident in LDS, output columns split over
+ * the waves, weight fragments global -> VGPR, one barrier per layer.  Training
  * stores (arrays nullable, entries nullable): y_bf[l] [M][pad8 N_l], pre_bf[l]
  * [M][pad8 N_l]; x_bf [M][pad8 K_0] = bf16 copy of the input. */
 int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
                     const float* const* bias, const int64_t* dims, const int64_t* acts,
                     float* out, void* const* y_bf, void* const* pre_bf, void* x_bf,
                     mi_stream_t stream);
+
+/* The dX chain of the same trunk in ONE launch (the backward twin of
+ * mi_mlp_fwd_bf16): from g_out [M][N_{L-1}] (fp32; times act'_{L-1}(aux_last) if
+ * act_last != MI_ACT_NONE) it produces dz_last [M][pad8 N_{L-1}] (bf16) and, walking
+ * the layers backwards, dz_bf[l-1] = (dz_l . W_l^T) (.) act'_{l-1}(aux[l-1]) for
+ * l = L-1..1 (each [M][pad8 K_l], bf16) — every operand the grouped dW launch
+ * needs — and optionally the fp32 input gradient g_in [M][K_0].  w_bf[l] = bf16 W_l
+ * [K_l][pad8 N_l]; aux[l] = layer l's output (pre-activation for swish);
+ * acts[l] as in the forward.  dz_bf has L-1 entries, aux L-1 entries. */
+int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int act_last, int64_t M,
+                       int64_t L, const void* const* w_bf, const int64_t* dims,
+                       const int64_t* acts, const void* const* aux, void* dz_last,
+                       void* const* dz_bf, float* g_in, mi_stream_t stream);
 
 /* ---- a20: GRU carry (persistent T-loop) ------------------------------------ */
 

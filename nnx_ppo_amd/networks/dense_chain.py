@@ -61,15 +61,11 @@ def _bias(layer):
 
 FUSED_MAX_LAYERS = 8
 FUSED_MAX_WIDTH = 512
-# Measured on MI355X (profiles/r01_*): the one-launch trunk wins while the grid
-# underfills the chip (rollout / bootstrap, M <= 8k rows: 28 us vs ~80 us of
-# per-layer launches); at M = 30 720 the per-layer NT kernels (up to 184 TF/s on
-# the 256x256 layer) are ahead of the trunk kernel's per-block latency chain.
-FUSED_MAX_ROWS = 8192
 
 
 def _fusable(layers, M: int) -> bool:
-    return M <= FUSED_MAX_ROWS and len(layers) <= FUSED_MAX_LAYERS and all(
+    """Whole-trunk kernels (csrc/mlp_bf16.hip) take up to 8 layers of width <= 512."""
+    return len(layers) <= FUSED_MAX_LAYERS and all(
         l.in_features <= FUSED_MAX_WIDTH and l.out_features <= FUSED_MAX_WIDTH for l in layers)
 
 
@@ -129,11 +125,23 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     """g_out2: fp32 [M, N_last] gradient of the chain output.  Accumulates weight /
     bias gradients; returns the fp32 input gradient [M, K0] or None.
 
-    The dX chain runs first (it is sequential by nature) and keeps every dz; the
-    dW / db of ALL layers then go out as one grouped launch per tile class."""
+    The dX chain runs first (it is sequential by nature: one fused launch when the
+    trunk fits the whole-trunk kernel) and keeps every dz; the dW / db of ALL
+    layers then go out as one grouped launch per tile class."""
     saved, M, need_input_grad = ctx
     L = len(layers)
     last = layers[-1]
+    grads = [(l.kernel.grad, l.bias.grad if l.bias is not None else None) for l in layers]
+    if _fusable(layers, M) and (L > 1 or need_input_grad):
+        dims = [layers[0].in_features] + [l.out_features for l in layers]
+        dz, g_in = ops.mlp_bwd_dx_bf16(
+            g_out2, saved[-1][1] if last.act_code != ops.ACT_NONE else None, last.act_code,
+            [sv[2] for sv in saved], dims, [l.act_code for l in layers],
+            [sv[1] for sv in saved], need_input_grad)
+        ops.dense_bwd_dw_grouped_bf16(
+            [(saved[i][0], dz[i], grads[i][0], grads[i][1]) for i in range(L - 1, -1, -1)],
+            accumulate=True)
+        return g_in
     dz_bf = ops.cast_pad_bf16(g_out2, aux=saved[-1][1] if last.act_code != ops.ACT_NONE else None,
                               act=last.act_code)
     g_in = None
@@ -141,8 +149,7 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     for i in range(L - 1, -1, -1):
         layer = layers[i]
         x_bf, _, w_bf = saved[i]
-        problems.append((x_bf, dz_bf, layer.kernel.grad,
-                         layer.bias.grad if layer.bias is not None else None))
+        problems.append((x_bf, dz_bf, grads[i][0], grads[i][1]))
         if i == 0:
             if need_input_grad:
                 g_in, _ = ops.dense_bwd_dx_bf16(dz_bf, w_bf, None, ops.ACT_NONE,

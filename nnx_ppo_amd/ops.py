@@ -395,6 +395,31 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
     return out, saved
 
 
+def mlp_bwd_dx_bf16(g_out: torch.Tensor, aux_last, act_last: int, w_bfs: list, dims: list,
+                    acts: list, auxs: list, need_input_grad: bool):
+    """Fused dX chain of an MLP trunk.  Returns (dz list per layer [L], g_in | None):
+    dz[l] is the bf16 gradient w.r.t. layer l's pre-activation, [M, pad8(N_l)]."""
+    M = g_out.shape[0]
+    L = len(w_bfs)
+    _need(len(dims) == L + 1 and g_out.shape[1] == dims[-1], "mlp_bwd_dx_bf16: dims")
+    dev = g_out.device
+    dz = [_bf_buf(M, dims[l + 1], dev) for l in range(L)]
+    g_in = torch.empty(M, dims[0], dtype=f32, device=dev) if need_input_grad else None
+    P = ctypes.c_void_p * L
+    Pm = ctypes.c_void_p * max(L - 1, 1)
+    if profiler.active:
+        first = 0 if need_input_grad else 1
+        profiler.next_flops = 2.0 * M * sum(dims[l] * dims[l + 1] for l in range(first, L))
+    check(lib().mi_mlp_bwd_dx_bf16(
+        ptr(g_out, f32), ptr(aux_last), int(act_last), M, L, P(*[ptr(w, bf16) for w in w_bfs]),
+        (ctypes.c_int64 * (L + 1))(*[int(d) for d in dims]),
+        (ctypes.c_int64 * L)(*[int(a) for a in acts]),
+        Pm(*[ptr(a) for a in auxs[:L - 1]]) if L > 1 else None, ptr(dz[L - 1], bf16),
+        Pm(*[ptr(t, bf16) for t in dz[:L - 1]]) if L > 1 else None, ptr(g_in, f32), stream()),
+        "mi_mlp_bwd_dx_bf16")
+    return dz, g_in
+
+
 # ------------------------------------------------------------- a14: loss
 def _loss_ws(device):
     return workspace(device, "loss", lib().mi_ppo_loss_workspace_bytes(1))

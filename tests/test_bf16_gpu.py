@@ -194,7 +194,7 @@ def test_bf16_gradients_close_to_f32_path(dev):
 
 @pytest.mark.parametrize("dims", [[5, 64, 64, 64, 64, 2], [5, 256, 256, 1], [17, 256, 256, 256, 256, 12],
                                   [17, 512, 512, 1], [33, 40, 129, 7], [3, 8]])
-@pytest.mark.parametrize("M", [1, 1000, 4096])
+@pytest.mark.parametrize("M", [1, 1000, 4096, 9000])
 @pytest.mark.parametrize("act", ["relu", "swish"])
 def test_fused_mlp_forward_matches_per_layer_path(dev, dims, M, act):
     """The one-launch MLP trunk must reproduce the per-layer bf16 kernels (same
@@ -262,3 +262,50 @@ def test_grouped_dw_matches_per_layer(dev):
         assert torch.allclose(gw, gw1, rtol=1e-4, atol=2e-3), (K, N)
         if gb is not None:
             assert torch.allclose(gb, gb1, rtol=1e-4, atol=2e-3), (K, N)
+
+
+@pytest.mark.parametrize("dims", [[5, 64, 64, 64, 64, 2], [5, 256, 256, 1], [17, 512, 512, 1],
+                                  [33, 40, 129, 7], [17, 256, 256, 256, 256, 12]])
+@pytest.mark.parametrize("M", [7, 1000, 9000])
+@pytest.mark.parametrize("act", ["relu", "tanh", "swish"])
+@pytest.mark.parametrize("need_gin", [False, True])
+def test_fused_mlp_backward_matches_per_layer_path(dev, dims, M, act, need_gin):
+    """The one-launch dX chain must reproduce the per-layer dX kernels: every dz
+    (bf16) identical up to one bf16 ulp of rounding-order noise, input gradient to
+    fp32 round-off."""
+    from nnx_ppo_amd import ops
+
+    if act == "tanh" and M == 9000:
+        pytest.skip("covered by relu / swish at this size")
+    rng = np.random.default_rng(M + len(dims) + need_gin)
+    L = len(dims) - 1
+    code = ops.ACT_CODES[act]
+    acts = [code] * (L - 1) + [ops.ACT_NONE]
+    g = lambda a: torch.as_tensor(a.astype(np.float32)).to(dev)
+    w_bfs, auxs = [], []
+    for l in range(L):
+        K, N = dims[l], dims[l + 1]
+        w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
+        wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
+        ops.weights_to_bf16(g(rng.normal(size=(K, N)) / math.sqrt(K)), w_bf, wt_bf)
+        w_bfs.append(w_bf)
+        auxs.append(ops.cast_pad_bf16(g(rng.normal(size=(M, N)))))  # stand-in layer outputs
+    g_out = g(rng.normal(size=(M, dims[-1])))
+    dz, g_in = ops.mlp_bwd_dx_bf16(g_out, None, ops.ACT_NONE, w_bfs, dims, acts, auxs, need_gin)
+    # per-layer reference
+    ref = [None] * L
+    ref[L - 1] = ops.cast_pad_bf16(g_out)
+    assert torch.equal(dz[L - 1], ref[L - 1])
+    for l in range(L - 1, 0, -1):
+        _, ref[l - 1] = ops.dense_bwd_dx_bf16(ref[l], w_bfs[l], auxs[l - 1], acts[l - 1], dims[l],
+                                              dims[l + 1], want_f32=False, want_bf=True)
+        a, b = dz[l - 1].float(), ref[l - 1].float()
+        assert torch.allclose(a, b, rtol=2 ** -7, atol=1e-6), l
+        assert float(dz[l - 1][:, dims[l]:].float().abs().sum()) == 0
+        assert (a != b).float().mean().item() < 0.02, l  # only rare 1-ulp differences
+    if need_gin:
+        want, _ = ops.dense_bwd_dx_bf16(ref[0], w_bfs[0], None, ops.ACT_NONE, dims[0], dims[1],
+                                        want_f32=True, want_bf=False)
+        assert torch.allclose(g_in, want, rtol=2e-2, atol=2e-2)
+    else:
+        assert g_in is None
