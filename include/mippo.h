@@ -164,10 +164,16 @@ int mi_cast_pad_bf16(const float* x, const void* aux_bf, int64_t ldaux, int act,
 int mi_weights_to_bf16(const float* w, void* w_bf, int64_t ldw, void* wt_bf, int64_t ldwt,
                        int64_t K, int64_t N, mi_stream_t stream);
 
-/* The same for up to 16 layers in one launch (ld = pad8 of N / K as above). */
+/* The same for up to 16 layers in one launch (ld = pad8 of N / K as above), plus
+ * (arrays nullable) the FRAGMENT-MAJOR images the whole-trunk kernels stream:
+ * frag_fwd[l] (ceil(N/16) * ceil(K/32) * 512 bf16; columns = outputs, reduce = K)
+ * and frag_bwd[l] (ceil(K/16) * ceil(N/32) * 512 bf16; columns = K, reduce = N).
+ * Block (ct, ks) of an image is the 64-lane MFMA 16x16x32 B-operand fragment of
+ * column tile ct, k-step ks (lane l: column ct*16 + (l & 15), reduce elements
+ * ks*32 + 8*(l >> 4) .. +7), so a wave reads it as one contiguous 1 KiB. */
 int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w, void* const* w_bf,
-                             void* const* wt_bf, const int64_t* K, const int64_t* N,
-                             mi_stream_t stream);
+                             void* const* wt_bf, void* const* frag_fwd, void* const* frag_bwd,
+                             const int64_t* K, const int64_t* N, mi_stream_t stream);
 
 /* y = act(x @ w + bias) (`feedforward.py:42-51`).  Outputs (each nullable, at
  * least one of y_f32 / y_bf): y_f32 [M][N], y_bf [M][ldy], preact_bf [M][ldy]
@@ -206,7 +212,7 @@ int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf, const void*
                                  mi_stream_t stream);
 
 /* A whole MLP trunk (L <= 8 Dense layers, widths <= 512) in ONE launch; only
- * weights stream (bf16 W^T shadows, `wt_bf[l]` = [N_l][pad8 K_l]).
+ * weights stream (`wt_bf[l]` = the frag_fwd image of layer l, mi_weights_to_bf16_multi).
  * dims[L+1] = (K_0, N_0 = K_1, ..., N_{L-1}); acts[L]; bias[l] nullable.
  * out: fp32 [M][N_{L-1}].  A workgroup walks 16 (M <= 8192) or 64 rows through
  * every layer with the activations resident in LDS, output columns split over
@@ -223,8 +229,8 @@ int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_
  * act_last != MI_ACT_NONE) it produces dz_last [M][pad8 N_{L-1}] (bf16) and, walking
  * the layers backwards, dz_bf[l-1] = (dz_l . W_l^T) (.) act'_{l-1}(aux[l-1]) for
  * l = L-1..1 (each [M][pad8 K_l], bf16) — every operand the grouped dW launch
- * needs — and optionally the fp32 input gradient g_in [M][K_0].  w_bf[l] = bf16 W_l
- * [K_l][pad8 N_l]; aux[l] = layer l's output (pre-activation for swish);
+ * needs — and optionally the fp32 input gradient g_in [M][K_0].  w_bf[l] = the
+ * frag_bwd image of layer l; aux[l] = layer l's output (pre-activation for swish);
  * acts[l] as in the forward.  dz_bf has L-1 entries, aux L-1 entries. */
 int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int act_last, int64_t M,
                        int64_t L, const void* const* w_bf, const int64_t* dims,

@@ -406,28 +406,58 @@ weights_to_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, int
 
 struct WLeaf {
   const float* w;
-  bf16_t* wb;
-  bf16_t* wt;
+  bf16_t* wb;   // [K][ldw]  row-major W (dX operand of the per-layer kernel)
+  bf16_t* wt;   // [N][ldwt] row-major W^T (forward operand of the per-layer kernel)
+  bf16_t* ff;   // forward fragment-major image (whole-trunk kernels), or null
+  bf16_t* fb;   // backward fragment-major image, or null
   int64_t K, N, ldw, ldwt;
 };
 struct WTable {
   WLeaf leaf[16];
 };
 
+// Fragment-major image of an [R x C] "NT" operand (C output columns, R reduce
+// elements): block (ct, ks) holds, for lane l of a wave, the 8 bf16 of column
+// ct*16 + (l & 15), reduce elements ks*32 + 8*(l >> 4) .. +7 — i.e. exactly the
+// MFMA 16x16x32 B-operand fragment — so a wave-wide fragment load is ONE
+// contiguous 1 KiB read instead of 16 strided 64-byte segments.
+__device__ inline void frag_store(bf16_t* dst, int64_t idx, int64_t C, int64_t R,
+                                  const float* w, int64_t N, bool transposed_src) {
+  // idx -> (ct, ks, lane, e)
+  const int e = (int)(idx & 7);
+  const int lane = (int)((idx >> 3) & 63);
+  const int64_t blk = idx >> 9;
+  const int64_t KS = (R + 31) / 32;
+  const int64_t ks = blk % KS, ct = blk / KS;
+  const int64_t c = ct * 16 + (lane & 15);
+  const int64_t r = ks * 32 + 8 * (lane >> 4) + e;
+  float v = 0.0f;
+  if (c < C && r < R) v = transposed_src ? w[r * N + c] : w[c * N + r];
+  dst[idx] = (bf16_t)v;
+}
+
 // all layers of a network in one launch (blockIdx.y = layer)
 __global__ void __launch_bounds__(kThreads)
 weights_to_bf16_multi_kernel(WTable tab) {
   const WLeaf lf = tab.leaf[blockIdx.y];
   const int64_t n1 = lf.K * lf.ldw, n2 = lf.N * lf.ldwt;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n1 + n2;
+  // forward image: columns = N outputs, reduce = K; source W[k][n] -> (c = n, r = k)
+  const int64_t n3 = lf.ff ? ((lf.N + 15) / 16) * ((lf.K + 31) / 32) * 512 : 0;
+  // backward image: columns = K outputs, reduce = N; source W[k][n] -> (c = k, r = n)
+  const int64_t n4 = lf.fb ? ((lf.K + 15) / 16) * ((lf.N + 31) / 32) * 512 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n1 + n2 + n3 + n4;
        i += (int64_t)gridDim.x * kThreads) {
     if (i < n1) {
       const int64_t k = i / lf.ldw, n = i % lf.ldw;
       lf.wb[i] = (bf16_t)(n < lf.N ? lf.w[k * lf.N + n] : 0.0f);
-    } else {
+    } else if (i < n1 + n2) {
       const int64_t q = i - n1;
       const int64_t n = q / lf.ldwt, k = q % lf.ldwt;
       lf.wt[q] = (bf16_t)(k < lf.K ? lf.w[k * lf.N + n] : 0.0f);
+    } else if (i < n1 + n2 + n3) {
+      frag_store(lf.ff, i - n1 - n2, lf.N, lf.K, lf.w, lf.N, true);
+    } else {
+      frag_store(lf.fb, i - n1 - n2 - n3, lf.K, lf.N, lf.w, lf.N, false);
     }
   }
 }
@@ -663,8 +693,9 @@ extern "C" int mi_dense_bwd_dw_bf16(const void* x_bf, int64_t ldx, const void* d
 }
 
 extern "C" int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w, void* const* w_bf,
-                                        void* const* wt_bf, const int64_t* K, const int64_t* N,
-                                        mi_stream_t stream) {
+                                        void* const* wt_bf, void* const* frag_fwd,
+                                        void* const* frag_bwd, const int64_t* K,
+                                        const int64_t* N, mi_stream_t stream) {
   MI_REQUIRE(n_layers >= 0 && n_layers <= 16, "mi_weights_to_bf16_multi: 0 <= n_layers <= 16");
   if (n_layers == 0) return 0;
   MI_REQUIRE(w && w_bf && wt_bf && K && N, "mi_weights_to_bf16_multi: null pointer");
@@ -677,11 +708,15 @@ extern "C" int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w,
     lf.w = w[l];
     lf.wb = static_cast<bf16_t*>(w_bf[l]);
     lf.wt = static_cast<bf16_t*>(wt_bf[l]);
+    lf.ff = frag_fwd ? static_cast<bf16_t*>(frag_fwd[l]) : nullptr;
+    lf.fb = frag_bwd ? static_cast<bf16_t*>(frag_bwd[l]) : nullptr;
     lf.K = K[l];
     lf.N = N[l];
     lf.ldw = mippo::ceil_div(N[l], 8) * 8;
     lf.ldwt = mippo::ceil_div(K[l], 8) * 8;
-    const int64_t tot = lf.K * lf.ldw + lf.N * lf.ldwt;
+    int64_t tot = lf.K * lf.ldw + lf.N * lf.ldwt;
+    if (lf.ff) tot += mippo::ceil_div(N[l], 16) * mippo::ceil_div(K[l], 32) * 512;
+    if (lf.fb) tot += mippo::ceil_div(K[l], 16) * mippo::ceil_div(N[l], 32) * 512;
     if (tot > max_total) max_total = tot;
   }
   dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_layers);

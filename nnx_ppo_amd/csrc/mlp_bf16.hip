@@ -29,12 +29,13 @@ constexpr int CH_MAXL = 8;
 constexpr int IF_KC = 128;  // reduce elements per pipeline step (4 MFMA k-steps)
 
 struct ChainLayer {
-  const bf16_t* w;      // streamed operand [N][ldw] (forward: W^T, backward: W), reduce-contiguous
+  const bf16_t* w;      // streamed operand, FRAGMENT-MAJOR (gemm_bf16.hip: frag_store):
+                        // block (ct, ks) = the 64-lane MFMA B fragment of column tile ct, k-step ks
   const float* bias;    // forward: [N] or null
   bf16_t* out_bf;       // [M][ldo] bf16 image of this layer's output, or null
   bf16_t* pre_bf;       // forward/swish: pre-activation [M][ldo], or null
   const bf16_t* aux;    // backward: tensor act' is evaluated on, [M][ldo], or null
-  int64_t ldw, ldo;
+  int64_t ldo;
   int K, N, act;        // reduce width, output width, activation (fwd) / act' kind (bwd)
 };
 struct Chain {
@@ -89,15 +90,18 @@ mlp_chain_kernel(Chain c) {
   // column tile b of this wave in pass p starts at column ((p*4 + b)*4 + wave) * 16
   auto load_frags = [&](const IStep& s, BFrags& B) {
     const ChainLayer& ly = c.layer[s.l];
+    const int KS = (ly.K + 31) / 32;        // k-steps of this layer
+    const int NT = (ly.N + 15) / 16;        // column tiles of this layer
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int col = ((s.p * 4 + b) * 4 + wave) * 16 + (lane & 15);
+      const int ct = (s.p * 4 + b) * 4 + wave;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int k = s.kc + ks * 32 + 8 * (lane >> 4);
+        const int kg = s.kc / 32 + ks;
         u32x4 r = u32x4{0u, 0u, 0u, 0u};
-        if (col < ly.N && k < ly.ldw)
-          r = *reinterpret_cast<const u32x4*>(ly.w + (int64_t)col * ly.ldw + k);
+        // one contiguous 1 KiB per wave-instruction (the image is zero padded)
+        if (ct < NT && kg < KS)
+          r = *reinterpret_cast<const u32x4*>(ly.w + (((int64_t)ct * KS + kg) * 64 + lane) * 8);
         B.f[ks][b] = __builtin_bit_cast(bf16x8, r);
       }
     }
@@ -281,7 +285,6 @@ extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void*
     MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "mi_mlp_fwd_bf16: weights must be 16-byte aligned");
     ChainLayer& ly = c.layer[l];
     ly.w = static_cast<const bf16_t*>(wt_bf[l]);
-    ly.ldw = mippo::ceil_div(K, 8) * 8;
     ly.bias = bias ? bias[l] : nullptr;
     ly.K = (int)K;
     ly.N = (int)N;
@@ -330,7 +333,6 @@ extern "C" int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int 
     MI_REQUIRE(w_bf[l] && al16(w_bf[l]), "mi_mlp_bwd_dx_bf16: weights must be 16-byte aligned");
     ChainLayer& ly = c.layer[q];
     ly.w = static_cast<const bf16_t*>(w_bf[l]);
-    ly.ldw = mippo::ceil_div(N, 8) * 8;
     ly.K = (int)N;
     ly.N = (int)K;
     ly.ldo = mippo::ceil_div(K, 8) * 8;

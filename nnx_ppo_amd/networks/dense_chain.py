@@ -41,8 +41,12 @@ def refresh(layers) -> None:
         if getattr(l, "_w_bf", None) is None or l._w_bf.device != w.device:
             l._w_bf = torch.zeros(K, ops.pad8(N), dtype=torch.bfloat16, device=w.device)
             l._wt_bf = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=w.device)
+            nf, nb = ops.frag_sizes(K, N)
+            l._ff = torch.zeros(nf, dtype=torch.bfloat16, device=w.device)
+            l._fb = torch.zeros(nb, dtype=torch.bfloat16, device=w.device)
     ops.weights_to_bf16_multi([l.kernel.data for l in stale], [l._w_bf for l in stale],
-                              [l._wt_bf for l in stale])
+                              [l._wt_bf for l in stale], [l._ff for l in stale],
+                              [l._fb for l in stale])
     for l in stale:
         l._shadow_epoch = param_epoch()
 
@@ -71,7 +75,7 @@ def _fusable(layers, M: int) -> bool:
 
 def _chain_args(layers):
     refresh(layers)
-    wts = [_shadows(l)[1] for l in layers]
+    wts = [l._ff for l in layers]  # forward fragment-major images
     biases = [_bias(l) for l in layers]
     dims = [layers[0].in_features] + [l.out_features for l in layers]
     acts = [l.act_code for l in layers]
@@ -134,9 +138,10 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     grads = [(l.kernel.grad, l.bias.grad if l.bias is not None else None) for l in layers]
     if _fusable(layers, M) and (L > 1 or need_input_grad):
         dims = [layers[0].in_features] + [l.out_features for l in layers]
+        refresh(layers)
         dz, g_in = ops.mlp_bwd_dx_bf16(
             g_out2, saved[-1][1] if last.act_code != ops.ACT_NONE else None, last.act_code,
-            [sv[2] for sv in saved], dims, [l.act_code for l in layers],
+            [l._fb for l in layers], dims, [l.act_code for l in layers],
             [sv[1] for sv in saved], need_input_grad)
         ops.dense_bwd_dw_grouped_bf16(
             [(saved[i][0], dz[i], grads[i][0], grads[i][1]) for i in range(L - 1, -1, -1)],

@@ -262,16 +262,24 @@ def weights_to_bf16(w: torch.Tensor, w_bf: torch.Tensor, wt_bf: torch.Tensor) ->
                                    wt_bf.shape[1], K, N, stream()), "mi_weights_to_bf16")
 
 
-def weights_to_bf16_multi(ws: list, w_bfs: list, wt_bfs: list) -> None:
-    """Refresh the bf16 shadows of up to 16 layers per launch."""
+def frag_sizes(K: int, N: int):
+    """Element counts of the (forward, backward) fragment-major images of a [K, N] layer."""
+    return (((N + 15) // 16) * ((K + 31) // 32) * 512, ((K + 15) // 16) * ((N + 31) // 32) * 512)
+
+
+def weights_to_bf16_multi(ws: list, w_bfs: list, wt_bfs: list, ffs=None, fbs=None) -> None:
+    """Refresh the bf16 shadows (row-major W, W^T and, if given, the two
+    fragment-major images) of up to 16 layers per launch."""
     for i in range(0, len(ws), 16):
         w, wb, wt = ws[i:i + 16], w_bfs[i:i + 16], wt_bfs[i:i + 16]
         n = len(w)
         P = ctypes.c_void_p * n
         I = ctypes.c_int64 * n
+        ff = P(*[ptr(t, bf16) for t in ffs[i:i + 16]]) if ffs is not None else None
+        fb = P(*[ptr(t, bf16) for t in fbs[i:i + 16]]) if fbs is not None else None
         check(lib().mi_weights_to_bf16_multi(
             n, P(*[ptr(t, f32) for t in w]), P(*[ptr(t, bf16) for t in wb]),
-            P(*[ptr(t, bf16) for t in wt]), I(*[t.shape[0] for t in w]),
+            P(*[ptr(t, bf16) for t in wt]), ff, fb, I(*[t.shape[0] for t in w]),
             I(*[t.shape[1] for t in w]), stream()), "mi_weights_to_bf16_multi")
 
 

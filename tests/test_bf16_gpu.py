@@ -118,6 +118,39 @@ def test_cast_pad_with_activation_derivative(dev):
     assert torch.equal(dz[:, :F], want) and float(dz[:, F:].float().abs().sum()) == 0
 
 
+def _shadows4(ops, w, dev):
+    """(row-major W, row-major W^T, forward fragment image, backward fragment image)."""
+    K, N = w.shape
+    w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
+    wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
+    nf, nb = ops.frag_sizes(K, N)
+    ff = torch.zeros(nf, dtype=BF, device=dev)
+    fb = torch.zeros(nb, dtype=BF, device=dev)
+    ops.weights_to_bf16_multi([w], [w_bf], [wt_bf], [ff], [fb])
+    return w_bf, wt_bf, ff, fb
+
+
+def test_fragment_major_images(dev):
+    """Block (ct, ks) of an image = the 64-lane MFMA B fragment: lane l holds
+    column ct*16 + (l & 15), reduce elements ks*32 + 8*(l >> 4) .. +7."""
+    from nnx_ppo_amd import ops
+
+    K, N = 70, 37
+    w = torch.arange(K * N, dtype=torch.float32, device=dev).reshape(K, N) % 211 - 100
+    w_bf, wt_bf, ff, fb = _shadows4(ops, w, dev)
+    wb = w.to(BF)
+    assert torch.equal(w_bf[:, :N], wb) and torch.equal(wt_bf[:, :K], wb.t())
+
+    def defrag(img, C, R):
+        NT, KS = (C + 15) // 16, (R + 31) // 32
+        t = img.view(NT, KS, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(NT * 16, KS * 32)
+        assert float(t[C:].float().abs().sum()) == 0 and float(t[:, R:].float().abs().sum()) == 0
+        return t[:C, :R]
+
+    assert torch.equal(defrag(ff, N, K), wb.t())  # forward: columns = outputs n, reduce = k
+    assert torch.equal(defrag(fb, K, N), wb)      # backward: columns = k, reduce = n
+
+
 def _make(obs, act, ah, ch, activation="relu", seed=17):
     from nnx_ppo_amd.networks import factories
     from nnx_ppo_amd.networks.types import Rngs
@@ -207,18 +240,16 @@ def test_fused_mlp_forward_matches_per_layer_path(dev, dims, M, act):
     code = ops.ACT_CODES[act]
     acts = [code] * (L - 1) + [ops.ACT_NONE]
     x = torch.as_tensor(rng.normal(size=(M, dims[0])).astype(np.float32)).to(dev)
-    wts, wbs, biases = [], [], []
+    wts, ffs, biases = [], [], []
     for l in range(L):
         K, N = dims[l], dims[l + 1]
         w = torch.as_tensor((rng.normal(size=(K, N)) / math.sqrt(K)).astype(np.float32)).to(dev)
-        w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
-        wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
-        ops.weights_to_bf16(w, w_bf, wt_bf)
+        _, wt_bf, ff, _ = _shadows4(ops, w, dev)
         wts.append(wt_bf)
-        wbs.append(w_bf)
+        ffs.append(ff)
         biases.append(torch.as_tensor(rng.normal(size=N).astype(np.float32)).to(dev))
-    out, saved = ops.mlp_fwd_bf16(x, wts, biases, dims, acts, train=True)
-    out_i, none = ops.mlp_fwd_bf16(x, wts, biases, dims, acts, train=False)
+    out, saved = ops.mlp_fwd_bf16(x, ffs, biases, dims, acts, train=True)
+    out_i, none = ops.mlp_fwd_bf16(x, ffs, biases, dims, acts, train=False)
     assert none is None and torch.allclose(out, out_i, rtol=1e-5, atol=1e-5)
     # per-layer reference path
     x_bf = ops.cast_pad_bf16(x)
@@ -282,16 +313,15 @@ def test_fused_mlp_backward_matches_per_layer_path(dev, dims, M, act, need_gin):
     code = ops.ACT_CODES[act]
     acts = [code] * (L - 1) + [ops.ACT_NONE]
     g = lambda a: torch.as_tensor(a.astype(np.float32)).to(dev)
-    w_bfs, auxs = [], []
+    w_bfs, fbs, auxs = [], [], []
     for l in range(L):
         K, N = dims[l], dims[l + 1]
-        w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
-        wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
-        ops.weights_to_bf16(g(rng.normal(size=(K, N)) / math.sqrt(K)), w_bf, wt_bf)
+        w_bf, _, _, fb = _shadows4(ops, g(rng.normal(size=(K, N)) / math.sqrt(K)), dev)
         w_bfs.append(w_bf)
+        fbs.append(fb)
         auxs.append(ops.cast_pad_bf16(g(rng.normal(size=(M, N)))))  # stand-in layer outputs
     g_out = g(rng.normal(size=(M, dims[-1])))
-    dz, g_in = ops.mlp_bwd_dx_bf16(g_out, None, ops.ACT_NONE, w_bfs, dims, acts, auxs, need_gin)
+    dz, g_in = ops.mlp_bwd_dx_bf16(g_out, None, ops.ACT_NONE, fbs, dims, acts, auxs, need_gin)
     # per-layer reference
     ref = [None] * L
     ref[L - 1] = ops.cast_pad_bf16(g_out)
