@@ -19,6 +19,8 @@
 // Backward: the same walk over the transposed problem: dz_{l-1} = (dz_l . W_l^T)
 //           (.) act'_{l-1}(y_{l-1}), with the y_{l-1} tile staged through LDS; every
 //           dz_l is copied out (bf16) for the grouped dW launch.
+#include <type_traits>
+
 #include "bf16_common.h"
 
 namespace {
@@ -79,7 +81,8 @@ mlp_chain_kernel(Chain c) {
   constexpr int ROWS = 16 * RT;
   constexpr int AROW = MAXW + 8;
   __shared__ __attribute__((aligned(16))) bf16_t act[2][ROWS][AROW];
-  __shared__ __attribute__((aligned(16))) bf16_t auxs[BWD ? ROWS : 1][BWD ? AROW : 8];
+  // backward: act' operand of the layer output; forward: pre-activations (swish)
+  __shared__ __attribute__((aligned(16))) bf16_t auxs[ROWS][AROW];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -130,8 +133,6 @@ mlp_chain_kernel(Chain c) {
   };
 
   IStep s = {0, 0, 0};
-  BFrags Ba, Bb;
-  load_frags(s, Ba);
 
   // stage 0: fp32 input tile (x act'(aux0) in the backward) -> bf16, zero padded
   for (int i = tid; i < ROWS * K0p; i += kThreads) {
@@ -146,14 +147,71 @@ mlp_chain_kernel(Chain c) {
   if (c.x_bf) flush(act[0], c.x_bf, c.ldx);
 
   f32x4 acc[RT][4];
-  auto run_step = [&](const IStep& st, const BFrags& B, BFrags& Bnext) {
+  // Unrolled epilogue of one column pass.  TRANS selects, at compile time, the
+  // variant with transcendentals (tanh / swish) so that the common relu / none
+  // variant stays a handful of VALU ops per element; the kernel keeps exactly ONE
+  // instance of the step body (the two weight-fragment register sets are swapped by
+  // register moves) — fully unrolled epilogues in several instances overflowed the
+  // instruction cache and ran 5x slower than their MFMA + memory time.
+  auto epilogue = [&](const IStep& st, auto trans_tag) {
+    constexpr bool TRANS = decltype(trans_tag)::value;
+    const ChainLayer& ly = c.layer[st.l];
+    const int nxt = (st.l & 1) ^ 1;
+    const bool last = st.l == c.L - 1;
+    const bool keep = !last || ly.out_bf;
+    const bool to_out = last && c.out;
+    const bool stage_pre = !BWD && TRANS && ly.pre_bf;
+    const bool use_aux = BWD && ly.aux && ly.act != MI_ACT_NONE;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = ((st.p * 4 + b) * 4 + wave) * 16 + (lane & 15);
+      if (j < ly.N) {
+        const float bj = (!BWD && ly.bias) ? ly.bias[j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const int row0 = r * 16 + 4 * (lane >> 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[r][b][e];
+            if constexpr (BWD) {
+              if (use_aux) {
+                const float a = (float)auxs[row0 + e][j];
+                if constexpr (TRANS) {  // swish: aux is the pre-activation
+                  const float sg = fast_sigmoid(a);
+                  v *= sg * (1.0f + a * (1.0f - sg));
+                } else {
+                  v *= ly.act == MI_ACT_RELU ? (a > 0.0f ? 1.0f : 0.0f) : 1.0f - a * a;
+                }
+              }
+            } else {
+              const float z = v + bj;
+              if constexpr (TRANS) {
+                const float sg = fast_sigmoid(ly.act == MI_ACT_TANH ? 2.0f * z : z);
+                v = ly.act == MI_ACT_TANH ? 2.0f * sg - 1.0f : z * sg;
+                if (stage_pre) auxs[row0 + e][j] = (bf16_t)z;
+              } else {
+                v = ly.act == MI_ACT_RELU ? fmaxf(z, 0.0f) : z;
+              }
+            }
+            if (keep) act[nxt][row0 + e][j] = (bf16_t)v;
+            if (to_out && i0 + row0 + e < c.M) c.out[(i0 + row0 + e) * ly.N + j] = v;
+          }
+        }
+      }
+    }
+  };
+
+  BFrags B, Bn;
+  load_frags(s, B);
+  while (s.l < c.L) {
+    const IStep st = s;
     const ChainLayer& ly = c.layer[st.l];
     const int Kp = (ly.K + 31) / 32 * 32;
     const int cur = st.l & 1, nxt = cur ^ 1;
     const bool last = st.l == c.L - 1;
     const bool keep = !last || ly.out_bf;  // does act[nxt] have a reader?
     const IStep sn = istep_next(c, st);
-    if (sn.l < c.L) load_frags(sn, Bnext);
+    if (sn.l < c.L) load_frags(sn, Bn);
     if constexpr (BWD) {
       if (st.p == 0 && st.kc == 0 && ly.aux && ly.act != MI_ACT_NONE) {
         // stage the act' operand of this layer's output; published by the barrier below
@@ -187,51 +245,37 @@ mlp_chain_kernel(Chain c) {
       }
     }
     if (st.kc + IF_KC >= Kp) {  // this wave's columns of this pass are complete
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = ((st.p * 4 + b) * 4 + wave) * 16 + (lane & 15);
-        if (j < ly.N) {
-          const float bj = (!BWD && ly.bias) ? ly.bias[j] : 0.0f;
-#pragma unroll
-          for (int r = 0; r < RT; ++r) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int row = r * 16 + 4 * (lane >> 4) + e;
-              const int64_t gi = i0 + row;
-              float v = acc[r][b][e];
-              if constexpr (BWD) {
-                if (ly.aux && ly.act != MI_ACT_NONE) v *= act_grad((float)auxs[row][j], ly.act);
-              } else {
-                const float z = v + bj;
-                v = act_fwd(z, ly.act);
-                if (ly.pre_bf && gi < c.M) ly.pre_bf[gi * ly.ldo + j] = (bf16_t)z;
-              }
-              if (keep) act[nxt][row][j] = (bf16_t)v;
-              if (last && c.out && gi < c.M) c.out[gi * ly.N + j] = v;
-            }
-          }
-        }
+      const bool trans = BWD ? ly.act == MI_ACT_SWISH : ly.act >= MI_ACT_TANH;
+      if (trans) {
+        epilogue(st, std::true_type{});
+      } else {
+        epilogue(st, std::false_type{});
       }
       if (sn.l != st.l) {  // layer finished: zero the pad columns, publish, copy out
+        const bool stage_pre = !BWD && ly.pre_bf && ly.act >= MI_ACT_TANH;
         if (keep) {
           const int Np = (ly.N + 31) / 32 * 32;
           if (Np != ly.N) {
-            for (int i = tid; i < ROWS * (Np - ly.N); i += kThreads)
+            for (int i = tid; i < ROWS * (Np - ly.N); i += kThreads) {
               act[nxt][i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
+              if (stage_pre) auxs[i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
+            }
           }
         }
         __syncthreads();
         if (ly.out_bf) flush(act[nxt], ly.out_bf, ly.ldo);
+        if (stage_pre) {
+          flush(auxs, ly.pre_bf, ly.ldo);
+          __syncthreads();  // the next swish layer overwrites auxs
+        }
       }
     }
-  };
-
-  while (s.l < c.L) {
-    run_step(s, Ba, Bb);
-    s = istep_next(c, s);
-    if (s.l >= c.L) break;
-    run_step(s, Bb, Ba);
-    s = istep_next(c, s);
+    // hand the prefetched fragments to the next step (register moves)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
+    s = sn;
   }
 }
 
