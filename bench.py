@@ -49,6 +49,7 @@ GEMM_SYMBOLS = {
     "mi_dense_bwd_dx_bf16": lambda a: (a[5], a[6], a[7]),   # lddz ldw ldprev act ldgx M K N
     "mi_dense_bwd_dw_bf16": lambda a: (a[2], a[3], a[4]),   # ldx lddz M K N acc
     "mi_mlp_fwd_bf16": None,                                # flops annotated by the wrapper
+    "mi_mlp_bwd_dx_bf16": None,
     "mi_dense_bwd_dw_grouped_bf16": None,
 }
 

@@ -5,20 +5,29 @@
 // per-layer kernels are bound by launch latency and by the HBM round trip of
 // every intermediate activation, not by MFMA rate.  Here a workgroup owns
 // 16*RT rows (envs / samples) and walks them through every layer:
-//   * activations ping-pong between two LDS buffers and never leave the CU;
+//   * activations ping-pong between two LDS buffers and never leave the CU; the
+//     buffers are sized to the trunk's real width (dynamic LDS), so narrow trunks
+//     keep many workgroups resident per CU;
 //   * each layer's OUTPUT COLUMNS are split over the 4 waves, so a wave's weight
 //     fragments are used by its own MFMAs only and go global -> VGPR directly
 //     (no LDS staging, no per-k-tile barrier); weights do not depend on
 //     activations, so the next chunk's fragments — across layer boundaries too —
 //     are in flight while the current chunk computes; ONE barrier per layer;
+//   * the MFMA computes the TRANSPOSED tile (weights as the A operand, activations
+//     as B): a lane then holds 4 CONSECUTIVE output columns of one row, so the
+//     epilogue moves 8-byte vectors (LDS store, act' operand load, swish
+//     pre-activation store) instead of 2-byte scalars;
 //   * RT row tiles per workgroup reuse every weight fragment RT times: RT = 1
-//     fills the chip at rollout sizes (M = 1k..8k rows), RT = 4 amortises the
-//     weight stream at training sizes (M = T * minibatch = 30 720).
+//     fills the chip at rollout sizes (M = 1k..8k rows), RT = 4 at training sizes
+//     (M = T * minibatch = 30 720) — measured in tools/microbench_trunk.py.
 // Forward:  v = act(acc + bias); training also copies each layer's output (and the
 //           bf16 input) out of LDS in coalesced 16-byte rows for the backward.
 // Backward: the same walk over the transposed problem: dz_{l-1} = (dz_l . W_l^T)
-//           (.) act'_{l-1}(y_{l-1}), with the y_{l-1} tile staged through LDS; every
-//           dz_l is copied out (bf16) for the grouped dW launch.
+//           (.) act'_{l-1}(y_{l-1}); the y_{l-1} values a lane needs are loaded
+//           global -> VGPR before the layer's last MFMAs; every dz_l is copied out
+//           (bf16) for the grouped dW launch.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "bf16_common.h"
@@ -28,11 +37,12 @@ namespace {
 using namespace mippo_bf16;
 
 constexpr int CH_MAXL = 8;
-constexpr int IF_KC = 128;  // reduce elements per pipeline step (4 MFMA k-steps)
+constexpr int IF_KC = 64;  // reduce elements per pipeline step (2 MFMA k-steps)
+constexpr int IF_KS = IF_KC / 32;
 
 struct ChainLayer {
   const bf16_t* w;      // streamed operand, FRAGMENT-MAJOR (gemm_bf16.hip: frag_store):
-                        // block (ct, ks) = the 64-lane MFMA B fragment of column tile ct, k-step ks
+                        // block (ct, ks) = the 64-lane MFMA fragment of column tile ct, k-step ks
   const float* bias;    // forward: [N] or null
   bf16_t* out_bf;       // [M][ldo] bf16 image of this layer's output, or null
   bf16_t* pre_bf;       // forward/swish: pre-activation [M][ldo], or null
@@ -51,6 +61,7 @@ struct Chain {
   int64_t ldx;
   int64_t M;
   int L;
+  int arow;             // LDS row length in bf16: widest (32-rounded) layer + 8
 };
 
 struct IStep {
@@ -72,20 +83,21 @@ __device__ inline IStep istep_next(const Chain& c, IStep s) {
 }
 
 struct BFrags {
-  bf16x8 f[4][4];  // [k-step][column tile]
+  bf16x8 f[IF_KS][4];  // [k-step][column tile]
 };
 
-template <int MAXW, int RT, bool BWD>
+template <int RT, bool BWD>
 __global__ void __launch_bounds__(kThreads)
 mlp_chain_kernel(Chain c) {
   constexpr int ROWS = 16 * RT;
-  constexpr int AROW = MAXW + 8;
-  __shared__ __attribute__((aligned(16))) bf16_t act[2][ROWS][AROW];
-  // backward: act' operand of the layer output; forward: pre-activations (swish)
-  __shared__ __attribute__((aligned(16))) bf16_t auxs[ROWS][AROW];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int arow = c.arow;
+  bf16_t* const act0 = reinterpret_cast<bf16_t*>(lds_raw);
+  bf16_t* const act1 = act0 + ROWS * arow;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
   const int64_t i0 = (int64_t)blockIdx.x * ROWS;
   const int K0 = c.layer[0].K;
   const int K0p = (K0 + 31) / 32 * 32;
@@ -99,7 +111,7 @@ mlp_chain_kernel(Chain c) {
     for (int b = 0; b < 4; ++b) {
       const int ct = (s.p * 4 + b) * 4 + wave;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < IF_KS; ++ks) {
         const int kg = s.kc / 32 + ks;
         u32x4 r = u32x4{0u, 0u, 0u, 0u};
         // one contiguous 1 KiB per wave-instruction (the image is zero padded)
@@ -110,29 +122,20 @@ mlp_chain_kernel(Chain c) {
     }
   };
   // coalesced copy of a published LDS buffer (rows x ld columns) to global
-  auto flush = [&](const bf16_t (*buf)[AROW], bf16_t* dst, int64_t ld) {
+  auto flush = [&](const bf16_t* buf, bf16_t* dst, int64_t ld) {
     const int nch = (int)(ld / 8);
     for (int cidx = tid; cidx < ROWS * nch; cidx += kThreads) {
       const int row = cidx / nch, cc = cidx % nch;
       const int64_t gi = i0 + row;
       if (gi < c.M)
         *reinterpret_cast<u32x4*>(dst + gi * ld + cc * 8) =
-            *reinterpret_cast<const u32x4*>(&buf[row][cc * 8]);
-    }
-  };
-  // coalesced load of a global bf16 tile (rows x ld columns) into an LDS buffer
-  auto fetch = [&](bf16_t (*buf)[AROW], const bf16_t* src, int64_t ld) {
-    const int nch = (int)(ld / 8);
-    for (int cidx = tid; cidx < ROWS * nch; cidx += kThreads) {
-      const int row = cidx / nch, cc = cidx % nch;
-      const int64_t gi = i0 + row;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (gi < c.M) v = *reinterpret_cast<const u32x4*>(src + gi * ld + cc * 8);
-      *reinterpret_cast<u32x4*>(&buf[row][cc * 8]) = v;
+            *reinterpret_cast<const u32x4*>(buf + row * arow + cc * 8);
     }
   };
 
   IStep s = {0, 0, 0};
+  BFrags B, Bn;
+  load_frags(s, B);
 
   // stage 0: fp32 input tile (x act'(aux0) in the backward) -> bf16, zero padded
   for (int i = tid; i < ROWS * K0p; i += kThreads) {
@@ -141,12 +144,13 @@ mlp_chain_kernel(Chain c) {
     float v = (gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f;
     if (BWD && c.aux0 && gi < c.M && k < K0)
       v *= act_grad((float)c.aux0[gi * c.ldaux0 + k], c.act0);
-    act[0][row][k] = (bf16_t)v;
+    act0[row * arow + k] = (bf16_t)v;
   }
   __syncthreads();
-  if (c.x_bf) flush(act[0], c.x_bf, c.ldx);
+  if (c.x_bf) flush(act0, c.x_bf, c.ldx);
 
-  f32x4 acc[RT][4];
+  f32x4 acc[RT][4];   // acc[r][b][e]: row r*16 + li, column tile b, column 4*lq + e
+  s16x4 auxr[RT][4];  // backward: the act' operands of the same elements
   // Unrolled epilogue of one column pass.  TRANS selects, at compile time, the
   // variant with transcendentals (tanh / swish) so that the common relu / none
   // variant stays a handful of VALU ops per element; the kernel keeps exactly ONE
@@ -156,26 +160,32 @@ mlp_chain_kernel(Chain c) {
   auto epilogue = [&](const IStep& st, auto trans_tag) {
     constexpr bool TRANS = decltype(trans_tag)::value;
     const ChainLayer& ly = c.layer[st.l];
-    const int nxt = (st.l & 1) ^ 1;
+    bf16_t* const nbuf = (st.l & 1) ? act0 : act1;
     const bool last = st.l == c.L - 1;
     const bool keep = !last || ly.out_bf;
     const bool to_out = last && c.out;
-    const bool stage_pre = !BWD && TRANS && ly.pre_bf;
+    const bool store_pre = !BWD && TRANS && ly.pre_bf;
     const bool use_aux = BWD && ly.aux && ly.act != MI_ACT_NONE;
+    const int Np = (ly.N + 31) / 32 * 32;  // the next layer reduces over Np columns
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int j = ((st.p * 4 + b) * 4 + wave) * 16 + (lane & 15);
-      if (j < ly.N) {
-        const float bj = (!BWD && ly.bias) ? ly.bias[j] : 0.0f;
+      const int j0 = ((st.p * 4 + b) * 4 + wave) * 16 + 4 * lq;
+      if (j0 < Np) {
+        float bj[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          bj[e] = (!BWD && ly.bias && j0 + e < ly.N) ? ly.bias[j0 + e] : 0.0f;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-          const int row0 = r * 16 + 4 * (lane >> 4);
+          const int row = r * 16 + li;
+          const int64_t gi = i0 + row;
+          bf16x4 vo, zo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[r][b][e];
             if constexpr (BWD) {
               if (use_aux) {
-                const float a = (float)auxs[row0 + e][j];
+                const float a = (float)__builtin_bit_cast(bf16x4, auxr[r][b])[e];
                 if constexpr (TRANS) {  // swish: aux is the pre-activation
                   const float sg = fast_sigmoid(a);
                   v *= sg * (1.0f + a * (1.0f - sg));
@@ -184,39 +194,53 @@ mlp_chain_kernel(Chain c) {
                 }
               }
             } else {
-              const float z = v + bj;
+              const float z = v + bj[e];
               if constexpr (TRANS) {
                 const float sg = fast_sigmoid(ly.act == MI_ACT_TANH ? 2.0f * z : z);
                 v = ly.act == MI_ACT_TANH ? 2.0f * sg - 1.0f : z * sg;
-                if (stage_pre) auxs[row0 + e][j] = (bf16_t)z;
+                zo[e] = (bf16_t)z;
               } else {
                 v = ly.act == MI_ACT_RELU ? fmaxf(z, 0.0f) : z;
               }
             }
-            if (keep) act[nxt][row0 + e][j] = (bf16_t)v;
-            if (to_out && i0 + row0 + e < c.M) c.out[(i0 + row0 + e) * ly.N + j] = v;
+            if (j0 + e >= ly.N) v = 0.0f;  // pad columns (weights are zero there)
+            vo[e] = (bf16_t)v;
+            if (to_out && gi < c.M && j0 + e < ly.N) c.out[gi * ly.N + j0 + e] = v;
+          }
+          if (keep) *reinterpret_cast<bf16x4*>(nbuf + row * arow + j0) = vo;
+          if constexpr (!BWD && TRANS) {
+            if (store_pre && gi < c.M && j0 < ly.ldo)
+              *reinterpret_cast<bf16x4*>(ly.pre_bf + gi * ly.ldo + j0) = zo;
           }
         }
       }
     }
   };
 
-  BFrags B, Bn;
-  load_frags(s, B);
   while (s.l < c.L) {
     const IStep st = s;
     const ChainLayer& ly = c.layer[st.l];
     const int Kp = (ly.K + 31) / 32 * 32;
-    const int cur = st.l & 1, nxt = cur ^ 1;
-    const bool last = st.l == c.L - 1;
-    const bool keep = !last || ly.out_bf;  // does act[nxt] have a reader?
+    const bf16_t* const cbuf = (st.l & 1) ? act1 : act0;
+    const bool pass_done = st.kc + IF_KC >= Kp;  // this step completes the wave's columns
     const IStep sn = istep_next(c, st);
     if (sn.l < c.L) load_frags(sn, Bn);
     if constexpr (BWD) {
-      if (st.p == 0 && st.kc == 0 && ly.aux && ly.act != MI_ACT_NONE) {
-        // stage the act' operand of this layer's output; published by the barrier below
-        fetch(auxs, ly.aux, ly.ldo);
-        __syncthreads();
+      if (pass_done && ly.aux && ly.act != MI_ACT_NONE) {
+        // act' operands of this pass: 8 bytes per (row, column tile), in flight
+        // during the MFMAs below
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int j0 = ((st.p * 4 + b) * 4 + wave) * 16 + 4 * lq;
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            const int64_t gi = i0 + r * 16 + li;
+            s16x4 a = s16x4{0, 0, 0, 0};
+            if (gi < c.M && j0 < ly.ldo)
+              a = *reinterpret_cast<const s16x4*>(ly.aux + gi * ly.ldo + j0);
+            auxr[r][b] = a;
+          }
+        }
       }
     }
     if (st.kc == 0) {
@@ -226,82 +250,72 @@ mlp_chain_kernel(Chain c) {
         for (int b = 0; b < 4; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < IF_KS; ++ks) {
       if (st.kc + ks * 32 < Kp) {
         bf16x8 af[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
-          af[r] = *reinterpret_cast<const bf16x8*>(
-              &act[cur][r * 16 + (lane & 15)][st.kc + ks * 32 + 8 * (lane >> 4)]);
+          af[r] = *reinterpret_cast<const bf16x8*>(cbuf + (r * 16 + li) * arow + st.kc +
+                                                   ks * 32 + 8 * lq);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           if (((st.p * 4 + b) * 4 + wave) * 16 < ly.N) {
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
-              acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r], B.f[ks][b], acc[r][b],
+            for (int r = 0; r < RT; ++r)  // transposed tile: weights are the A operand
+              acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][b], af[r], acc[r][b],
                                                                   0, 0, 0);
           }
         }
       }
     }
-    if (st.kc + IF_KC >= Kp) {  // this wave's columns of this pass are complete
+    if (pass_done) {
       const bool trans = BWD ? ly.act == MI_ACT_SWISH : ly.act >= MI_ACT_TANH;
       if (trans) {
         epilogue(st, std::true_type{});
       } else {
         epilogue(st, std::false_type{});
       }
-      if (sn.l != st.l) {  // layer finished: zero the pad columns, publish, copy out
-        const bool stage_pre = !BWD && ly.pre_bf && ly.act >= MI_ACT_TANH;
-        if (keep) {
-          const int Np = (ly.N + 31) / 32 * 32;
-          if (Np != ly.N) {
-            for (int i = tid; i < ROWS * (Np - ly.N); i += kThreads) {
-              act[nxt][i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
-              if (stage_pre) auxs[i / (Np - ly.N)][ly.N + i % (Np - ly.N)] = (bf16_t)0.0f;
-            }
-          }
-        }
+      if (sn.l != st.l) {  // layer finished: publish, copy out
         __syncthreads();
-        if (ly.out_bf) flush(act[nxt], ly.out_bf, ly.ldo);
-        if (stage_pre) {
-          flush(auxs, ly.pre_bf, ly.ldo);
-          __syncthreads();  // the next swish layer overwrites auxs
-        }
+        if (ly.out_bf) flush((st.l & 1) ? act0 : act1, ly.out_bf, ly.ldo);
       }
     }
     // hand the prefetched fragments to the next step (register moves)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < IF_KS; ++ks)
 #pragma unroll
       for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
     s = sn;
   }
 }
 
-template <bool BWD>
-int launch_chain(const Chain& c, int maxw, hipStream_t st) {
-  // RT = 1 fills the chip at rollout sizes; larger M reuses each weight fragment
-  // across 4 (2 for 512-wide trunks: LDS) row tiles
-  const bool small = c.M <= 8192;
-  if (maxw <= 256) {
-    if (small) {
-      hipLaunchKernelGGL((mlp_chain_kernel<256, 1, BWD>), dim3((unsigned)mippo::ceil_div(c.M, 16)),
-                         dim3(kThreads), 0, st, c);
-    } else {
-      hipLaunchKernelGGL((mlp_chain_kernel<256, 4, BWD>), dim3((unsigned)mippo::ceil_div(c.M, 64)),
-                         dim3(kThreads), 0, st, c);
-    }
-  } else {
-    if (small) {
-      hipLaunchKernelGGL((mlp_chain_kernel<512, 1, BWD>), dim3((unsigned)mippo::ceil_div(c.M, 16)),
-                         dim3(kThreads), 0, st, c);
-    } else {
-      hipLaunchKernelGGL((mlp_chain_kernel<512, 2, BWD>), dim3((unsigned)mippo::ceil_div(c.M, 32)),
-                         dim3(kThreads), 0, st, c);
-    }
-  }
+template <int RT, bool BWD>
+int launch_rt(const Chain& c, hipStream_t st) {
+  const size_t lds = (size_t)2 * 16 * RT * c.arow * sizeof(bf16_t);
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&mlp_chain_kernel<RT, BWD>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * RT * (512 + 8) * (int)sizeof(bf16_t));
+  MI_REQUIRE(attr == hipSuccess, "mlp_chain: cannot raise the dynamic LDS limit: %s",
+             hipGetErrorString(attr));
+  hipLaunchKernelGGL((mlp_chain_kernel<RT, BWD>), dim3((unsigned)mippo::ceil_div(c.M, 16 * RT)),
+                     dim3(kThreads), lds, st, c);
   return mippo::check_launch(BWD ? "mi_mlp_bwd_dx_bf16" : "mi_mlp_fwd_bf16");
+}
+
+template <bool BWD>
+int launch_chain(Chain& c, int maxw, hipStream_t st) {
+  c.arow = maxw + 8;
+  // RT = 1 fills the chip at rollout sizes; larger M reuses each weight fragment
+  // across 4 row tiles (2 for trunks wider than 256: LDS).  Measured with
+  // tools/microbench_trunk.py; MIPPO_TRUNK_RT=1|2|4 overrides (tuning aid).
+  static const int rt_override = [] {
+    const char* e = getenv("MIPPO_TRUNK_RT");
+    return e ? atoi(e) : 0;
+  }();
+  const int rt = rt_override ? rt_override : (c.M <= 8192 ? 1 : 4);
+  if (rt == 1) return launch_rt<1, BWD>(c, st);
+  if (rt == 4 && maxw <= 256) return launch_rt<4, BWD>(c, st);
+  return launch_rt<2, BWD>(c, st);
 }
 
 }  // namespace

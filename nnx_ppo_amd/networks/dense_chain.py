@@ -65,12 +65,17 @@ def _bias(layer):
 
 FUSED_MAX_LAYERS = 8
 FUSED_MAX_WIDTH = 512
+FUSED_WIDE_MAX_ROWS = 8192  # wider-than-256 trunks: whole-trunk kernel up to this M
 
 
 def _fusable(layers, M: int) -> bool:
-    """Whole-trunk kernels (csrc/mlp_bf16.hip) take up to 8 layers of width <= 512."""
-    return len(layers) <= FUSED_MAX_LAYERS and all(
-        l.in_features <= FUSED_MAX_WIDTH and l.out_features <= FUSED_MAX_WIDTH for l in layers)
+    """Whole-trunk kernels (csrc/mlp_bf16.hip) take up to 8 layers of width <= 512.
+    Trunks wider than 256 at training-size M go layer by layer: there the per-layer
+    GEMMs are no longer latency-bound and measure ~15% faster (tools/microbench_trunk.py)."""
+    width = max(max(l.in_features, l.out_features) for l in layers)
+    if len(layers) > FUSED_MAX_LAYERS or width > FUSED_MAX_WIDTH:
+        return False
+    return width <= 256 or M <= FUSED_WIDE_MAX_ROWS
 
 
 def _chain_args(layers):
