@@ -59,6 +59,18 @@ int mi_gae_f32(const float* rewards, const float* values,
                int64_t T, int64_t N, float gamma, float lambda,
                mi_stream_t stream);
 
+/* The same scan, also reducing adv_stats[3] = (sum A, sum A^2, T*N) in fp64 in
+ * the same launch — the operands of the advantage normalisation that follows
+ * (`ppo.py:477-480`; see mi_adv_stats_f32).  workspace:
+ * mi_gae_stats_workspace_bytes(N) bytes whose first 16 bytes (a ticket counter)
+ * are ZERO before the first call; the call leaves them zero. */
+int64_t mi_gae_stats_workspace_bytes(int64_t N);
+int mi_gae_stats_f32(const float* rewards, const float* values,
+                     const float* last_value, const uint8_t* done,
+                     const uint8_t* truncated, float* advantages, float* targets,
+                     int64_t T, int64_t N, float gamma, float lambda,
+                     double* adv_stats, void* workspace, mi_stream_t stream);
+
 /* ---- a8 / a16: running observation normaliser -------------------------- */
 
 /* Normalizer.__call__, `nnx_ppo/networks/normalizer.py:63-96`:
@@ -263,7 +275,9 @@ int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const float* h_prev
 /* ---- a14: loss terms ---------------------------------------------------- */
 
 /* Advantage statistics for `ppo.py:477-480`: stats[3] = (sum, sum of squares,
- * count) in fp64 — a multi-GPU run all-reduces this triple before the loss. */
+ * count) in fp64 — a multi-GPU run all-reduces this triple before the loss.
+ * workspace (both calls): mi_ppo_loss_workspace_bytes(n) bytes whose first 16
+ * bytes (a ticket counter) are ZERO before the first call; calls leave them zero. */
 int64_t mi_ppo_loss_workspace_bytes(int64_t n);
 int mi_adv_stats_f32(const float* adv, int64_t n, double* stats, void* workspace,
                      mi_stream_t stream);
@@ -332,9 +346,12 @@ int mi_gather_cols_multi(const void* const* src, void* const* dst, const int64_t
  * `jax.random.split`), 1 bits (int64), 2 randint in [minval, maxval) (int64,
  * `episode_wrapper.py:28-30`), 3 uniform [0,1) (fp32, 24 exact bits),
  * 4 zero-mean unit-variance uniform (fp32).  child_major != 0 lays the output out
- * as [m][n] (each child set contiguous) instead of [n][m]. */
-int mi_key_expand(const int64_t* keys, void* out, int64_t n, int64_t m, int mode,
-                  int64_t minval, int64_t maxval, int child_major, mi_stream_t stream);
+ * as [m][n] (each child set contiguous) instead of [n][m].  fold (nullable,
+ * int64[n]): expand mi_key_fold(keys, fold) instead of keys, in the same launch
+ * (`test_dummies/mock_env.py:41-52` folds the step count into the obs key). */
+int mi_key_expand(const int64_t* keys, const int64_t* fold, void* out, int64_t n, int64_t m,
+                  int mode, int64_t minval, int64_t maxval, int child_major,
+                  mi_stream_t stream);
 
 /* out[i] = mix(a[i] ^ mix(b[i] + GOLDEN)): fold a per-env integer into a key. */
 int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int64_t n,
@@ -343,10 +360,12 @@ int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int64_t n,
 /* EpisodeWrapper.step, `nnx_ppo/wrappers/episode_wrapper.py:12-22`:
  * counter' = counter + 1; truncated = inner_truncated | counter' >= max_len;
  * done = float(inner_done | truncated).  inner_done is uint8/bool or fp32
- * (done_is_float); inner_truncated nullable. */
+ * (done_is_float); inner_truncated nullable.  done_flag_out (nullable, uint8[n])
+ * receives the same flag as a byte (`rollout.py:24,41-44` selects on it). */
 int mi_episode_step(const int64_t* counter, const void* inner_done, int done_is_float,
                     const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
-                    uint8_t* truncated_out, float* done_out, int64_t n, mi_stream_t stream);
+                    uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out, int64_t n,
+                    mi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ import torch
 
 from .. import ops, parallel
 from .. import random as rnd
+from ..networks.adapter import _Fork, _can_fork
 from ..networks.types import PPONetworkOutput, StatefulModule, bump_param_epoch
 from ..optim import Optimizer
 from ..tree import tree_leaves, tree_map
@@ -252,7 +253,7 @@ def ppo_step(
         optimizer.begin()
         ppo_loss(networks, net_state_subset, minibatch, clip_range, normalize_advantages,
                  combine_advantages, discounting_factor, gae_lambda, critic_loss_weight,
-                 logging_level, loss_out=loss_rows[i])
+                 logging_level, loss_out=loss_rows[i], want_total=False)
         have_norm = False
         if grad_norms is not None:
             grad_norms[i:i + 1].copy_(optimizer.compute_grad_norm())
@@ -313,7 +314,8 @@ def ppo_loss(
     *,
     loss_out: Optional[torch.Tensor] = None,
     backward: bool = True,
-) -> tuple[torch.Tensor, dict]:
+    want_total: bool = True,
+) -> tuple[Optional[torch.Tensor], dict]:
     """ppo.py:397-531.  Evaluates the loss on one minibatch (`[T, mb, ...]` leaves)
     and — where the reference returns gradients from `nnx.grad` — ACCUMULATES the
     parameter gradients into `Parameter.grad`.  Returns (total_loss, loss_metrics);
@@ -323,14 +325,26 @@ def ppo_loss(
     truncated = rollout_data.truncated
     T, B = done.shape
 
+    # bootstrap value at T (ppo.py:433-437): forward on the last next_obs; only the
+    # value estimate is used, so only the value port is evaluated
+    last_obs = tree_map(lambda x: x[-1], rollout_data.next_obs)
+    stateless = not any(isinstance(t, torch.Tensor) for t in tree_leaves(network_state))
+    fork = None
+    if stateless and _can_fork(last_obs):
+        # no carry: the bootstrap forward does not depend on the replay's final
+        # state, so it runs beside the replay on the second stream (it is a 1/T-size
+        # launch that would otherwise sit alone on the critical path)
+        fork = _Fork(last_obs)
+        with fork:
+            last_values = networks.forward_value(network_state, last_obs)
     # replay scan (ppo.py:411-431), layer by layer over the whole sequence
     ctx, out, reg_seq, final_state = networks.replay(
         network_state, rollout_data.obs, done, rollout_data.rollout_extras,
         need_input_grad=False)
-    # bootstrap value at T (ppo.py:433-437): forward on the last next_obs; only the
-    # value estimate is used, so only the value port is evaluated
-    last_obs = tree_map(lambda x: x[-1], rollout_data.next_obs)
-    last_values = networks.forward_value(final_state, last_obs)
+    if fork is not None:
+        fork.join(last_values)
+    else:
+        last_values = networks.forward_value(final_state, last_obs)
 
     rewards = rollout_data.rewards
     values = out.value_estimates
@@ -345,13 +359,17 @@ def ppo_loss(
     del combine_advantages  # single reward key: nothing to combine
 
     values = values.contiguous()
-    adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
-                  done.contiguous(), truncated.contiguous(), discounting_factor, gae_lambda)
     stats = None
     if normalize_advantages:
-        stats = ops.adv_stats(adv)
+        # the statistics of ppo.py:477-480 come out of the GAE launch itself
+        adv, stats = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
+                             done.contiguous(), truncated.contiguous(), discounting_factor,
+                             gae_lambda, with_stats=True)
         if parallel.is_distributed():
             parallel.allreduce_sum_(stats)
+    else:
+        adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
+                      done.contiguous(), truncated.contiguous(), discounting_factor, gae_lambda)
     reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
     g_ll, g_v, loss_out = ops.ppo_loss(
         ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1), values.reshape(-1), reg_flat,
@@ -368,7 +386,9 @@ def ppo_loss(
         loss_metrics["losses/regularization"] = loss_out[2]
     if LoggingLevel.ACTOR_EXTRA in logging_level:
         loss_metrics["losses/clipping_fraction"] = loss_out[3]
-    total = loss_out[0] + critic_loss_weight * loss_out[1] + loss_out[2]
+    total = None
+    if want_total:  # three tiny launches: the training loop reads `loss_out` instead
+        total = loss_out[0] + critic_loss_weight * loss_out[1] + loss_out[2]
     return total, loss_metrics
 
 

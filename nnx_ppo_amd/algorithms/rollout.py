@@ -9,6 +9,7 @@ import torch
 
 from .. import ops
 from .. import random as rnd
+from ..envs.constants import cast_constant, is_constant
 from ..networks.types import StatefulModule
 from ..tree import tree_all, tree_map
 from .types import Transition
@@ -28,7 +29,10 @@ def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
         if not isinstance(y, torch.Tensor):
             return x
         if y.dtype != x.dtype:
-            y = y.to(x.dtype)
+            if is_constant(x):
+                x = cast_constant(x, y.dtype)  # cached: no launch (e.g. reset's done=False)
+            else:
+                y = y.to(x.dtype)
         pairs.append((x.contiguous(), y.contiguous()))
         return _Slot(len(pairs) - 1)
 
@@ -43,7 +47,10 @@ class _Slot:
 
 
 def _as_bool(x: torch.Tensor) -> torch.Tensor:
-    return x if x.dtype == torch.bool else x != 0
+    if x.dtype == torch.bool:
+        return x
+    flag = getattr(x, "done_flag", None)  # EpisodeWrapper.step emits both forms at once
+    return flag if flag is not None else x != 0
 
 
 def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_reset):

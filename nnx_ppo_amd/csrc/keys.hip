@@ -33,15 +33,17 @@ enum { OUT_SPLIT = 0, OUT_BITS = 1, OUT_RANDINT = 2, OUT_UNIFORM = 3, OUT_UNIT_U
 //   UNIFORM      (BITS >> 40) * 2^-24                               (random.uniform)
 //   UNIT_UNIFORM (UNIFORM - 0.5) * sqrt(12)                         (random.unit_uniform)
 __global__ void __launch_bounds__(kThreads)
-key_expand_kernel(const int64_t* __restrict__ keys, void* __restrict__ out, int64_t n, int64_t m,
-                  int mode, int64_t minval, int64_t span, int child_major) {
+key_expand_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__ fold,
+                  void* __restrict__ out, int64_t n, int64_t m, int mode, int64_t minval,
+                  int64_t span, int child_major) {
   const int64_t total = n * m;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * kThreads) {
     // key-major: out[i*m + j]; child-major: out[j*n + i] (each child set contiguous)
     const int64_t i = child_major ? e % n : e / m;
     const int64_t j = child_major ? e / n : e % m;
-    const uint64_t k = (uint64_t)keys[i];
+    uint64_t k = (uint64_t)keys[i];
+    if (fold) k = mix(k ^ mix((uint64_t)fold[i] + kGolden));  // key_fold_kernel
     if (mode == OUT_SPLIT) {
       static_cast<int64_t*>(out)[e] = (int64_t)mix(k + (uint64_t)(j + 1) * kGolden);
       continue;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(kThreads)
 episode_step_kernel(const int64_t* __restrict__ counter, const void* __restrict__ inner_done,
                     int done_is_float, const uint8_t* __restrict__ inner_trunc, int64_t max_len,
                     int64_t* __restrict__ counter_out, uint8_t* __restrict__ trunc_out,
-                    float* __restrict__ done_out, int64_t n) {
+                    float* __restrict__ done_out, uint8_t* __restrict__ flag_out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * kThreads) {
     const int64_t c = counter[i] + 1;
@@ -86,6 +88,7 @@ episode_step_kernel(const int64_t* __restrict__ counter, const void* __restrict_
     counter_out[i] = c;
     trunc_out[i] = t ? 1 : 0;
     done_out[i] = (d || t) ? 1.0f : 0.0f;
+    if (flag_out) flag_out[i] = (d || t) ? 1 : 0;
   }
 }
 
@@ -97,17 +100,17 @@ int stream_grid(int64_t n) {
 
 }  // namespace
 
-extern "C" int mi_key_expand(const int64_t* keys, void* out, int64_t n, int64_t m, int mode,
-                             int64_t minval, int64_t maxval, int child_major,
-                             mi_stream_t stream) {
+extern "C" int mi_key_expand(const int64_t* keys, const int64_t* fold, void* out, int64_t n,
+                             int64_t m, int mode, int64_t minval, int64_t maxval,
+                             int child_major, mi_stream_t stream) {
   MI_REQUIRE(n >= 0 && m >= 0 && mode >= OUT_SPLIT && mode <= OUT_UNIT_UNIFORM,
              "mi_key_expand: bad arguments");
   if (n == 0 || m == 0) return 0;
   MI_REQUIRE(keys && out, "mi_key_expand: null pointer");
   MI_REQUIRE(mode != OUT_RANDINT || maxval > minval, "mi_key_expand: empty randint range");
   hipLaunchKernelGGL(key_expand_kernel, dim3(stream_grid(n * m)), dim3(kThreads), 0,
-                     mippo::as_stream(stream), keys, out, n, m, mode, minval, maxval - minval,
-                     child_major);
+                     mippo::as_stream(stream), keys, fold, out, n, m, mode, minval,
+                     maxval - minval, child_major);
   return mippo::check_launch("mi_key_expand");
 }
 
@@ -124,13 +127,13 @@ extern "C" int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int
 extern "C" int mi_episode_step(const int64_t* counter, const void* inner_done, int done_is_float,
                                const uint8_t* inner_truncated, int64_t max_len,
                                int64_t* counter_out, uint8_t* truncated_out, float* done_out,
-                               int64_t n, mi_stream_t stream) {
+                               uint8_t* done_flag_out, int64_t n, mi_stream_t stream) {
   MI_REQUIRE(n >= 0, "mi_episode_step: bad n");
   if (n == 0) return 0;
   MI_REQUIRE(counter && inner_done && counter_out && truncated_out && done_out,
              "mi_episode_step: null pointer");
   hipLaunchKernelGGL(episode_step_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
                      mippo::as_stream(stream), counter, inner_done, done_is_float, inner_truncated,
-                     max_len, counter_out, truncated_out, done_out, n);
+                     max_len, counter_out, truncated_out, done_out, done_flag_out, n);
   return mippo::check_launch("mi_episode_step");
 }

@@ -17,12 +17,13 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kMaxBlocks = 256;
-// Up to this many elements one block does the whole reduction in ONE launch.
-// Measured on MI355X at the workload's minibatch (30 720 elements): the statistics
-// pass is cheap enough for one block (8 us vs two launches), the loss pass (exp,
-// four fp64 reductions) is not (34 us on one CU vs 7 + 5 us on 30 CUs).
+// Up to this many elements one block does the whole statistics reduction in ONE
+// launch (8 us at the workload's 30 720-element minibatch vs two launches).  The
+// loss pass (exp, four fp64 reductions) is spread over ceil(n / 1024) blocks and
+// the last block to finish sums the per-block partials in block order
+// (mippo::last_block_ticket): one launch, fixed summation order.
 constexpr int64_t kSingleBlockMax = 65536;
-constexpr int64_t kLossSingleBlockMax = 4096;
+constexpr int kTicketBytes = 16;  // workspace: [ticket counter | partials[G][4]]
 
 __device__ inline double block_sum(double v, double* scratch) {
   // wave reduce (64 lanes) then across the 16 waves of the block
@@ -97,9 +98,11 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
                 const float* __restrict__ adv, const float* __restrict__ values,
                 const float* __restrict__ reg, const double* __restrict__ stats,
                 float clip, float critic_weight, float* __restrict__ g_ll,
-                float* __restrict__ g_v, double* __restrict__ partials,
+                float* __restrict__ g_v, void* __restrict__ ws,
                 float* __restrict__ loss_out, int64_t n) {
   __shared__ double scratch[kThreads / 64];
+  unsigned int* counter = static_cast<unsigned int*>(ws);
+  double* partials = reinterpret_cast<double*>(static_cast<char*>(ws) + kTicketBytes);
   float mean = 0.0f, denom = 1.0f;
   if (stats) {
     // ppo.py:477-480: (a - a.mean()) / (a.std() + 1e-8), population std
@@ -137,34 +140,24 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
   const double t2 = block_sum(s_reg, scratch);
   const double t3 = block_sum(s_clip, scratch);
   if (threadIdx.x == 0) {
-    if (loss_out) {  // single-block launch: finalize in place
-      const double dn = (double)n;
-      loss_out[0] = (float)(-t0 / dn);
-      loss_out[1] = (float)(0.5 * t1 / dn);
-      loss_out[2] = (float)(t2 / dn);
-      loss_out[3] = (float)(t3 / dn);
-    } else {
-      double* p = partials + 4 * blockIdx.x;
-      p[0] = t0;
-      p[1] = t1;
-      p[2] = t2;
-      p[3] = t3;
-    }
+    double* p = partials + 4 * blockIdx.x;
+    p[0] = t0;
+    p[1] = t1;
+    p[2] = t2;
+    p[3] = t3;
   }
-}
-
-// loss_out: [4] = (actor, critic, regularization, clipping_fraction)
-__global__ void ppo_loss_finalize_kernel(const double* partials, int G, int64_t n,
-                                         float* loss_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s[4] = {0, 0, 0, 0};
-  for (int g = 0; g < G; ++g)
-    for (int k = 0; k < 4; ++k) s[k] += partials[4 * g + k];
-  const double dn = (double)n;
-  loss_out[0] = (float)(-s[0] / dn);
-  loss_out[1] = (float)(0.5 * s[1] / dn);
-  loss_out[2] = (float)(s[2] / dn);
-  loss_out[3] = (float)(s[3] / dn);
+  // loss_out: [4] = (actor, critic, regularization, clipping_fraction)
+  if (mippo::last_block_ticket(counter) && threadIdx.x == 0) {
+    double s[4] = {0, 0, 0, 0};
+    for (int g = 0; g < (int)gridDim.x; ++g)
+      for (int k = 0; k < 4; ++k) s[k] += partials[4 * g + k];
+    const double dn = (double)n;
+    loss_out[0] = (float)(-s[0] / dn);
+    loss_out[1] = (float)(0.5 * s[1] / dn);
+    loss_out[2] = (float)(s[2] / dn);
+    loss_out[3] = (float)(s[3] / dn);
+    *counter = 0;
+  }
 }
 
 int grid_for(int64_t n) {
@@ -177,7 +170,7 @@ int grid_for(int64_t n) {
 
 extern "C" int64_t mi_ppo_loss_workspace_bytes(int64_t n) {
   if (n < 0) return -EINVAL;
-  return (int64_t)kMaxBlocks * 4 * (int64_t)sizeof(double);
+  return kTicketBytes + (int64_t)kMaxBlocks * 4 * (int64_t)sizeof(double);
 }
 
 extern "C" int mi_adv_stats_f32(const float* adv, int64_t n, double* stats, void* workspace,
@@ -190,7 +183,7 @@ extern "C" int mi_adv_stats_f32(const float* adv, int64_t n, double* stats, void
     return mippo::check_launch("mi_adv_stats_f32(single)");
   }
   const int G = grid_for(n);
-  double* partials = static_cast<double*>(workspace);
+  double* partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kTicketBytes);
   hipLaunchKernelGGL(adv_stats_partial_kernel, dim3(G), dim3(kThreads), 0, st, adv, n, partials);
   int rc = mippo::check_launch("mi_adv_stats_f32(partial)");
   if (rc) return rc;
@@ -206,19 +199,9 @@ extern "C" int mi_ppo_loss_f32(const float* ll_new, const float* ll_old, const f
   MI_REQUIRE(n >= 1, "mi_ppo_loss_f32: n must be >= 1");
   MI_REQUIRE(ll_new && ll_old && adv && values && g_ll && g_v && loss_out && workspace,
              "mi_ppo_loss_f32: null pointer");
-  double* partials = static_cast<double*>(workspace);
   hipStream_t st = mippo::as_stream(stream);
-  if (n <= kLossSingleBlockMax) {
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(kThreads), 0, st, ll_new, ll_old, adv, values,
-                       reg, adv_stats, clip_range, critic_weight, g_ll, g_v, partials, loss_out, n);
-    return mippo::check_launch("mi_ppo_loss_f32(single)");
-  }
   const int G = grid_for(n);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(G), dim3(kThreads), 0, st, ll_new, ll_old, adv, values,
-                     reg, adv_stats, clip_range, critic_weight, g_ll, g_v, partials,
-                     (float*)nullptr, n);
-  int rc = mippo::check_launch("mi_ppo_loss_f32");
-  if (rc) return rc;
-  hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(64), 0, st, partials, G, n, loss_out);
-  return mippo::check_launch("mi_ppo_loss_f32(finalize)");
+                     reg, adv_stats, clip_range, critic_weight, g_ll, g_v, workspace, loss_out, n);
+  return mippo::check_launch("mi_ppo_loss_f32");
 }

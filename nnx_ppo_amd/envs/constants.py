@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 _cache: dict = {}
+_ids: dict = {}
 
 
 def constant(shape, dtype, value, device) -> torch.Tensor:
@@ -20,4 +21,21 @@ def constant(shape, dtype, value, device) -> torch.Tensor:
     if t is None:
         t = torch.full(tuple(shape), value, dtype=dtype, device=device)
         _cache[key] = t
+        _ids[id(t)] = t
     return t
+
+
+def is_constant(t) -> bool:
+    """True for a tensor handed out by `constant` (identity, not value)."""
+    return isinstance(t, torch.Tensor) and _ids.get(id(t)) is t
+
+
+def cast_constant(t: torch.Tensor, dtype) -> torch.Tensor:
+    """`t.to(dtype)` of a cached constant, itself cached."""
+    key = ("cast", id(t), dtype)
+    c = _cache.get(key)
+    if c is None:
+        c = t.to(dtype)
+        _cache[key] = c
+        _ids[id(c)] = c
+    return c

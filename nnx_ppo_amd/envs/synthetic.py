@@ -27,16 +27,15 @@ class MockEnv:
         self.observation_size = obs_size
 
     def _obs(self, key: torch.Tensor, step: torch.Tensor) -> Any:
-        k = rnd.fold_key(key, step)
         if isinstance(self.obs_size, dict):
             names = sorted(self.obs_size)
-            flat = rnd.unit_uniform(k, (sum(self.obs_size[n] for n in names),))
+            flat = rnd.unit_uniform(key, (sum(self.obs_size[n] for n in names),), fold=step)
             out, o = {}, 0
             for name in names:
                 out[name] = flat[..., o:o + self.obs_size[name]].contiguous()
                 o += self.obs_size[name]
             return out
-        return rnd.unit_uniform(k, (self.obs_size,))
+        return rnd.unit_uniform(key, (self.obs_size,), fold=step)
 
     def reset(self, rng: torch.Tensor) -> State:
         n = rng.shape

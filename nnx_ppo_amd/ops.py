@@ -8,6 +8,7 @@ to torch arithmetic: a CPU tensor or a missing library raises `MippoError`.
 from __future__ import annotations
 
 import ctypes
+from typing import Optional
 
 import torch
 
@@ -28,11 +29,14 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "tanh": ACT_TAN
 _workspaces: dict = {}
 
 
-def workspace(device, tag: str, nbytes: int) -> torch.Tensor:
+def workspace(device, tag: str, nbytes: int, zeroed: bool = False) -> torch.Tensor:
+    """Per (device, stream, tag, size) scratch buffer.  `zeroed`: zero-filled when
+    created (ticket counters; the kernels that use them leave them zero)."""
     key = (str(device), stream(), tag, int(nbytes))
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        alloc = torch.zeros if zeroed else torch.empty
+        ws = alloc(max(int(nbytes), 16), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
@@ -53,9 +57,10 @@ def _need(cond: bool, msg: str) -> None:
 
 # ---------------------------------------------------------------- a13: GAE
 def gae(rewards, values, last_value, done, truncated, gamma: float, lambda_: float,
-        with_targets: bool = False, out=None, out_targets=None):
+        with_targets: bool = False, out=None, out_targets=None, with_stats: bool = False):
     """GAE reverse scan over `[T, N]` (reference ppo.py:351-394).
-    Returns `advantages` or `(advantages, targets)` with `targets = V + A`."""
+    Returns `advantages` or `(advantages, targets)` with `targets = V + A`;
+    `with_stats` appends fp64 [3] = (sum A, sum A^2, count), reduced in the same launch."""
     _need(rewards.dim() == 2, f"rewards must be [T, N], got {tuple(rewards.shape)}")
     T, N = rewards.shape
     _need(values.shape == (T, N) and done.shape == (T, N) and truncated.shape == (T, N),
@@ -67,6 +72,17 @@ def gae(rewards, values, last_value, done, truncated, gamma: float, lambda_: flo
     tgt = None
     if with_targets:
         tgt = out_targets if out_targets is not None else torch.empty_like(rewards)
+    if with_stats:
+        _need(T >= 1 and N >= 1, "gae: with_stats needs a non-empty [T, N]")
+        stats = torch.empty(3, dtype=f64, device=rewards.device)
+        ws = workspace(rewards.device, "gae_stats", lib().mi_gae_stats_workspace_bytes(N),
+                       zeroed=True)
+        rc = lib().mi_gae_stats_f32(ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32),
+                                    ptr(done, u8), ptr(truncated, u8), ptr(adv, f32),
+                                    ptr(tgt, f32), T, N, float(gamma), float(lambda_),
+                                    ptr(stats, f64), ptr(ws), stream())
+        check(rc, "mi_gae_stats_f32")
+        return (adv, tgt, stats) if with_targets else (adv, stats)
     rc = lib().mi_gae_f32(ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32),
                           ptr(done, u8), ptr(truncated, u8), ptr(adv, f32), ptr(tgt, f32),
                           T, N, float(gamma), float(lambda_), stream())
@@ -430,7 +446,7 @@ def mlp_bwd_dx_bf16(g_out: torch.Tensor, aux_last, act_last: int, w_bfs: list, d
 
 # ------------------------------------------------------------- a14: loss
 def _loss_ws(device):
-    return workspace(device, "loss", lib().mi_ppo_loss_workspace_bytes(1))
+    return workspace(device, "loss", lib().mi_ppo_loss_workspace_bytes(1), zeroed=True)
 
 
 def adv_stats(adv: torch.Tensor) -> torch.Tensor:
@@ -624,17 +640,22 @@ KEY_SPLIT, KEY_BITS, KEY_RANDINT, KEY_UNIFORM, KEY_UNIT_UNIFORM = 0, 1, 2, 3, 4
 
 
 def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: int = 0,
-               child_major: bool = False):
+               child_major: bool = False, fold: Optional[torch.Tensor] = None):
     """keys (int64, any shape) -> `[*keys.shape, m]` children / bits / integers / floats
-    (`[m, *keys.shape]` when child_major: each child set is contiguous)."""
+    (`[m, *keys.shape]` when child_major: each child set is contiguous).  `fold`
+    (int64, keys' shape) is folded into the keys first, as `key_fold` would."""
     _need(keys.dtype == i64, "key_expand: keys must be int64")
     k = keys if keys.is_contiguous() else keys.contiguous()
     n = k.numel()
+    if fold is not None:
+        _need(fold.dtype == i64 and fold.shape == k.shape, "key_expand: fold must match keys")
+        fold = fold if fold.is_contiguous() else fold.contiguous()
     dt = f32 if mode in (KEY_UNIFORM, KEY_UNIT_UNIFORM) else i64
     shape = (m, *k.shape) if child_major else (*k.shape, m)
     out = torch.empty(shape, dtype=dt, device=k.device)
-    check(lib().mi_key_expand(ptr(k, i64), ptr(out), n, int(m), int(mode), int(minval),
-                              int(maxval), int(bool(child_major)), stream()), "mi_key_expand")
+    check(lib().mi_key_expand(ptr(k, i64), ptr(fold, i64), ptr(out), n, int(m), int(mode),
+                              int(minval), int(maxval), int(bool(child_major)), stream()),
+          "mi_key_expand")
     return out
 
 
@@ -649,7 +670,8 @@ def key_fold(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def episode_step(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc, max_len: int):
-    """Returns (counter + 1, truncated (bool), done (float32)) — episode_wrapper.py:12-22."""
+    """Returns (counter + 1, truncated (bool), done (float32), done (bool)) —
+    episode_wrapper.py:12-22."""
     n = counter.numel()
     _need(counter.dtype == i64 and inner_done.numel() == n, "episode_step: shapes")
     is_float = inner_done.dtype == f32
@@ -658,10 +680,11 @@ def episode_step(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc, m
     c_out = torch.empty_like(counter)
     t_out = torch.empty(counter.shape, dtype=torch.bool, device=counter.device)
     d_out = torch.empty(counter.shape, dtype=f32, device=counter.device)
+    f_out = torch.empty(counter.shape, dtype=torch.bool, device=counter.device)
     check(lib().mi_episode_step(ptr(counter, i64), ptr(d), int(is_float), ptr(t), int(max_len),
-                                ptr(c_out, i64), ptr(t_out.view(torch.uint8)), ptr(d_out, f32), n,
-                                stream()), "mi_episode_step")
-    return c_out, t_out, d_out
+                                ptr(c_out, i64), ptr(t_out.view(torch.uint8)), ptr(d_out, f32),
+                                ptr(f_out.view(torch.uint8)), n, stream()), "mi_episode_step")
+    return c_out, t_out, d_out, f_out
 
 
 # ------------------------------------------------------------- a20: GRU

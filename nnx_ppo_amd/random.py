@@ -123,13 +123,18 @@ def uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor:
     return b.to(dtype) * (1.0 / (1 << 24))
 
 
-def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor:
+def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32,
+                 fold: torch.Tensor | None = None) -> torch.Tensor:
     """Zero-mean unit-variance uniform noise, (u - 1/2)·sqrt(12).  One IEEE
     multiply after exact operands, so CPU and GPU agree bit for bit; synthetic
     envs use it where the reference's test envs draw `jax.random.normal`
-    (`test_dummies/mock_env.py:41-52`)."""
+    (`test_dummies/mock_env.py:41-52`).  `fold` (int64, k's shape): draw from
+    `fold_key(k, fold)` — on the GPU in the same launch."""
     if k.is_cuda and dtype == torch.float32:
-        return _ops().key_expand(k, _numel(shape), 4).reshape(*k.shape, *tuple(shape))
+        return _ops().key_expand(k, _numel(shape), 4, fold=fold).reshape(*k.shape,
+                                                                        *tuple(shape))
+    if fold is not None:
+        k = fold_key(k, fold)
     u = uniform(k, shape, dtype)
     return (u - 0.5) * 3.4641016151377544
 

@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 
 from .. import random as rnd
-from ..envs.constants import constant
+from ..envs.constants import cast_constant, constant, is_constant
 
 
 class EpisodeWrapper:
@@ -22,9 +22,10 @@ class EpisodeWrapper:
             from .. import ops
 
             prev = next_state.info.get("truncated", None)
-            c, t, d = ops.episode_step(state.info["step_counter"], next_state.done,
-                                       prev if isinstance(prev, torch.Tensor) else None,
-                                       self.max_len)
+            c, t, d, flag = ops.episode_step(state.info["step_counter"], next_state.done,
+                                             prev if isinstance(prev, torch.Tensor) else None,
+                                             self.max_len)
+            d.done_flag = flag  # the same flag as bool: the rollout's reset select reads it
             next_state.info["step_counter"] = c
             next_state.info["truncated"] = t
             return next_state.replace(done=d)
@@ -41,7 +42,13 @@ class EpisodeWrapper:
         next_state = self.env.reset(base_rng)
         next_state.info["step_counter"] = rnd.randint(step_counter_rng, (), 0, self.max_len // 2)
         next_state.info["truncated"] = constant(rng.shape, torch.bool, 0, rng.device)
-        return next_state
+        # `step` returns done as float (episode_wrapper.py:21): keep the reset state's
+        # leaf the same dtype so rollout carries (and captured graphs) see stable leaves
+        done = next_state.done
+        if done.dtype != torch.float32:
+            done = cast_constant(done, torch.float32) if is_constant(done) \
+                else done.to(torch.float32)
+        return next_state.replace(done=done)
 
     @property
     def observation_size(self):

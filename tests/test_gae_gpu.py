@@ -94,3 +94,33 @@ def test_large_property(dev):
     sub = ops.gae(r1[:, idx].contiguous(), v1[:, idx].contiguous(), l1[idx].contiguous(),
                   d[:, idx].contiguous(), tr[:, idx].contiguous(), 0.99, 0.95)
     assert torch.equal(sub, a1[:, idx])
+
+
+@pytest.mark.parametrize("T,N", [(1, 1), (30, 1024), (7, 65), (33, 1000), (5, 64 * 70 + 3)])
+def test_fused_statistics(dev, T, N):
+    """mi_gae_stats_f32: same advantages as mi_gae_f32 (bit-exact) plus fp64
+    (sum A, sum A^2, count) from the same launch; called twice to check that the
+    ticket counter in the workspace is left ready for the next launch."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(T * 7919 + N)
+    r = rng.normal(size=(T, N)).astype(np.float32)
+    v = rng.normal(size=(T, N)).astype(np.float32)
+    lv = rng.normal(size=(N,)).astype(np.float32)
+    d = rng.random((T, N)) < 0.2
+    tr = d & (rng.random((T, N)) < 0.5)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+    args = (t(r, torch.float32), t(v, torch.float32), t(lv, torch.float32), t(d, torch.bool),
+            t(tr, torch.bool), 0.99, 0.95)
+    plain = ops.gae(*args)
+    for _ in range(2):
+        adv, stats = ops.gae(*args, with_stats=True)
+        assert torch.equal(adv, plain)
+        a = plain.cpu().numpy().astype(np.float64)
+        s = stats.cpu().numpy()
+        assert s[2] == T * N
+        assert abs(s[0] - a.sum()) <= 1e-12 * max(1.0, np.abs(a).sum())
+        assert abs(s[1] - (a * a).sum()) <= 1e-12 * max(1.0, (a * a).sum())
+        # the separate statistics kernel agrees to fp64 rounding
+        s2 = ops.adv_stats(plain).cpu().numpy()
+        assert np.allclose(s, s2, rtol=1e-12, atol=1e-12)

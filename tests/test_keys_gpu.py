@@ -66,13 +66,26 @@ def test_episode_step_kernel(dev):
     d_f = (torch.rand(n, generator=g) < 0.2).float()
     tr = torch.rand(n, generator=g) < 0.1
     for done, trunc in ((d_f, None), (d_f != 0, tr), (d_f, tr)):
-        co, to, do = ops.episode_step(c.to(dev), done.to(dev),
-                                      None if trunc is None else trunc.to(dev), 10)
+        co, to, do, fo = ops.episode_step(c.to(dev), done.to(dev),
+                                          None if trunc is None else trunc.to(dev), 10)
         wc = c + 1
         wt = (wc >= 10) | (trunc if trunc is not None else torch.zeros(n, dtype=torch.bool))
         wd = ((done != 0) | wt).float()
         assert torch.equal(co.cpu(), wc) and torch.equal(to.cpu(), wt) and torch.equal(do.cpu(), wd)
         assert to.dtype == torch.bool and do.dtype == torch.float32
+        assert fo.dtype == torch.bool and torch.equal(fo.cpu(), wd != 0)
+
+
+def test_unit_uniform_fold_matches_two_step(dev):
+    """key_expand's in-launch fold == fold_key then expand, on GPU and on CPU."""
+    from nnx_ppo_amd import random as rnd
+
+    k = rnd.split(rnd.key(5), 300)
+    step = torch.arange(300, dtype=torch.int64) * 7 - 11
+    want = rnd.unit_uniform(rnd.fold_key(k, step), (6,))
+    assert torch.equal(rnd.unit_uniform(k, (6,), fold=step), want)
+    got = rnd.unit_uniform(k.to(dev), (6,), fold=step.to(dev))
+    assert torch.equal(got.cpu(), want)
 
 
 def test_select_rows_multi(dev):
