@@ -37,6 +37,7 @@ SEED = 17
 FWD_FLOP_PER_SAMPLE = 2 * (OBS * 64 + 3 * 64 * 64 + 64 * 2 * ACT + OBS * 256 + 256 * 256 + 256)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16
+PEAK_HBM_GBPS = 8000.0          # HBM3E, MI355X_MICROARCH.md
 
 
 # symbol -> (M, K, N) from the integer arguments of a recorded call (in call order;
@@ -113,8 +114,28 @@ def roofline_of_dominant_kernel(env, ts):
     flops = 0.0
     ms = 0.0
     per_kernel = {}
+    # kernel classes of the whole-trunk launches, named as rocprofv3 shows them
+    # (csrc/mlp_bf16.hip: RT = 1 up to 8192 rows, RT = 4 above)
+    classes: dict = {}
+
+    def add(cls, t_ms, work):
+        c = classes.setdefault(cls, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        c["launches"] += 1
+        c["ms"] += t_ms
+        c["flops"] += work[0] or 0.0
+        c["bytes"] += work[1] or 0.0
+
     for name, d in summ.items():
         per_kernel[name] = {"calls": d["calls"], "ms": round(d["ms"], 4)}
+        if name in ("mi_mlp_fwd_bf16", "mi_mlp_bwd_dx_bf16"):
+            bwd = "true" if name == "mi_mlp_bwd_dx_bf16" else "false"
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                M = ints[1] if name == "mi_mlp_bwd_dx_bf16" else ints[0]
+                add(f"mlp_chain_kernel<{1 if M <= 8192 else 4}, {bwd}>", t_ms, work)
+        if name == "mi_dense_bwd_dw_grouped_bf16":
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                add("dW group (tn_gemm_dw_kernel x tile classes + reduce_slabs_grouped)",
+                    t_ms, work)
         if name in GEMM_SYMBOLS:
             if GEMM_SYMBOLS[name] is None:
                 flops += d["flops"]
@@ -125,19 +146,61 @@ def roofline_of_dominant_kernel(env, ts):
                 flops += 2.0 * M * K * N
                 ms += t_ms
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    dom = max(GEMM_SYMBOLS, key=lambda k: summ.get(k, {"ms": 0})["ms"])
     per_kernel["_note"] = ("HIP events around each C-ABI call of one eager iteration queued "
                            "behind a spin kernel (device time, no host gaps)")
     from nnx_ppo_amd import config as mi_config
 
-    peak = PEAK_BF16_MFMA_TFLOPS if mi_config.compute_dtype() == "bf16" else PEAK_F32_MFMA_TFLOPS
-    roof = {
-        "bound": "mfma", "kernel": "dense GEMM family (fwd, dX, dW); largest: " + dom,
-        "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 5), "traffic": None,
-        "event_pair_overhead_us": round(pair_ms * 1e3, 2),
-        "gemm_ms_per_iter": round(ms, 3), "gemm_flop_per_iter": flops,
+    bf16 = mi_config.compute_dtype() == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    gemm_family = {
+        "achieved_tflops": round(achieved, 3), "peak_tflops": peak,
+        "frac": round(achieved / peak, 5), "ms_per_iter": round(ms, 3),
+        "flop_per_iter": flops,
+        "note": "every dense launch (trunk fwd, dX chain, dW): SURVEY 8(d)'s 2*M*K*N count",
     }
+    traffic_db = {}
+    pmc = Path(__file__).resolve().parent / "profiles" / "r01_pmc_traffic.json"
+    if pmc.exists():
+        traffic_db = json.loads(pmc.read_text()).get("kernels", {})
+    trunk = {k: v for k, v in classes.items() if k.startswith("mlp_chain_kernel")}
+    if trunk:
+        # Dominant kernel = the trunk class with the most device time.  Its arithmetic
+        # intensity (~100-150 flop/B with the activations kept for the backward) is below
+        # the bf16 ridge (2500 TF/s / 8 TB/s = 312 flop/B), so HBM bounds it.
+        dom = max(trunk, key=lambda k: trunk[k]["ms"])
+        c = trunk[dom]
+        gbps = c["bytes"] / (c["ms"] * 1e-3) / 1e9
+        tf = c["flops"] / (c["ms"] * 1e-3) / 1e12
+        t = traffic_db.get(dom)
+        roof = {
+            "bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
+            "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5),
+            "traffic": None if t is None else t["hbm_bytes_per_launch"],
+            "traffic_source": None if t is None else
+            "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+            "this command; FETCH_SIZE x2 on gfx950)",
+            "launches_per_iter": c["launches"],
+            "avg_launch_us": round(c["ms"] / c["launches"] * 1e3, 2),
+            "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
+            "arithmetic_intensity_flop_per_byte": round(c["flops"] / max(c["bytes"], 1.0), 1),
+            "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak, 5),
+            "event_pair_overhead_us": round(pair_ms * 1e3, 2),
+            "classes": {k: {"launches": v["launches"],
+                            "avg_launch_us": round(v["ms"] / v["launches"] * 1e3, 2),
+                            "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                            "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                        for k, v in classes.items()},
+            "gemm_family": gemm_family,
+        }
+    else:  # fp32 path: per-layer MFMA GEMMs only
+        dom = max(GEMM_SYMBOLS, key=lambda k: summ.get(k, {"ms": 0})["ms"])
+        roof = {
+            "bound": "mfma", "kernel": "dense GEMM family (fwd, dX, dW); largest: " + dom,
+            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 5), "traffic": None,
+            "event_pair_overhead_us": round(pair_ms * 1e3, 2),
+            "gemm_ms_per_iter": round(ms, 3), "gemm_flop_per_iter": flops,
+        }
     return ts, roof, per_kernel
 
 

@@ -89,6 +89,7 @@ class Profiler:
         self.active = False
         self.records: list = []
         self.next_flops = None  # set by a wrapper that knows the work of its next call
+        self.next_bytes = None  # likewise: algorithmic HBM bytes of the next call
 
     def __enter__(self):
         self.records = []
@@ -102,12 +103,14 @@ class Profiler:
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out: dict = {}
-        for name, ints, e0, e1, flops in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": [], "flops": 0.0})
+        for name, ints, e0, e1, flops, nbytes in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": [], "flops": 0.0,
+                                      "work": []})
             d["calls"] += 1
             ms = e0.elapsed_time(e1)
             d["ms"] += ms
             d["args"].append((ints, ms))
+            d["work"].append((flops, nbytes))
             if flops is not None:
                 d["flops"] += flops
         for d in out.values():
@@ -137,8 +140,10 @@ class _Proxy:
             rc = fn(*args)
             e1.record()
             ints = tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 40))
-            profiler.records.append((name, ints, e0, e1, profiler.next_flops))
+            profiler.records.append((name, ints, e0, e1, profiler.next_flops,
+                                     profiler.next_bytes))
             profiler.next_flops = None
+            profiler.next_bytes = None
             return rc
 
         return timed

@@ -23,23 +23,24 @@ constexpr int kNumCU = 256;
 constexpr int kMaxStreamBlocks = kNumCU * 8;
 
 #ifdef __HIPCC__
-// "Last block done" ticket: every block calls this after writing its partial
-// results; it returns true (to all threads) in the block that arrives last, which
-// may then read every block's partials.  `counter` must be zero before the launch
-// and is left zero by the caller (`*counter = 0` in the last block), so launches
-// that are ordered on one stream can share it.  Saves the separate one-block
+// "Last block done" ticket: every block calls this after THREAD 0 wrote the
+// block's partial results; it returns true (to all threads) in the block that
+// arrives last.  A thread of that block that reads the other blocks' partials
+// executes __threadfence() first (acquire).  `counter` must be zero before the
+// launch and is left zero by the caller (`*counter = 0` in the last block), so
+// launches ordered on one stream can share it.  Saves the separate one-block
 // "finalize" launch of a two-pass reduction (~5 us + a dependency edge at this
-// workload's sizes) while keeping a fixed summation order.
+// workload's sizes) while keeping a fixed summation order.  Only thread 0 fences:
+// a device-scope release writes back the XCD's L2, and 16 waves doing so per block
+// cost more than the launch it saves.
 __device__ inline bool last_block_ticket(unsigned int* counter) {
   __shared__ bool is_last;
-  __threadfence();  // release: this block's partials are visible device-wide
-  __syncthreads();
   if (threadIdx.x == 0) {
+    __threadfence();  // release: this block's partials are visible device-wide
     const unsigned int blocks = gridDim.x * gridDim.y * gridDim.z;
     is_last = atomicAdd(counter, 1u) == blocks - 1;
   }
   __syncthreads();
-  if (is_last) __threadfence();  // acquire: see the other blocks' partials
   return is_last;
 }
 #endif

@@ -78,6 +78,7 @@ gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
       partials[2 * blockIdx.x + 1] = s2;
     }
     if (mippo::last_block_ticket(counter)) {
+      __threadfence();  // acquire
       const int G = (int)gridDim.x;
       double t = 0.0, t2 = 0.0;
       for (int g = threadIdx.x; g < G; g += 64) {  // lane-strided, then lane order

@@ -27,6 +27,8 @@
 //        through `act(x @ W + b)` (nnx_ppo/networks/feedforward.py:42-51);
 //   DW : split over the reduce dimension into fp32 slabs (+ bias column sums),
 //        reduced in fixed order by reduce_slabs (dense.hip) — no float atomics.
+#include <stdlib.h>
+
 #include "bf16_common.h"
 
 namespace {
@@ -223,25 +225,41 @@ constexpr int kMaxDwProblems = 8;
 struct DwTable {
   DwProblem p[kMaxDwProblems];
   int n;
+  int gx, gy;        // tile grid of the largest problem; the launch is 1-D: gx * gy * splits
   int64_t M, rows_per_split;
 };
+
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.
+// Map the hardware id so that CONSECUTIVE logical ids share an XCD: the tiles of one
+// row split (same X / dZ rows, read by gx * gy workgroups) then hit in one L2
+// instead of being fetched into several.
+__device__ inline unsigned xcd_swizzle(unsigned hw, unsigned total) {
+  constexpr unsigned kXcd = 8;
+  const unsigned chunk = total / kXcd, rem = total % kXcd;
+  const unsigned xcd = hw % kXcd, idx = hw / kXcd;
+  return xcd * chunk + (xcd < rem ? xcd : rem) + idx;
+}
 
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(kThreads)
 tn_gemm_dw_kernel(DwTable tab) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  const unsigned logical = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int bx = (int)(logical % (unsigned)tab.gx);
+  const int by = (int)((logical / (unsigned)tab.gx) % (unsigned)tab.gy);
+  const int bz = (int)(logical / (unsigned)(tab.gx * tab.gy));
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < kMaxDwProblems; ++q)
-    if (q < tab.n && (int)blockIdx.z >= tab.p[q].z_begin) pi = q;
+    if (q < tab.n && bz >= tab.p[q].z_begin) pi = q;
   const DwProblem pr = tab.p[pi];
   const bf16_t* __restrict__ A = pr.A;
   const bf16_t* __restrict__ B = pr.B;
   const int64_t lda = pr.lda, ldb = pr.ldb, I = pr.I, J = pr.J, M = tab.M;
   const int64_t rows_per_split = tab.rows_per_split;
   float* __restrict__ slabs = pr.slabs;
-  const int zsplit = (int)blockIdx.z - pr.z_begin;
-  if ((int64_t)blockIdx.x * (WM * TM * 16) >= I || (int64_t)blockIdx.y * (WN * TN * 16) >= J)
+  const int zsplit = bz - pr.z_begin;
+  if ((int64_t)bx * (WM * TM * 16) >= I || (int64_t)by * (WN * TN * 16) >= J)
     return;  // this problem has fewer tiles than the group's grid
   constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
@@ -258,8 +276,8 @@ tn_gemm_dw_kernel(DwTable tab) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t i0 = (int64_t)blockIdx.x * BM;
-  const int64_t j0 = (int64_t)blockIdx.y * BN;
+  const int64_t i0 = (int64_t)bx * BM;
+  const int64_t j0 = (int64_t)by * BN;
   const int64_t r_begin = (int64_t)zsplit * rows_per_split;
   const int64_t r_end = r_begin + rows_per_split < M ? r_begin + rows_per_split : M;
 
@@ -321,7 +339,7 @@ tn_gemm_dw_kernel(DwTable tab) {
   };
 
   float bias_sum = 0.0f;
-  const bool do_bias = blockIdx.x == 0;
+  const bool do_bias = bx == 0;
 
   load_tile(r_begin);
   store_tile(0);
@@ -578,7 +596,12 @@ extern "C" int mi_dense_bwd_dx_bf16(const void* dz_bf, int64_t lddz, const void*
 // rows per split / number of splits shared by every problem of a launch (they
 // share M): enough workgroups to cover the chip about twice, >= 128 rows each.
 static void dw_split_plan(int64_t M, int64_t total_tiles, int64_t* rows, int64_t* S) {
-  int64_t s = mippo::ceil_div((int64_t)2 * mippo::kNumCU, total_tiles < 1 ? 1 : total_tiles);
+  // MIPPO_DW_BLOCKS overrides the target workgroup count (tuning aid)
+  static const int64_t target = [] {
+    const char* e = getenv("MIPPO_DW_BLOCKS");
+    return e ? (int64_t)atoi(e) : (int64_t)2 * mippo::kNumCU;
+  }();
+  int64_t s = mippo::ceil_div(target, total_tiles < 1 ? 1 : total_tiles);
   const int64_t max_s = mippo::ceil_div(M, 128);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -663,7 +686,10 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
       Sv[l] = S;
       ws += S * (KNv[l] + N[l]);
     }
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(tab.n * S));
+    tab.gx = (int)gx;
+    tab.gy = (int)gy;
+    MI_REQUIRE(gx * gy * tab.n * S <= 0x7fffffffLL, "mi_dense_bwd_dw_grouped_bf16: grid too large");
+    dim3 grid((unsigned)(gx * gy * tab.n * S));
     if (cls == 0) {
       hipLaunchKernelGGL((tn_gemm_dw_kernel<2, 2, 4, 4>), grid, dim3(kThreads), 0, st, tab);
     } else if (cls == 1) {

@@ -147,16 +147,22 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
     p[3] = t3;
   }
   // loss_out: [4] = (actor, critic, regularization, clipping_fraction)
-  if (mippo::last_block_ticket(counter) && threadIdx.x == 0) {
+  if (mippo::last_block_ticket(counter) && threadIdx.x < 64) {
+    __threadfence();  // acquire
     double s[4] = {0, 0, 0, 0};
-    for (int g = 0; g < (int)gridDim.x; ++g)
+    for (int g = threadIdx.x; g < (int)gridDim.x; g += 64)  // lane-strided, then lane order
       for (int k = 0; k < 4; ++k) s[k] += partials[4 * g + k];
-    const double dn = (double)n;
-    loss_out[0] = (float)(-s[0] / dn);
-    loss_out[1] = (float)(0.5 * s[1] / dn);
-    loss_out[2] = (float)(s[2] / dn);
-    loss_out[3] = (float)(s[3] / dn);
-    *counter = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      for (int k = 0; k < 4; ++k) s[k] += __shfl_down(s[k], off, 64);
+    if (threadIdx.x == 0) {
+      const double dn = (double)n;
+      loss_out[0] = (float)(-s[0] / dn);
+      loss_out[1] = (float)(0.5 * s[1] / dn);
+      loss_out[2] = (float)(s[2] / dn);
+      loss_out[3] = (float)(s[3] / dn);
+      *counter = 0;
+    }
   }
 }
 

@@ -365,6 +365,9 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
         ws = workspace(grp[0][2].device, "dense_dw_grouped", nbytes)
         if profiler.active:
             profiler.next_flops = 2.0 * M * sum(K * N for K, N in zip(Ks, Ns))
+            # operands once + fp32 gradients read-modify-written
+            profiler.next_bytes = (sum((g[0].numel() + g[1].numel()) * 2.0 for g in grp)
+                                   + sum(8.0 * (K * N + N) for K, N in zip(Ks, Ns)))
         check(lib().mi_dense_bwd_dw_grouped_bf16(
             n, P(*[ptr(g[0], bf16) for g in grp]), P(*[ptr(g[1], bf16) for g in grp]),
             P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]), Kc, Nc, M,
@@ -391,19 +394,18 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
         for l in range(L):
             last = l == L - 1
             N = dims[l + 1]
-            # hidden y_bf is copied out of LDS with its zero padding; the last layer's
-            # y_bf and every pre_bf are element stores, so their padding is zeroed here
-            zpad = (lambda r, c: torch.zeros(r, pad8(c), dtype=bf16, device=dev)
-                    if pad8(c) != c else _bf_buf(r, c, dev))
-            if not last:
+            # every image is written whole by the kernel, zero padding included
+            if not last or acts[l] != ACT_NONE:
                 y_bf[l] = _bf_buf(M, N, dev)
-            elif acts[l] != ACT_NONE:
-                y_bf[l] = zpad(M, N)
             if acts[l] == ACT_SWISH:
-                pre_bf[l] = zpad(M, N)
+                pre_bf[l] = _bf_buf(M, N, dev)
     arr = lambda ts: P(*[ptr(t) for t in ts])
     if profiler.active:
         profiler.next_flops = 2.0 * M * sum(dims[l] * dims[l + 1] for l in range(L))
+        w_bytes = sum(2 * dims[l] * dims[l + 1] + 4 * dims[l + 1] for l in range(L))
+        kept = sum(t.numel() * 2 for t in [x_bf, *y_bf, *pre_bf] if t is not None)
+        # algorithmic HBM bytes: fp32 input + weights in, fp32 output + kept bf16 images out
+        profiler.next_bytes = 4.0 * M * K0 + w_bytes + 4.0 * M * dims[-1] + kept
     check(lib().mi_mlp_fwd_bf16(
         ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
         (ctypes.c_int64 * L)(*[int(a) for a in acts]), ptr(out, f32),
@@ -434,6 +436,11 @@ def mlp_bwd_dx_bf16(g_out: torch.Tensor, aux_last, act_last: int, w_bfs: list, d
     if profiler.active:
         first = 0 if need_input_grad else 1
         profiler.next_flops = 2.0 * M * sum(dims[l] * dims[l + 1] for l in range(first, L))
+        w_bytes = sum(2 * dims[l] * dims[l + 1] for l in range(first, L))
+        moved = sum(t.numel() * 2 for t in [aux_last, *auxs[:L - 1], *dz] if t is not None)
+        # fp32 output gradient + act' operands + weights in, every dz (+ fp32 g_in) out
+        profiler.next_bytes = (4.0 * M * dims[-1] + w_bytes + moved
+                               + (4.0 * M * dims[0] if need_input_grad else 0.0))
     check(lib().mi_mlp_bwd_dx_bf16(
         ptr(g_out, f32), ptr(aux_last), int(act_last), M, L, P(*[ptr(w, bf16) for w in w_bfs]),
         (ctypes.c_int64 * (L + 1))(*[int(d) for d in dims]),
