@@ -15,7 +15,9 @@ from pathlib import Path
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "libmippo.so"
+# MIPPO_LIB points the binding at another build of the same ABI (A/B timing of kernel
+# variants on one GPU box: boxes differ by more than most kernel changes do)
+_LIB_PATH = Path(os.environ.get("MIPPO_LIB") or Path(__file__).resolve().parent / "libmippo.so")
 
 ABI_VERSION = 1
 
