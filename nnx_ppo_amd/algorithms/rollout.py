@@ -53,8 +53,10 @@ def _as_bool(x: torch.Tensor) -> torch.Tensor:
     return flag if flag is not None else x != 0
 
 
-def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_reset):
-    """rollout.py:11-45."""
+def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_reset,
+                      reset_states=None):
+    """rollout.py:11-45.  `reset_states` (optional): `env.reset(rng_keys_for_env_reset)`
+    evaluated ahead of time (see `unroll_env`)."""
     network_state, env_state = carry
     out = networks(network_state, env_state.obs)
     next_network_state = out.next_state
@@ -73,7 +75,8 @@ def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_res
         metrics={"env": next_env_state.metrics, "net": out.metrics},
         rollout_extras=out.rollout_extras,
     )
-    reset_states = env.reset(rng_keys_for_env_reset)
+    if reset_states is None:
+        reset_states = env.reset(rng_keys_for_env_reset)
     next_env_state = tree_where(done, reset_states, next_env_state)
     reset_network_states = networks.reset_state(next_network_state)
     next_network_state = tree_where(done, reset_network_states, next_network_state)
@@ -86,10 +89,23 @@ def unroll_env(env, env_state, networks: StatefulModule, network_state, unroll_l
     with time-major `[T, N, ...]` leaves)."""
     batch_size = env_state.done.shape[0]
     keys = rnd.split(rng_key_for_env_reset, (unroll_length, batch_size))
+    # The reset state of step t is a function of keys[t] alone (rollout.py:57-59
+    # evaluates it inside the scan, every step, for every env): evaluate all T of
+    # them in ONE batched call — same values, T times fewer launches on the
+    # per-step critical path.
+    TN = unroll_length * batch_size
+    resets = env.reset(keys.reshape(TN))
+
+    def at_step(t):
+        return tree_map(
+            lambda x: x.view(unroll_length, batch_size, *x.shape[1:])[t]
+            if isinstance(x, torch.Tensor) and x.dim() >= 1 and x.shape[0] == TN else x,
+            resets)
+
     carry = (network_state, env_state)
     steps = []
     for t in range(unroll_length):
-        carry, tr = single_transition(env, networks, carry, keys[t])
+        carry, tr = single_transition(env, networks, carry, keys[t], reset_states=at_step(t))
         steps.append(tr)
     rollout = tree_map(lambda *xs: torch.stack(xs, dim=0), steps[0], *steps[1:])
     shapes_match = tree_map(lambda v, r: v.shape == r.shape,

@@ -48,13 +48,23 @@ class MockEnv:
             metrics={}, info={})
 
     def step(self, state: State, action: torch.Tensor) -> State:
-        step = state.data["step_count"] + 1
         key = state.data["key"]
+        count = state.data["step_count"]
+        if count.is_cuda:
+            # counter + 1 and the `>= max_steps` flag in one launch (the episode
+            # bookkeeping kernel with no inner done)
+            from .. import ops
+
+            step, done, _, _ = ops.episode_step(
+                count, constant(count.shape, torch.bool, 0, count.device), None, self.max_steps)
+        else:
+            step = count + 1
+            done = step >= self.max_steps
         return State(
             data={"key": key, "step_count": step},
             obs=self._obs(key, step),
             reward=constant(step.shape, torch.float32, 1.0, step.device),
-            done=step >= self.max_steps,
+            done=done,
             metrics={}, info={})
 
 
