@@ -236,6 +236,29 @@ int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_
                     float* out, void* const* y_bf, void* const* pre_bf, void* x_bf,
                     mi_stream_t stream);
 
+/* One policy evaluation in ONE launch — the rollout / replay forward of
+ * `make_mlp_actor_critic`'s network (`nnx_ppo/networks/factories.py:88-146`):
+ *   x  = (obs - mean) / std                  normalizer.py:63-96   (norm_mean nullable)
+ *   ms = action trunk(x); sampler(ms)        feedforward.py:42-51, sampling_layers.py:82-147
+ *   v  = value trunk(x)                      adapter.py:75-117
+ * obs [M, K0] fp32.  Trunk arguments as mi_mlp_fwd_bf16 (a_* action, c_* value;
+ * a_dims[0] == c_dims[0] == K0, a_dims[La] == 2A).  Sampler arguments and outputs
+ * as mi_tanh_gauss_fwd_f32 (extras != null scores stored raw actions: replay).
+ * mean_and_std [M, 2A] (nullable) receives the action trunk's fp32 output (the
+ * sampler backward reads it); value [M, c_dims[Lc]].  The *_y_bf / *_pre_bf /
+ * *_x_bf arrays (nullable) receive the training images of mi_mlp_fwd_bf16. */
+int mi_policy_fwd_bf16(
+    const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
+    const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,
+    const float* const* a_bias, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
+    const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const float* extras, const uint64_t* rng_state, uint64_t offset_add,
+    const float* eps, const float* eps2, float min_std, float std_scale, float entropy_weight,
+    int deterministic, float* mean_and_std, float* raw_out, float* action, float* loglik,
+    float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
+    void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
+    void* c_x_bf, mi_stream_t stream);
+
 /* The dX chain of the same trunk in ONE launch (the backward twin of
  * mi_mlp_fwd_bf16): from g_out [M][N_{L-1}] (fp32; times act'_{L-1}(aux_last) if
  * act_last != MI_ACT_NONE) it produces dz_last [M][pad8 N_{L-1}] (bf16) and, walking

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "bf16_common.h"
+#include "sampler_math.h"
 
 namespace {
 
@@ -64,6 +65,22 @@ struct Chain {
   int arow;             // LDS row length in bf16: widest (32-rounded) layer + 8
 };
 
+// Fused policy step (mi_policy_fwd_bf16): blockIdx.y picks one of two trunks that
+// read the same input (0 = action port, 1 = value port); the input stage applies the
+// running-statistics normaliser and the action trunk ends in the sampler.
+struct PolicyExtra {
+  const float* norm_mean;   // [K0] or null: no normalisation
+  const float* norm_m2;
+  const float* norm_count;  // [1]
+  float norm_eps;
+  mippo_sampler::FwdParams samp;  // samp.A == 0: no sampler
+  int ms_off;               // LDS byte offset of the fp32 [ROWS][2A] sampler input
+};
+struct PolicyArgs {
+  Chain c[2];
+  PolicyExtra px;
+};
+
 struct IStep {
   int l, p, kc;  // layer, column pass (256 columns per pass), k-chunk
 };
@@ -86,9 +103,8 @@ struct BFrags {
   bf16x8 f[IF_KS][4];  // [k-step][column tile]
 };
 
-template <int RT, bool BWD>
-__global__ void __launch_bounds__(kThreads)
-mlp_chain_kernel(Chain c) {
+template <int RT, bool BWD, bool POLICY>
+__device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px) {
   constexpr int ROWS = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int arow = c.arow;
@@ -142,6 +158,14 @@ mlp_chain_kernel(Chain c) {
     const int row = i / K0p, k = i % K0p;
     const int64_t gi = i0 + row;
     float v = (gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f;
+    if constexpr (POLICY) {
+      // normalizer.py:76-81,92-96 — the same fp32 expression as normalize_fwd_kernel
+      if (px->norm_mean && gi < c.M && k < K0) {
+        const float cnt = *px->norm_count;
+        const float sd = cnt > 0.0f ? sqrtf(fmaxf(px->norm_m2[k] / cnt, px->norm_eps)) : 10.0f;
+        v = (v - px->norm_mean[k]) / sd;
+      }
+    }
     if (BWD && c.aux0 && gi < c.M && k < K0)
       v *= act_grad((float)c.aux0[gi * c.ldaux0 + k], c.act0);
     act0[row * arow + k] = (bf16_t)v;
@@ -164,6 +188,9 @@ mlp_chain_kernel(Chain c) {
     const bool last = st.l == c.L - 1;
     const bool keep = !last || ly.out_bf;
     const bool to_out = last && c.out;
+    // action trunk of a policy step: the sampler reads the fp32 output row from LDS
+    const bool to_ms = POLICY && last && px->samp.A > 0 && blockIdx.y == 0;
+    float* const ms_s = POLICY ? reinterpret_cast<float*>(lds_raw + px->ms_off) : nullptr;
     const bool store_pre = !BWD && TRANS && ly.pre_bf;
     const bool use_aux = BWD && ly.aux && ly.act != MI_ACT_NONE;
     const int Np = (ly.N + 31) / 32 * 32;  // the next layer reduces over Np columns
@@ -206,6 +233,9 @@ mlp_chain_kernel(Chain c) {
             if (j0 + e >= ly.N) v = 0.0f;  // pad columns (weights are zero there)
             vo[e] = (bf16_t)v;
             if (to_out && gi < c.M && j0 + e < ly.N) c.out[gi * ly.N + j0 + e] = v;
+            if constexpr (POLICY) {
+              if (to_ms && j0 + e < ly.N) ms_s[row * ly.N + j0 + e] = v;
+            }
           }
           if (keep) *reinterpret_cast<bf16x4*>(nbuf + row * arow + j0) = vo;
           if constexpr (!BWD && TRANS) {
@@ -287,6 +317,27 @@ mlp_chain_kernel(Chain c) {
       for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
     s = sn;
   }
+  if constexpr (POLICY) {
+    // sampling_layers.py:82-147 on this workgroup's rows (the last layer's barrier
+    // has published ms_s); one thread per row, as in sampler_fwd_kernel
+    if (px->samp.A > 0 && blockIdx.y == 0) {
+      const float* ms_s = reinterpret_cast<const float*>(lds_raw + px->ms_off);
+      for (int row = tid; row < ROWS; row += kThreads)
+        if (i0 + row < c.M) mippo_sampler::fwd_row(ms_s + row * 2 * px->samp.A, i0 + row, px->samp);
+    }
+  }
+}
+
+template <int RT, bool BWD>
+__global__ void __launch_bounds__(kThreads)
+mlp_chain_kernel(Chain c) {
+  chain_body<RT, BWD, false>(c, nullptr);
+}
+
+template <int RT>
+__global__ void __launch_bounds__(kThreads)
+policy_kernel(PolicyArgs a) {
+  chain_body<RT, false, true>(a.c[blockIdx.y], &a.px);
 }
 
 template <int RT, bool BWD>
@@ -320,14 +371,17 @@ int launch_chain(Chain& c, int maxw, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
-                               const float* const* bias, const int64_t* dims,
-                               const int64_t* acts, float* out, void* const* y_bf,
-                               void* const* pre_bf, void* x_bf, mi_stream_t stream) {
-  MI_REQUIRE(M >= 0 && L >= 1 && L <= CH_MAXL, "mi_mlp_fwd_bf16: 1 <= L <= %d", CH_MAXL);
-  if (M == 0) return 0;
-  MI_REQUIRE(x && wt_bf && dims && acts && out, "mi_mlp_fwd_bf16: null pointer");
-  Chain c = {};
+namespace {
+
+// Fills a forward Chain from the C-ABI arrays (shared by mi_mlp_fwd_bf16 and
+// mi_policy_fwd_bf16); *maxw receives the widest 32-rounded layer.
+int fill_fwd_chain(Chain& c, const char* who, const float* x, int64_t M, int64_t L,
+                   const void* const* wt_bf, const float* const* bias, const int64_t* dims,
+                   const int64_t* acts, float* out, void* const* y_bf, void* const* pre_bf,
+                   void* x_bf, int* maxw_out) {
+  MI_REQUIRE(L >= 1 && L <= CH_MAXL, "%s: 1 <= L <= %d", who, CH_MAXL);
+  MI_REQUIRE(x && wt_bf && dims && acts, "%s: null pointer", who);
+  c = {};
   c.x = x;
   c.out = out;
   c.M = M;
@@ -337,10 +391,10 @@ extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void*
   int maxw = 0;
   for (int l = 0; l < L; ++l) {
     const int64_t K = dims[l], N = dims[l + 1];
-    MI_REQUIRE(K >= 1 && N >= 1 && K <= 512 && N <= 512,
-               "mi_mlp_fwd_bf16: layer widths must be in [1, 512]");
-    MI_REQUIRE(acts[l] >= MI_ACT_NONE && acts[l] <= MI_ACT_SWISH, "mi_mlp_fwd_bf16: bad act");
-    MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "mi_mlp_fwd_bf16: weights must be 16-byte aligned");
+    MI_REQUIRE(K >= 1 && N >= 1 && K <= 512 && N <= 512, "%s: layer widths must be in [1, 512]",
+               who);
+    MI_REQUIRE(acts[l] >= MI_ACT_NONE && acts[l] <= MI_ACT_SWISH, "%s: bad act", who);
+    MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "%s: weights must be 16-byte aligned", who);
     ChainLayer& ly = c.layer[l];
     ly.w = static_cast<const bf16_t*>(wt_bf[l]);
     ly.bias = bias ? bias[l] : nullptr;
@@ -350,11 +404,94 @@ extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void*
     ly.ldo = mippo::ceil_div(N, 8) * 8;
     ly.out_bf = y_bf ? static_cast<bf16_t*>(y_bf[l]) : nullptr;
     ly.pre_bf = pre_bf ? static_cast<bf16_t*>(pre_bf[l]) : nullptr;
-    MI_REQUIRE(al16(ly.out_bf) && al16(ly.pre_bf), "mi_mlp_fwd_bf16: outputs must be 16-byte aligned");
+    MI_REQUIRE(al16(ly.out_bf) && al16(ly.pre_bf), "%s: outputs must be 16-byte aligned", who);
     const int w = (int)(mippo::ceil_div(K > N ? K : N, 32) * 32);
     if (w > maxw) maxw = w;
   }
+  *maxw_out = maxw;
+  return 0;
+}
+
+template <int RT>
+int launch_policy(PolicyArgs& a, int maxw, hipStream_t st) {
+  constexpr int ROWS = 16 * RT;
+  const int act_bytes = 2 * ROWS * (maxw + 8) * (int)sizeof(bf16_t);
+  a.px.ms_off = act_bytes;
+  const size_t lds = (size_t)act_bytes + (size_t)ROWS * 2 * a.px.samp.A * sizeof(float);
+  constexpr int kWant = 2 * ROWS * (512 + 8) * (int)sizeof(bf16_t) + ROWS * 128 * (int)sizeof(float);
+  constexpr int kCap = kWant < 160 * 1024 ? kWant : 160 * 1024;
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&policy_kernel<RT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
+  MI_REQUIRE(attr == hipSuccess, "policy_kernel: cannot raise the dynamic LDS limit: %s",
+             hipGetErrorString(attr));
+  MI_REQUIRE(lds <= (size_t)kCap, "policy_kernel: %zu bytes of LDS needed, %d available", lds, kCap);
+  hipLaunchKernelGGL((policy_kernel<RT>), dim3((unsigned)mippo::ceil_div(a.c[0].M, ROWS), 2),
+                     dim3(kThreads), lds, st, a);
+  return mippo::check_launch("mi_policy_fwd_bf16");
+}
+
+}  // namespace
+
+extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
+                               const float* const* bias, const int64_t* dims,
+                               const int64_t* acts, float* out, void* const* y_bf,
+                               void* const* pre_bf, void* x_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_mlp_fwd_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(out, "mi_mlp_fwd_bf16: null pointer");
+  Chain c;
+  int maxw = 0;
+  int rc = fill_fwd_chain(c, "mi_mlp_fwd_bf16", x, M, L, wt_bf, bias, dims, acts, out, y_bf,
+                          pre_bf, x_bf, &maxw);
+  if (rc) return rc;
   return launch_chain<false>(c, maxw, mippo::as_stream(stream));
+}
+
+extern "C" int mi_policy_fwd_bf16(
+    const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
+    const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,
+    const float* const* a_bias, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
+    const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const float* extras, const uint64_t* rng_state, uint64_t offset_add,
+    const float* eps, const float* eps2, float min_std, float std_scale, float entropy_weight,
+    int deterministic, float* mean_and_std, float* raw_out, float* action, float* loglik,
+    float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
+    void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
+    void* c_x_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_policy_fwd_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(obs && value && a_dims && c_dims, "mi_policy_fwd_bf16: null pointer");
+  MI_REQUIRE(a_dims[0] == c_dims[0], "mi_policy_fwd_bf16: both trunks read the same input");
+  MI_REQUIRE(!norm_mean || (norm_m2 && norm_count), "mi_policy_fwd_bf16: incomplete normaliser");
+  MI_REQUIRE(rng_state || (eps && eps2),
+             "mi_policy_fwd_bf16: need rng_state or both injected noises");
+  PolicyArgs a;
+  int wa = 0, wc = 0;
+  int rc = fill_fwd_chain(a.c[0], "mi_policy_fwd_bf16(action)", obs, M, La, a_w, a_bias, a_dims,
+                          a_acts, mean_and_std, a_y_bf, a_pre_bf, a_x_bf, &wa);
+  if (rc) return rc;
+  rc = fill_fwd_chain(a.c[1], "mi_policy_fwd_bf16(value)", obs, M, Lc, c_w, c_bias, c_dims, c_acts,
+                      value, c_y_bf, c_pre_bf, c_x_bf, &wc);
+  if (rc) return rc;
+  const int64_t A2 = a_dims[La];
+  MI_REQUIRE(A2 >= 2 && A2 % 2 == 0 && A2 <= 128,
+             "mi_policy_fwd_bf16: the action trunk must end in 2A <= 128 columns");
+  a.c[0].arow = wa + 8;
+  a.c[1].arow = wc + 8;
+  a.px = {};
+  a.px.norm_mean = norm_mean;
+  a.px.norm_m2 = norm_m2;
+  a.px.norm_count = norm_count;
+  a.px.norm_eps = norm_eps;
+  a.px.samp = {extras, {rng_state, offset_add, eps, eps2}, raw_out, action, mu_out, sigma_out,
+               loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
+  const int maxw = wa > wc ? wa : wc;
+  hipStream_t st = mippo::as_stream(stream);
+  if (M <= 8192) return launch_policy<1>(a, maxw, st);
+  MI_REQUIRE(maxw <= 256, "mi_policy_fwd_bf16: trunks wider than 256 take at most 8192 rows "
+                          "(use mi_mlp_fwd_bf16 per trunk)");
+  return launch_policy<4>(a, maxw, st);
 }
 
 extern "C" int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int act_last,

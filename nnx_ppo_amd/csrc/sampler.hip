@@ -7,79 +7,19 @@
 // Philox (philox.h) keyed by a device-resident {seed, offset} pair so that a
 // captured HIP graph draws fresh noise on every replay; the backward kernel
 // regenerates the entropy noise from the same counter instead of storing it.
-#include "common.h"
-#include "philox.h"
+#include "sampler_math.h"
 
 namespace {
 
+using namespace mippo_sampler;
+
 constexpr int kThreads = 256;
-constexpr float kLog2 = 0.69314718055994530942f;
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;
-
-__device__ inline float softplus(float x) {
-  // jax.nn.softplus = logaddexp(x, 0)
-  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
-}
-
-__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ inline float log_det_jac(float z) {
-  // sampling_layers.py:133: 2 (log 2 - z - softplus(-2 z))
-  return 2.0f * (kLog2 - z - softplus(-2.0f * z));
-}
-
-struct Noise {
-  const uint64_t* rng;  // {seed, offset}; may be null when both eps are injected
-  uint64_t offset_add;
-  const float* eps;   // [B, A] injected action noise or null
-  const float* eps2;  // [B, A] injected entropy noise or null
-  __device__ inline void get(int64_t elem, float& e, float& e2) const {
-    if (eps && eps2) {
-      e = eps[elem];
-      e2 = eps2[elem];
-      return;
-    }
-    float pe, pe2;
-    mippo::philox_normal_pair(rng[0], rng[1] + offset_add, (uint64_t)elem, pe, pe2);
-    e = eps ? eps[elem] : pe;
-    e2 = eps2 ? eps2[elem] : pe2;
-  }
-};
 
 __global__ void __launch_bounds__(kThreads)
-sampler_fwd_kernel(const float* __restrict__ ms, const float* __restrict__ extras,
-                   Noise noise, float* __restrict__ raw_out, float* __restrict__ action,
-                   float* __restrict__ ll, float* __restrict__ reg,
-                   float* __restrict__ mu_out, float* __restrict__ sigma_out, int64_t B,
-                   int A, float min_std, float std_scale, float entropy_weight,
-                   int deterministic) {
+sampler_fwd_kernel(const float* __restrict__ ms, FwdParams p, int64_t B) {
   const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (b >= B) return;
-  const float* row = ms + b * 2 * A;
-  float ll_acc = 0.0f, h_acc = 0.0f;
-  for (int a = 0; a < A; ++a) {
-    const int64_t e = b * A + a;
-    const float mu = row[a];
-    const float sigma = (softplus(row[A + a]) + min_std) * std_scale;
-    float eps, eps2;
-    noise.get(e, eps, eps2);
-    const float sampled = deterministic ? mu : mu + sigma * eps;
-    const float z = extras ? extras[e] : sampled;
-    // _loglikelihood, sampling_layers.py:118-135
-    const float q = (z - mu) / sigma;
-    float lp = -0.5f * (q * q) - (kHalfLog2Pi + logf(sigma));
-    lp -= log_det_jac(z);
-    ll_acc += lp;
-    // _entropy, sampling_layers.py:137-147
-    const float z2 = mu + sigma * eps2;
-    h_acc += (0.5f + kHalfLog2Pi + logf(sigma)) + log_det_jac(z2);
-    if (raw_out) raw_out[e] = z;
-    if (action) action[e] = tanhf(z);
-    if (mu_out) mu_out[e] = mu;
-    if (sigma_out) sigma_out[e] = sigma;
-  }
-  if (ll) ll[b] = ll_acc;
-  if (reg) reg[b] = -entropy_weight * h_acc;
+  fwd_row(ms + b * 2 * p.A, b, p);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -144,11 +84,10 @@ extern "C" int mi_tanh_gauss_fwd_f32(const float* mean_and_std, const float* ext
   MI_REQUIRE(mean_and_std, "mi_tanh_gauss_fwd_f32: null mean_and_std");
   MI_REQUIRE(rng_state || (eps && eps2),
              "mi_tanh_gauss_fwd_f32: need rng_state or both injected noises");
-  Noise nz = {rng_state, offset_add, eps, eps2};
+  FwdParams p = {extras, {rng_state, offset_add, eps, eps2}, raw_out, action, mu_out, sigma_out,
+                 loglik, reg, (int)A, min_std, std_scale, entropy_weight, deterministic};
   hipLaunchKernelGGL(sampler_fwd_kernel, dim3((unsigned)mippo::ceil_div(B, kThreads)),
-                     dim3(kThreads), 0, mippo::as_stream(stream), mean_and_std, extras, nz,
-                     raw_out, action, loglik, reg, mu_out, sigma_out, B, (int)A, min_std,
-                     std_scale, entropy_weight, deterministic);
+                     dim3(kThreads), 0, mippo::as_stream(stream), mean_and_std, p, B);
   return mippo::check_launch("mi_tanh_gauss_fwd_f32");
 }
 

@@ -1,0 +1,87 @@
+// Row function of the tanh-Gaussian sampler forward
+// (reference: nnx_ppo/networks/sampling_layers.py:82-147), shared by the
+// stand-alone kernel (sampler.hip) and the fused policy step (mlp_bf16.hip) so
+// both evaluate the same fp32 expression sequence.
+#pragma once
+#include "common.h"
+#include "philox.h"
+
+namespace mippo_sampler {
+
+constexpr float kLog2 = 0.69314718055994530942f;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+__device__ inline float softplus(float x) {
+  // jax.nn.softplus = logaddexp(x, 0)
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ inline float log_det_jac(float z) {
+  // sampling_layers.py:133: 2 (log 2 - z - softplus(-2 z))
+  return 2.0f * (kLog2 - z - softplus(-2.0f * z));
+}
+
+struct Noise {
+  const uint64_t* rng;  // {seed, offset}; may be null when both eps are injected
+  uint64_t offset_add;
+  const float* eps;   // [B, A] injected action noise or null
+  const float* eps2;  // [B, A] injected entropy noise or null
+  __device__ inline void get(int64_t elem, float& e, float& e2) const {
+    if (eps && eps2) {
+      e = eps[elem];
+      e2 = eps2[elem];
+      return;
+    }
+    float pe, pe2;
+    mippo::philox_normal_pair(rng[0], rng[1] + offset_add, (uint64_t)elem, pe, pe2);
+    e = eps ? eps[elem] : pe;
+    e2 = eps2 ? eps2[elem] : pe2;
+  }
+};
+
+struct FwdParams {
+  const float* extras;  // [B, A] raw actions to score (replay) or null (sample)
+  Noise noise;
+  float* raw_out;       // each [B, A] or null
+  float* action;
+  float* mu_out;
+  float* sigma_out;
+  float* ll;            // [B] or null
+  float* reg;           // [B] or null
+  int A;
+  float min_std, std_scale, entropy_weight;
+  int deterministic;
+};
+
+// `row`: the 2A floats (mean | pre-softplus std) of batch row b.
+__device__ inline void fwd_row(const float* row, int64_t b, const FwdParams& p) {
+  const int A = p.A;
+  float ll_acc = 0.0f, h_acc = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    const int64_t e = b * A + a;
+    const float mu = row[a];
+    const float sigma = (softplus(row[A + a]) + p.min_std) * p.std_scale;
+    float eps, eps2;
+    p.noise.get(e, eps, eps2);
+    const float sampled = p.deterministic ? mu : mu + sigma * eps;
+    const float z = p.extras ? p.extras[e] : sampled;
+    // _loglikelihood, sampling_layers.py:118-135
+    const float q = (z - mu) / sigma;
+    float lp = -0.5f * (q * q) - (kHalfLog2Pi + logf(sigma));
+    lp -= log_det_jac(z);
+    ll_acc += lp;
+    // _entropy, sampling_layers.py:137-147
+    const float z2 = mu + sigma * eps2;
+    h_acc += (0.5f + kHalfLog2Pi + logf(sigma)) + log_det_jac(z2);
+    if (p.raw_out) p.raw_out[e] = z;
+    if (p.action) p.action[e] = tanhf(z);
+    if (p.mu_out) p.mu_out[e] = mu;
+    if (p.sigma_out) p.sigma_out[e] = sigma;
+  }
+  if (p.ll) p.ll[b] = ll_acc;
+  if (p.reg) p.reg[b] = -p.entropy_weight * h_acc;
+}
+
+}  // namespace mippo_sampler

@@ -58,8 +58,12 @@ def make_mlp_actor_critic(
     sampler = NormalTanhSampler(rngs, entropy_weight=entropy_weight, min_std=min_std,
                                 std_scale=std_scale)
     adapter = PPOAdapter(action=Sequential([*actor_layers, sampler]), value=critic)
+    # the same module tree as the reference's; `MLPActorCritic` is a `Sequential` that
+    # evaluates this particular tree in one launch on the bf16 path (networks/policy.py)
+    from .policy import MLPActorCritic
+
     if normalize_obs:
-        return Sequential([Normalizer(obs_size), adapter])
+        return MLPActorCritic([Normalizer(obs_size), adapter])
     return adapter
 
 

@@ -1,0 +1,187 @@
+"""The network `make_mlp_actor_critic` builds (`nnx_ppo/networks/factories.py:88-146`:
+`Sequential([Normalizer?, PPOAdapter(action=Sequential([Dense.., sampler]),
+value=Sequential([Dense..]))])`) with its evaluation as ONE launch on the bf16 path.
+
+Module tree, parameters, state / extras / metrics structure and every method are
+those of the plain `Sequential` — `MLPActorCritic` only recognises its own shape and
+routes `__call__` (rollout / inference) and `replay` / `replay_backward` (loss) to
+`mi_policy_fwd_bf16`: normaliser in the input stage, both trunks side by side
+(they read the same input, adapter.py:75-117), sampler on the action trunk's output.
+At this workload's sizes a policy step is bound by launch and dependency latency,
+not arithmetic: four launches on two streams become one.  Anything outside the
+pattern (PyTree observations, fp32 compute, CPU tensors, injected rollout extras,
+trunks the kernel cannot take) goes through the generic container path."""
+from __future__ import annotations
+
+import os
+from typing import Any
+
+import torch
+
+from .. import config, ops
+from . import dense_chain
+from .adapter import PPOAdapter, _Fork, _can_fork
+from .containers import Sequential
+from .feedforward import Dense
+from .normalizer import Normalizer
+from .sampling_layers import NormalTanhSampler
+from .types import PPONetworkOutput, StatefulModuleOutput
+
+
+# MIPPO_FUSED_POLICY=0 sends everything through the generic containers (A/B timing)
+FUSED = os.environ.get("MIPPO_FUSED_POLICY", "1") != "0"
+
+
+class MLPActorCritic(Sequential):
+    def __init__(self, layers):
+        super().__init__(layers)
+        adapter = self.layers[-1]
+        assert isinstance(adapter, PPOAdapter) and len(self.layers) == 2
+        self._norm = self.layers[0]
+        self._adapter = adapter
+
+    # ---- pattern ---------------------------------------------------------------------
+    def _parts(self):
+        a_layers = self._adapter.action.layers[:-1]
+        sampler = self._adapter.action.layers[-1]
+        c_layers = self._adapter.value.layers
+        return a_layers, sampler, c_layers
+
+    def _fusable(self, x, M: int) -> bool:
+        if not FUSED or config.compute_dtype() != "bf16" or not isinstance(x, torch.Tensor):
+            return False
+        if not x.is_cuda or x.dtype != torch.float32:
+            return False
+        norm = self._norm
+        if norm is not None and not (isinstance(norm, Normalizer)
+                                     and isinstance(norm.mean.value, torch.Tensor)
+                                     and norm.mean.value.dim() == 1):
+            return False
+        if not (isinstance(self._adapter.action, Sequential)
+                and isinstance(self._adapter.value, Sequential)):
+            return False
+        a_layers, sampler, c_layers = self._parts()
+        if type(sampler) is not NormalTanhSampler or not a_layers or not c_layers:
+            return False
+        if not all(type(l) is Dense for l in list(a_layers) + list(c_layers)):
+            return False
+        if a_layers[-1].out_features % 2 or a_layers[-1].out_features > 128:
+            return False
+        for layers in (a_layers, c_layers):
+            width = max(max(l.in_features, l.out_features) for l in layers)
+            if len(layers) > dense_chain.FUSED_MAX_LAYERS:
+                return False
+            if width > 256 and M > dense_chain.FUSED_WIDE_MAX_ROWS:
+                return False
+            if width > dense_chain.FUSED_MAX_WIDTH:
+                return False
+        return True
+
+    def _launch(self, x2: torch.Tensor, extras2, train: bool):
+        a_layers, sampler, c_layers = self._parts()
+        dense_chain.refresh(list(a_layers) + list(c_layers))  # one launch for both trunks
+        chain = lambda ls: ([l._ff for l in ls], [dense_chain._bias(l) for l in ls],
+                            [ls[0].in_features] + [l.out_features for l in ls],
+                            [l.act_code for l in ls])
+        norm = None
+        if self._norm is not None:
+            n = self._norm
+            norm = (n.mean.value, n.M2.value, n.counter.value, n.epsilon)
+        M = x2.shape[0]
+        A = a_layers[-1].out_features // 2
+        eps, eps2 = sampler._noise(M, A, x2.device)
+        off = sampler._next_offset()
+        r = ops.policy_fwd_bf16(
+            x2, norm, chain(a_layers), chain(c_layers), sampler._state(x2.device), off,
+            deterministic=sampler.deterministic, extras=extras2, eps=eps, eps2=eps2,
+            train=train, want_stats=not train, **sampler._kw())
+        return r, off, eps2
+
+    # ---- rollout / inference (adapter.py:75-117 over the whole stack) -----------------
+    def __call__(self, network_state, obs: Any, rollout_extras: Any = None):
+        if (rollout_extras is not None or not isinstance(obs, torch.Tensor) or obs.dim() != 2
+                or not self._fusable(obs, obs.shape[0])):
+            return super().__call__(network_state, obs, rollout_extras)
+        x2 = obs if obs.is_contiguous() else obs.contiguous()
+        r, _, _ = self._launch(x2, None, train=False)
+        a_layers, _, c_layers = self._parts()
+        value = r["value"]
+        if value.shape[-1] == 1:
+            value = value.squeeze(-1)
+        a_state = network_state[-1]["action"]
+        v_state = network_state[-1]["value"]
+        a_metrics = {i: {} for i in range(len(a_layers))}
+        a_metrics[len(a_layers)] = {"mu": r["mu"], "sigma": r["sigma"]}
+        adapter_out = dict(
+            next_state={"action": list(a_state), "value": list(v_state)},
+            metrics={"action": a_metrics, "value": {i: {} for i in range(len(c_layers))}},
+            rollout_extras={"action": [None] * len(a_layers) + [r["raw"]],
+                            "value": [None] * len(c_layers)})
+        pre = self._norm is not None
+        return StatefulModuleOutput(
+            next_state=([()] if pre else []) + [adapter_out["next_state"]],
+            output=PPONetworkOutput(actions=r["action"], loglikelihoods=r["log_likelihood"],
+                                    value_estimates=value),
+            regularization_loss=r["reg"],
+            metrics=dict(enumerate(([{}] if pre else []) + [adapter_out["metrics"]])),
+            rollout_extras=([obs] if pre else []) + [adapter_out["rollout_extras"]])
+
+    # ---- loss replay (ppo.py:411-431) ------------------------------------------------
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+        fus = (not need_input_grad and extras_seq is not None
+               and isinstance(x_seq, torch.Tensor) and x_seq.dim() == 3
+               and self._fusable(x_seq, x_seq.shape[0] * x_seq.shape[1]))
+        if not fus:
+            ctx, out, reg, fs = super().replay(state0, x_seq, done_seq, extras_seq,
+                                               need_input_grad)
+            return ("generic", ctx), out, reg, fs
+        T, B, K0 = x_seq.shape
+        M = T * B
+        a_layers, sampler, c_layers = self._parts()
+        A = a_layers[-1].out_features // 2
+        raw = extras_seq[-1]["action"][len(a_layers)]
+        ex2 = raw.reshape(M, A)
+        if not ex2.is_contiguous():
+            ex2 = ex2.contiguous()
+        x2 = x_seq.reshape(M, K0)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r, off, eps2 = self._launch(x2, ex2, train=True)
+        value = r["value"].view(T, B, -1)
+        squeezed = value.shape[-1] == 1
+        if squeezed:
+            value = value.squeeze(-1)
+        out = PPONetworkOutput(actions=None, loglikelihoods=r["log_likelihood"].view(T, B),
+                               value_estimates=value)
+        s_ctx = (r["mean_and_std"], ex2, off, eps2, (T, B, 2 * A))
+        shadows = lambda ls, saved: [(xb, aux, dense_chain._shadows(l)[0])
+                                     for (xb, aux), l in zip(saved, ls)]
+        ctx = ("fused", s_ctx, (shadows(a_layers, r["actor_saved"]), M, False),
+               (shadows(c_layers, r["critic_saved"]), M, False), squeezed, (T, B))
+        pre = self._norm is not None
+        final_state = ([()] if pre else []) + [{"action": list(state0[-1]["action"]),
+                                                "value": list(state0[-1]["value"])}]
+        return ctx, out, r["reg"].view(T, B), final_state
+
+    def replay_backward(self, ctx, g_out, g_reg):
+        if ctx[0] == "generic":
+            return super().replay_backward(ctx[1], g_out, g_reg)
+        _, s_ctx, a_ctx, v_ctx, squeezed, (T, B) = ctx
+        a_layers, sampler, c_layers = self._parts()
+        M = T * B
+        g_v = g_out.value_estimates.reshape(M, -1)
+        if not g_v.is_contiguous():
+            g_v = g_v.contiguous()
+        g_ms = sampler.replay_backward(s_ctx, {"action": None,
+                                               "log_likelihood": g_out.loglikelihoods}, g_reg)
+        g_ms = g_ms.reshape(M, g_ms.shape[-1])
+        if _can_fork(g_v):
+            fork = _Fork(g_v)
+            with fork:
+                dense_chain.backward(c_layers, v_ctx, g_v)
+            dense_chain.backward(a_layers, a_ctx, g_ms)
+            fork.join()
+        else:
+            dense_chain.backward(a_layers, a_ctx, g_ms)
+            dense_chain.backward(c_layers, v_ctx, g_v)
+        return None

@@ -421,6 +421,82 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
     return out, saved
 
 
+def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_add: int, *,
+                    min_std: float, std_scale: float, entropy_weight: float,
+                    deterministic: bool, extras=None, eps=None, eps2=None, train: bool = False,
+                    want_stats: bool = True):
+    """Normaliser -> action trunk -> sampler and value trunk in ONE launch
+    (`mi_policy_fwd_bf16`).  `norm` = (mean, m2, counter, eps) | None; `actor` / `critic`
+    = (frag images, biases, dims, acts).  Returns a dict: raw, action, log_likelihood,
+    reg, mu, sigma, value and — training — mean_and_std, actor_saved, critic_saved
+    (per-layer (x_bf, aux_bf) as `mlp_fwd_bf16`)."""
+    M, K0 = obs.shape
+    dev = obs.device
+    (a_w, a_b, a_dims, a_acts), (c_w, c_b, c_dims, c_acts) = actor, critic
+    La, Lc = len(a_w), len(c_w)
+    _need(a_dims[0] == K0 and c_dims[0] == K0, "policy_fwd_bf16: trunk inputs must match obs")
+    A2 = a_dims[-1]
+    A = A2 // 2
+    if extras is not None:
+        _need(extras.shape == (M, A), "policy_fwd_bf16: extras must be [M, A]")
+    mk = lambda *sh: torch.empty(*sh, dtype=f32, device=dev)
+    replay = extras is not None
+    raw = None if replay else mk(M, A)
+    action = None if replay else mk(M, A)
+    ll, reg = mk(M), mk(M)
+    mu = mk(M, A) if want_stats else None
+    sigma = mk(M, A) if want_stats else None
+    value = mk(M, c_dims[-1])
+    ms = mk(M, A2) if train else None
+
+    def images(L, dims, acts):
+        if not train:
+            return None, None, None
+        y, pre = [None] * L, [None] * L
+        for l in range(L):
+            if l < L - 1 or acts[l] != ACT_NONE:
+                y[l] = _bf_buf(M, dims[l + 1], dev)
+            if acts[l] == ACT_SWISH:
+                pre[l] = _bf_buf(M, dims[l + 1], dev)
+        return y, pre, _bf_buf(M, K0, dev)
+
+    a_y, a_pre, a_x = images(La, a_dims, a_acts)
+    c_y, c_pre, c_x = images(Lc, c_dims, c_acts)
+    arr = lambda ts, L: None if ts is None else (ctypes.c_void_p * L)(*[ptr(t) for t in ts])
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    n_mean, n_m2, n_cnt, n_eps = norm if norm is not None else (None, None, None, 0.0)
+    if profiler.active:
+        flop = sum(a_dims[l] * a_dims[l + 1] for l in range(La)) \
+            + sum(c_dims[l] * c_dims[l + 1] for l in range(Lc))
+        profiler.next_flops = 2.0 * M * flop
+        kept = sum(t.numel() * 2 for t in [a_x, c_x, *(a_y or []), *(a_pre or []),
+                                           *(c_y or []), *(c_pre or [])] if t is not None)
+        w_bytes = sum(2 * a_dims[l] * a_dims[l + 1] for l in range(La)) \
+            + sum(2 * c_dims[l] * c_dims[l + 1] for l in range(Lc))
+        outs = sum(t.numel() * 4 for t in [raw, action, ll, reg, mu, sigma, value, ms, extras]
+                   if t is not None)
+        profiler.next_bytes = 4.0 * M * K0 + w_bytes + kept + outs
+    check(lib().mi_policy_fwd_bf16(
+        ptr(obs, f32), M, ptr(n_mean, f32), ptr(n_m2, f32), ptr(n_cnt, f32), float(n_eps),
+        La, arr(a_w, La), arr(a_b, La), i64s(a_dims), i64s(a_acts),
+        Lc, arr(c_w, Lc), arr(c_b, Lc), i64s(c_dims), i64s(c_acts),
+        ptr(extras, f32), ptr(rng_state), int(offset_add), ptr(eps, f32), ptr(eps2, f32),
+        float(min_std), float(std_scale), float(entropy_weight), int(bool(deterministic)),
+        ptr(ms, f32), ptr(raw, f32), ptr(action, f32), ptr(ll, f32), ptr(reg, f32),
+        ptr(mu, f32), ptr(sigma, f32), ptr(value, f32),
+        arr(a_y, La), arr(a_pre, La), ptr(a_x), arr(c_y, Lc), arr(c_pre, Lc), ptr(c_x),
+        stream()), "mi_policy_fwd_bf16")
+    out = dict(raw=extras if replay else raw, action=action, log_likelihood=ll, reg=reg, mu=mu,
+               sigma=sigma, value=value, mean_and_std=ms)
+    if train:
+        def saved(L, acts, x_bf, y, pre):
+            return [((x_bf if l == 0 else y[l - 1]), (pre[l] if acts[l] == ACT_SWISH else y[l]))
+                    for l in range(L)]
+        out["actor_saved"] = saved(La, a_acts, a_x, a_y, a_pre)
+        out["critic_saved"] = saved(Lc, c_acts, c_x, c_y, c_pre)
+    return out
+
+
 def mlp_bwd_dx_bf16(g_out: torch.Tensor, aux_last, act_last: int, w_bfs: list, dims: list,
                     acts: list, auxs: list, need_input_grad: bool):
     """Fused dX chain of an MLP trunk.  Returns (dz list per layer [L], g_in | None):

@@ -400,7 +400,7 @@ def from_product(net: Any, dtype=DTYPE) -> Module:
     """Build the oracle twin of a product network by duck-typing on class names
     and copying its weights / statistics / noise seeds (no product import)."""
     name = type(net).__name__
-    if name == "Sequential":
+    if name in ("Sequential", "MLPActorCritic"):  # the latter is a Sequential (policy.py)
         return Sequential([from_product(l, dtype) for l in net.layers])
     if name == "PPOAdapter":
         return PPOAdapter(from_product(net.action, dtype), from_product(net.value, dtype))

@@ -1,0 +1,114 @@
+"""One-launch policy evaluation (`mi_policy_fwd_bf16`, networks/policy.py) against the
+generic container path it replaces: the same normaliser expression, the same trunk
+code and the same sampler row function, so every output — actions, log-likelihoods,
+values, regulariser, extras, saved images, gradients — must be BIT-identical."""
+import pytest
+import torch
+
+from nnx_ppo_amd import config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16():
+    prev = config.compute_dtype()
+    config.set_compute_dtype("bf16")
+    yield
+    config.set_compute_dtype(prev)
+
+
+def _net(dev, obs, act_dim, actor_h, critic_h, activation, seed=3):
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+
+    net = factories.make_mlp_actor_critic(obs, act_dim, actor_h, critic_h, Rngs(seed),
+                                          activation=activation)
+    net.to(dev)
+    # non-trivial normaliser statistics
+    n = net.layers[0]
+    g = torch.Generator().manual_seed(seed)
+    n.mean.value.copy_(torch.randn(obs, generator=g))
+    n.M2.value.copy_(torch.rand(obs, generator=g) * 50 + 1)
+    n.counter.value.fill_(37.0)
+    return net
+
+
+def _sampler(net):
+    return net.layers[-1].action.layers[-1]
+
+
+def _leaves(x):
+    from nnx_ppo_amd.tree import tree_leaves
+
+    return [t for t in tree_leaves(x) if isinstance(t, torch.Tensor)]
+
+
+@pytest.mark.parametrize("M", [1, 100, 4096, 9000])
+@pytest.mark.parametrize("activation", ["relu", "tanh", "swish"])
+@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [256] * 2, [128])])
+def test_rollout_call_is_bit_identical_to_generic(dev, bf16, M, activation, shape):
+    from nnx_ppo_amd.networks.containers import Sequential
+    from nnx_ppo_amd.networks.policy import MLPActorCritic
+
+    obs_dim, act_dim, ah, ch = shape
+    net = _net(dev, obs_dim, act_dim, ah, ch, activation)
+    assert isinstance(net, MLPActorCritic)
+    x = torch.randn(M, obs_dim, generator=torch.Generator().manual_seed(M)).to(dev)
+    state = net.initialize_state(M)
+    smp = _sampler(net)
+    for deterministic in (False, True):
+        smp.deterministic = deterministic
+        smp._pending = 5
+        fused = net(state, x)
+        smp._pending = 5
+        plain = Sequential.__call__(net, state, x)
+        for name in ("next_state", "output", "regularization_loss", "metrics", "rollout_extras"):
+            a, b = _leaves(getattr(fused, name)), _leaves(getattr(plain, name))
+            assert len(a) == len(b) and len(a) > 0 or name == "next_state", name
+            for u, v in zip(a, b):
+                assert u.shape == v.shape and torch.equal(u, v), name
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("T,B", [(3, 7), (30, 1024)])
+@pytest.mark.parametrize("activation", ["relu", "swish"])
+def test_replay_and_gradients_bit_identical_to_generic(dev, bf16, T, B, activation):
+    from nnx_ppo_amd.networks.containers import Sequential
+    from nnx_ppo_amd.networks.types import PPONetworkOutput, bump_param_epoch
+    from nnx_ppo_amd.optim import Optimizer
+
+    net = _net(dev, 5, 2, [64, 64], [256, 256], activation)
+    opt = Optimizer(net, 1e-3, None, None, device=dev)
+    g = torch.Generator().manual_seed(T * B)
+    x_seq = torch.randn(T, B, 5, generator=g).to(dev)
+    done = torch.zeros(T, B, dtype=torch.bool, device=dev)
+    state = net.initialize_state(B)
+    smp = _sampler(net)
+    # rollout extras as a rollout would have stacked them
+    steps = [net(state, x_seq[t]).rollout_extras for t in range(T)]
+    from nnx_ppo_amd.tree import tree_map
+
+    extras = tree_map(lambda *xs: torch.stack(xs, 0), steps[0], *steps[1:])
+    g_ll = torch.randn(T, B, generator=g).to(dev)
+    g_v = torch.randn(T, B, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        bump_param_epoch()
+        opt.begin()
+        smp._pending = 11
+        if fused:
+            ctx, out, reg, fs = net.replay(state, x_seq, done, extras, need_input_grad=False)
+            assert ctx[0] == "fused"
+            net.replay_backward(ctx, PPONetworkOutput(None, g_ll, g_v), 1.0 / (T * B))
+        else:
+            ctx, out, reg, fs = Sequential.replay(net, state, x_seq, done, extras,
+                                                  need_input_grad=False)
+            Sequential.replay_backward(net, ctx, PPONetworkOutput(None, g_ll, g_v),
+                                       1.0 / (T * B))
+        torch.cuda.synchronize()
+        res.append((out.loglikelihoods.clone(), out.value_estimates.clone(), reg.clone(),
+                    opt.grads.clone()))
+    for a, b in zip(*res):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert float(res[0][3].abs().sum()) > 0
