@@ -51,6 +51,8 @@ GEMM_SYMBOLS = {
     "mi_dense_bwd_dw_bf16": lambda a: (a[2], a[3], a[4]),   # ldx lddz M K N acc
     "mi_mlp_fwd_bf16": None,                                # flops annotated by the wrapper
     "mi_mlp_bwd_dx_bf16": None,
+    "mi_policy_fwd_bf16": None,
+    "mi_policy_bwd_bf16": None,
     "mi_dense_bwd_dw_grouped_bf16": None,
 }
 
@@ -132,6 +134,11 @@ def roofline_of_dominant_kernel(env, ts):
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 M = ints[1] if name == "mi_mlp_bwd_dx_bf16" else ints[0]
                 add(f"mlp_chain_kernel<{1 if M <= 8192 else 4}, {bwd}>", t_ms, work)
+        if name in ("mi_policy_fwd_bf16", "mi_policy_bwd_bf16"):
+            kern = "policy_kernel" if name == "mi_policy_fwd_bf16" else "policy_bwd_kernel"
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                M = ints[0] if name == "mi_policy_fwd_bf16" else ints[1]  # (offset_add, M, ..)
+                add(f"{kern}<{1 if M <= 8192 else 4}>", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("dW group (tn_gemm_dw_kernel x tile classes + reduce_slabs_grouped)",
@@ -162,7 +169,8 @@ def roofline_of_dominant_kernel(env, ts):
     pmc = Path(__file__).resolve().parent / "profiles" / "r01_pmc_traffic.json"
     if pmc.exists():
         traffic_db = json.loads(pmc.read_text()).get("kernels", {})
-    trunk = {k: v for k, v in classes.items() if k.startswith("mlp_chain_kernel")}
+    trunk = {k: v for k, v in classes.items()
+             if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel"))}
     if trunk:
         # Dominant kernel = the trunk class with the most device time.  Its arithmetic
         # intensity (~100-150 flop/B with the activations kept for the backward) is below

@@ -259,6 +259,20 @@ int mi_policy_fwd_bf16(
     void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
     void* c_x_bf, mi_stream_t stream);
 
+/* Backward of mi_policy_fwd_bf16's replay form in ONE launch: the sampler backward
+ * (arguments as mi_tanh_gauss_bwd_f32) produces the action trunk's output gradient
+ * in the kernel's input stage, g_value [M, c_dims[Lc]] is the value trunk's; both dX
+ * chains then run as mi_mlp_bwd_dx_bf16 (a_* / c_* as there, no input gradient).
+ * Every dz (bf16) is written for mi_dense_bwd_dw_grouped_bf16. */
+int mi_policy_bwd_bf16(
+    const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, const float* g_loglik, float g_reg, float min_std,
+    float std_scale, float entropy_weight, const float* g_value, int64_t M, int64_t La,
+    const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
+    const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
+    const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf, mi_stream_t stream);
+
 /* The dX chain of the same trunk in ONE launch (the backward twin of
  * mi_mlp_fwd_bf16): from g_out [M][N_{L-1}] (fp32; times act'_{L-1}(aux_last) if
  * act_last != MI_ACT_NONE) it produces dz_last [M][pad8 N_{L-1}] (bf16) and, walking
@@ -328,12 +342,15 @@ int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out, void* wor
                        mi_stream_t stream);
 
 /* optax.chain([clip_by_global_norm(max_norm)]?, adam | adamw) over flat arenas
- * (`ppo.py:555-569`).  step: device int64 holding t (already advanced);
- * grad_norm (nullable): device scalar from mi_global_norm_f32, enables clipping;
- * weight_decay = 0 gives plain adam. */
-int mi_adam_step_f32(float* params, const float* grads, float* m, float* v, int64_t n,
-                     float lr, float b1, float b2, float eps, float weight_decay,
-                     const int64_t* step, const float* grad_norm, float max_norm,
+ * (`ppo.py:555-569`).  grad_norm (nullable): device scalar from mi_global_norm_f32,
+ * enables clipping; weight_decay = 0 gives plain adam.
+ * begin_next_ticket == null: step holds t, already advanced by mi_begin_grad_step_f32.
+ * begin_next_ticket != null (16 bytes, ZERO before the first call, left zero): step
+ * holds the number of COMPLETED steps; the launch uses t = step + 1, stores it, and
+ * zeroes grads after reading them — it is the next step's mi_begin_grad_step_f32. */
+int mi_adam_step_f32(float* params, float* grads, float* m, float* v, int64_t n, float lr,
+                     float b1, float b2, float eps, float weight_decay, int64_t* step,
+                     const float* grad_norm, float max_norm, void* begin_next_ticket,
                      mi_stream_t stream);
 
 /* ---- a5 / a7: data movement ---------------------------------------------- */

@@ -73,8 +73,10 @@ struct PolicyExtra {
   const float* norm_m2;
   const float* norm_count;  // [1]
   float norm_eps;
-  mippo_sampler::FwdParams samp;  // samp.A == 0: no sampler
+  mippo_sampler::FwdParams samp;  // forward: samp.A == 0: no sampler
   int ms_off;               // LDS byte offset of the fp32 [ROWS][2A] sampler input
+  mippo_sampler::BwdParams sbwd;  // backward: the action trunk's output gradient comes
+                                  // from the sampler backward (sbwd.A == 0: from c.x)
 };
 struct PolicyArgs {
   Chain c[2];
@@ -154,11 +156,29 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   load_frags(s, B);
 
   // stage 0: fp32 input tile (x act'(aux0) in the backward) -> bf16, zero padded
-  for (int i = tid; i < ROWS * K0p; i += kThreads) {
+  bool from_sampler = false;
+  if constexpr (POLICY && BWD) from_sampler = px->sbwd.A > 0 && blockIdx.y == 0;
+  if constexpr (POLICY && BWD) {
+    if (from_sampler) {
+      // sampling_layers.py:82-147 differentiated: one thread per row writes the 2A
+      // gradient columns (K0 == 2A); the others clear the pad columns
+      for (int row = tid; row < ROWS; row += kThreads) {
+        bf16_t* dst = act0 + row * arow;
+        if (i0 + row < c.M) {
+          mippo_sampler::bwd_row(i0 + row, px->sbwd, [dst](int j, float v) { dst[j] = (bf16_t)v; });
+        } else {
+          for (int k = 0; k < K0; ++k) dst[k] = (bf16_t)0.0f;
+        }
+      }
+      for (int i = tid; i < ROWS * (K0p - K0); i += kThreads)
+        act0[(i / (K0p - K0)) * arow + K0 + i % (K0p - K0)] = (bf16_t)0.0f;
+    }
+  }
+  for (int i = tid; i < (from_sampler ? 0 : ROWS * K0p); i += kThreads) {
     const int row = i / K0p, k = i % K0p;
     const int64_t gi = i0 + row;
     float v = (gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f;
-    if constexpr (POLICY) {
+    if constexpr (POLICY && !BWD) {
       // normalizer.py:76-81,92-96 — the same fp32 expression as normalize_fwd_kernel
       if (px->norm_mean && gi < c.M && k < K0) {
         const float cnt = *px->norm_count;
@@ -189,8 +209,12 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     const bool keep = !last || ly.out_bf;
     const bool to_out = last && c.out;
     // action trunk of a policy step: the sampler reads the fp32 output row from LDS
-    const bool to_ms = POLICY && last && px->samp.A > 0 && blockIdx.y == 0;
-    float* const ms_s = POLICY ? reinterpret_cast<float*>(lds_raw + px->ms_off) : nullptr;
+    bool to_ms = false;
+    float* ms_s = nullptr;
+    if constexpr (POLICY && !BWD) {
+      to_ms = last && px->samp.A > 0 && blockIdx.y == 0;
+      ms_s = reinterpret_cast<float*>(lds_raw + px->ms_off);
+    }
     const bool store_pre = !BWD && TRANS && ly.pre_bf;
     const bool use_aux = BWD && ly.aux && ly.act != MI_ACT_NONE;
     const int Np = (ly.N + 31) / 32 * 32;  // the next layer reduces over Np columns
@@ -233,7 +257,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
             if (j0 + e >= ly.N) v = 0.0f;  // pad columns (weights are zero there)
             vo[e] = (bf16_t)v;
             if (to_out && gi < c.M && j0 + e < ly.N) c.out[gi * ly.N + j0 + e] = v;
-            if constexpr (POLICY) {
+            if constexpr (POLICY && !BWD) {
               if (to_ms && j0 + e < ly.N) ms_s[row * ly.N + j0 + e] = v;
             }
           }
@@ -317,7 +341,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
       for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
     s = sn;
   }
-  if constexpr (POLICY) {
+  if constexpr (POLICY && !BWD) {
     // sampling_layers.py:82-147 on this workgroup's rows (the last layer's barrier
     // has published ms_s); one thread per row, as in sampler_fwd_kernel
     if (px->samp.A > 0 && blockIdx.y == 0) {
@@ -338,6 +362,12 @@ template <int RT>
 __global__ void __launch_bounds__(kThreads)
 policy_kernel(PolicyArgs a) {
   chain_body<RT, false, true>(a.c[blockIdx.y], &a.px);
+}
+
+template <int RT>
+__global__ void __launch_bounds__(kThreads)
+policy_bwd_kernel(PolicyArgs a) {
+  chain_body<RT, true, true>(a.c[blockIdx.y], &a.px);
 }
 
 template <int RT, bool BWD>
@@ -494,19 +524,21 @@ extern "C" int mi_policy_fwd_bf16(
   return launch_policy<4>(a, maxw, st);
 }
 
-extern "C" int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int act_last,
-                                  int64_t M, int64_t L, const void* const* w_bf,
-                                  const int64_t* dims, const int64_t* acts,
-                                  const void* const* aux, void* dz_last, void* const* dz_bf,
-                                  float* g_in, mi_stream_t stream) {
-  MI_REQUIRE(M >= 0 && L >= 1 && L <= CH_MAXL, "mi_mlp_bwd_dx_bf16: 1 <= L <= %d", CH_MAXL);
-  if (M == 0) return 0;
-  MI_REQUIRE(g_out && w_bf && dims && acts && dz_last, "mi_mlp_bwd_dx_bf16: null pointer");
-  MI_REQUIRE(act_last >= MI_ACT_NONE && act_last <= MI_ACT_SWISH, "mi_mlp_bwd_dx_bf16: bad act");
-  MI_REQUIRE(act_last == MI_ACT_NONE || aux_last, "mi_mlp_bwd_dx_bf16: aux_last needed");
-  // walk the layers backwards: step q handles layer l = L-1-q:  dz_{l-1} = dz_l . W_l^T
+namespace {
+
+// Fills a backward (dX) Chain from the C-ABI arrays (mi_mlp_bwd_dx_bf16,
+// mi_policy_bwd_bf16).  Walks the layers backwards: step q handles layer
+// l = L-1-q:  dz_{l-1} = dz_l . W_l^T.
+int fill_bwd_chain(Chain& c, const char* who, const float* g_out, const void* aux_last,
+                   int act_last, int64_t M, int64_t L, const void* const* w_bf,
+                   const int64_t* dims, const int64_t* acts, const void* const* aux,
+                   void* dz_last, void* const* dz_bf, float* g_in, int* maxw_out) {
+  MI_REQUIRE(L >= 1 && L <= CH_MAXL, "%s: 1 <= L <= %d", who, CH_MAXL);
+  MI_REQUIRE(w_bf && dims && acts && dz_last, "%s: null pointer", who);
+  MI_REQUIRE(act_last >= MI_ACT_NONE && act_last <= MI_ACT_SWISH, "%s: bad act", who);
+  MI_REQUIRE(act_last == MI_ACT_NONE || aux_last, "%s: aux_last needed", who);
   const int steps = (int)(g_in ? L : L - 1);
-  Chain c = {};
+  c = {};
   c.x = g_out;
   c.M = M;
   c.L = steps;
@@ -516,35 +548,109 @@ extern "C" int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int 
   c.x_bf = static_cast<bf16_t*>(dz_last);
   c.ldx = mippo::ceil_div(dims[L], 8) * 8;
   c.out = g_in;
-  MI_REQUIRE(al16(dz_last) && al16(aux_last), "mi_mlp_bwd_dx_bf16: buffers must be 16-byte aligned");
+  MI_REQUIRE(al16(dz_last) && al16(aux_last), "%s: buffers must be 16-byte aligned", who);
   int maxw = (int)(mippo::ceil_div(dims[L], 32) * 32);
   for (int l = 0; l <= L; ++l)
-    MI_REQUIRE(dims[l] >= 1 && dims[l] <= 512, "mi_mlp_bwd_dx_bf16: widths must be in [1, 512]");
-  MI_REQUIRE(steps >= 1, "mi_mlp_bwd_dx_bf16: nothing to do (L == 1 without input gradient: "
-                         "use mi_cast_pad_bf16)");
+    MI_REQUIRE(dims[l] >= 1 && dims[l] <= 512, "%s: widths must be in [1, 512]", who);
+  MI_REQUIRE(steps >= 1, "%s: nothing to do (L == 1 without input gradient: use mi_cast_pad_bf16)",
+             who);
   for (int q = 0; q < steps; ++q) {
     const int l = (int)L - 1 - q;
     const int64_t K = dims[l], N = dims[l + 1];  // layer l maps K -> N; here reduce N, emit K
-    MI_REQUIRE(w_bf[l] && al16(w_bf[l]), "mi_mlp_bwd_dx_bf16: weights must be 16-byte aligned");
+    MI_REQUIRE(w_bf[l] && al16(w_bf[l]), "%s: weights must be 16-byte aligned", who);
     ChainLayer& ly = c.layer[q];
     ly.w = static_cast<const bf16_t*>(w_bf[l]);
     ly.K = (int)N;
     ly.N = (int)K;
     ly.ldo = mippo::ceil_div(K, 8) * 8;
     if (l > 0) {
-      MI_REQUIRE(acts[l - 1] >= MI_ACT_NONE && acts[l - 1] <= MI_ACT_SWISH,
-                 "mi_mlp_bwd_dx_bf16: bad act");
+      MI_REQUIRE(acts[l - 1] >= MI_ACT_NONE && acts[l - 1] <= MI_ACT_SWISH, "%s: bad act", who);
       ly.act = (int)acts[l - 1];
       ly.aux = (aux && ly.act != MI_ACT_NONE) ? static_cast<const bf16_t*>(aux[l - 1]) : nullptr;
-      MI_REQUIRE(ly.act == MI_ACT_NONE || ly.aux, "mi_mlp_bwd_dx_bf16: aux[%d] needed", l - 1);
+      MI_REQUIRE(ly.act == MI_ACT_NONE || ly.aux, "%s: aux[%d] needed", who, l - 1);
       ly.out_bf = dz_bf ? static_cast<bf16_t*>(dz_bf[l - 1]) : nullptr;
-      MI_REQUIRE(ly.out_bf, "mi_mlp_bwd_dx_bf16: dz_bf[%d] needed", l - 1);
-      MI_REQUIRE(al16(ly.out_bf) && al16(ly.aux), "mi_mlp_bwd_dx_bf16: buffers must be 16-byte aligned");
+      MI_REQUIRE(ly.out_bf, "%s: dz_bf[%d] needed", who, l - 1);
+      MI_REQUIRE(al16(ly.out_bf) && al16(ly.aux), "%s: buffers must be 16-byte aligned", who);
     } else {
       ly.act = MI_ACT_NONE;  // input gradient: no activation upstream
     }
     const int w = (int)(mippo::ceil_div(K > N ? K : N, 32) * 32);
     if (w > maxw) maxw = w;
   }
+  *maxw_out = maxw;
+  return 0;
+}
+
+template <int RT>
+int launch_policy_bwd(PolicyArgs& a, int maxw, hipStream_t st) {
+  constexpr int ROWS = 16 * RT;
+  const size_t lds = (size_t)2 * ROWS * (maxw + 8) * sizeof(bf16_t);
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&policy_bwd_kernel<RT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROWS * (512 + 8) * (int)sizeof(bf16_t));
+  MI_REQUIRE(attr == hipSuccess, "policy_bwd_kernel: cannot raise the dynamic LDS limit: %s",
+             hipGetErrorString(attr));
+  hipLaunchKernelGGL((policy_bwd_kernel<RT>), dim3((unsigned)mippo::ceil_div(a.c[0].M, ROWS), 2),
+                     dim3(kThreads), lds, st, a);
+  return mippo::check_launch("mi_policy_bwd_bf16");
+}
+
+}  // namespace
+
+extern "C" int mi_mlp_bwd_dx_bf16(const float* g_out, const void* aux_last, int act_last,
+                                  int64_t M, int64_t L, const void* const* w_bf,
+                                  const int64_t* dims, const int64_t* acts,
+                                  const void* const* aux, void* dz_last, void* const* dz_bf,
+                                  float* g_in, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_mlp_bwd_dx_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(g_out, "mi_mlp_bwd_dx_bf16: null pointer");
+  Chain c;
+  int maxw = 0;
+  int rc = fill_bwd_chain(c, "mi_mlp_bwd_dx_bf16", g_out, aux_last, act_last, M, L, w_bf, dims,
+                          acts, aux, dz_last, dz_bf, g_in, &maxw);
+  if (rc) return rc;
   return launch_chain<true>(c, maxw, mippo::as_stream(stream));
+}
+
+extern "C" int mi_policy_bwd_bf16(
+    const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, const float* g_loglik, float g_reg, float min_std,
+    float std_scale, float entropy_weight, const float* g_value, int64_t M, int64_t La,
+    const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
+    const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
+    const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_policy_bwd_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(mean_and_std && extras && g_value && a_dims && c_dims && a_acts && c_acts,
+             "mi_policy_bwd_bf16: null pointer");
+  MI_REQUIRE(rng_state || eps2, "mi_policy_bwd_bf16: need rng_state or injected eps2");
+  MI_REQUIRE(La >= 2 && Lc >= 2, "mi_policy_bwd_bf16: trunks of at least two layers");
+  MI_REQUIRE(a_acts[La - 1] == MI_ACT_NONE && c_acts[Lc - 1] == MI_ACT_NONE,
+             "mi_policy_bwd_bf16: the trunks' last layers must be linear");
+  const int64_t A2 = a_dims[La];
+  MI_REQUIRE(A2 >= 2 && A2 % 2 == 0 && A2 <= 128,
+             "mi_policy_bwd_bf16: the action trunk must end in 2A <= 128 columns");
+  PolicyArgs a;
+  int wa = 0, wc = 0;
+  // the action trunk's output gradient is produced in the kernel: c.x is unused there
+  int rc = fill_bwd_chain(a.c[0], "mi_policy_bwd_bf16(action)", mean_and_std, nullptr,
+                          MI_ACT_NONE, M, La, a_w, a_dims, a_acts, a_aux, a_dz_last, a_dz_bf,
+                          nullptr, &wa);
+  if (rc) return rc;
+  rc = fill_bwd_chain(a.c[1], "mi_policy_bwd_bf16(value)", g_value, nullptr, MI_ACT_NONE, M, Lc,
+                      c_w, c_dims, c_acts, c_aux, c_dz_last, c_dz_bf, nullptr, &wc);
+  if (rc) return rc;
+  a.c[0].arow = wa + 8;
+  a.c[1].arow = wc + 8;
+  a.px = {};
+  a.px.sbwd = {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
+               (int)(A2 / 2), min_std, std_scale, entropy_weight};
+  const int maxw = wa > wc ? wa : wc;
+  hipStream_t st = mippo::as_stream(stream);
+  if (M <= 8192) return launch_policy_bwd<1>(a, maxw, st);
+  MI_REQUIRE(maxw <= 256, "mi_policy_bwd_bf16: trunks wider than 256 take at most 8192 rows "
+                          "(use mi_mlp_bwd_dx_bf16 per trunk)");
+  return launch_policy_bwd<4>(a, maxw, st);
 }

@@ -56,11 +56,16 @@ __global__ void norm_finalize_kernel(const double* partials, int G, float* norm_
 }
 
 __global__ void __launch_bounds__(kThreads)
-adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-            float weight_decay, const int64_t* __restrict__ step,
-            const float* __restrict__ grad_norm, float max_norm) {
-  const float t = (float)(*step);
+            float weight_decay, int64_t* __restrict__ step,
+            const float* __restrict__ grad_norm, float max_norm, unsigned int* ticket) {
+  // ticket != null: this launch also opens the NEXT gradient step — it counts itself
+  // (t = step + 1, stored by the last block to finish, after every block has read
+  // `step`) and leaves the gradient arena zeroed, so no separate
+  // mi_begin_grad_step_f32 launch sits between two minibatches.
+  const int64_t s0 = *step;
+  const float t = (float)(ticket ? s0 + 1 : s0);
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2 = 1.0f - powf(b2, t);
   float gscale = 1.0f;
@@ -83,6 +88,13 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     const float pi = p[i];
     if (weight_decay != 0.0f) u += weight_decay * pi;
     p[i] = pi - lr * u;
+    if (ticket) g[i] = 0.0f;
+  }
+  if (ticket) {
+    if (mippo::last_block_ticket(ticket) && threadIdx.x == 0) {
+      *step = s0 + 1;
+      *ticket = 0;
+    }
   }
 }
 
@@ -123,13 +135,14 @@ extern "C" int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out
   return mippo::check_launch("mi_global_norm_f32(finalize)");
 }
 
-extern "C" int mi_adam_step_f32(float* params, const float* grads, float* m, float* v,
-                                int64_t n, float lr, float b1, float b2, float eps,
-                                float weight_decay, const int64_t* step,
-                                const float* grad_norm, float max_norm, mi_stream_t stream) {
+extern "C" int mi_adam_step_f32(float* params, float* grads, float* m, float* v, int64_t n,
+                                float lr, float b1, float b2, float eps, float weight_decay,
+                                int64_t* step, const float* grad_norm, float max_norm,
+                                void* begin_next_ticket, mi_stream_t stream) {
   MI_REQUIRE(n >= 1 && params && grads && m && v && step, "mi_adam_step_f32: bad arguments");
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
                      mippo::as_stream(stream), params, grads, m, v, n, lr, b1, b2, eps,
-                     weight_decay, step, grad_norm, max_norm);
+                     weight_decay, step, grad_norm, max_norm,
+                     static_cast<unsigned int*>(begin_next_ticket));
   return mippo::check_launch("mi_adam_step_f32");
 }

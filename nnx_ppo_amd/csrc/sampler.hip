@@ -23,36 +23,11 @@ sampler_fwd_kernel(const float* __restrict__ ms, FwdParams p, int64_t B) {
 }
 
 __global__ void __launch_bounds__(kThreads)
-sampler_bwd_kernel(const float* __restrict__ ms, const float* __restrict__ extras,
-                   Noise noise, const float* __restrict__ g_ll, float g_reg,
-                   float* __restrict__ g_ms, int64_t B, int A, float min_std,
-                   float std_scale, float entropy_weight) {
+sampler_bwd_kernel(BwdParams p, float* __restrict__ g_ms, int64_t B) {
   const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (b >= B) return;
-  const float* row = ms + b * 2 * A;
-  float* grow = g_ms + b * 2 * A;
-  const float gl = g_ll ? g_ll[b] : 0.0f;
-  const float gh = -entropy_weight * g_reg;  // d loss / d H
-  for (int a = 0; a < A; ++a) {
-    const int64_t e = b * A + a;
-    const float mu = row[a];
-    const float s = row[A + a];
-    const float sigma = (softplus(s) + min_std) * std_scale;
-    float eps, eps2;
-    noise.get(e, eps, eps2);
-    const float z = extras[e];
-    const float inv = 1.0f / sigma;
-    const float q = (z - mu) * inv;
-    // ll: d/dmu = q/sigma ; d/dsigma = (q^2 - 1)/sigma
-    float g_mu = gl * q * inv;
-    float g_sigma = gl * (q * q - 1.0f) * inv;
-    // H: z2 = mu + sigma*eps2 ; d logdetjac / dz2 = -2 tanh(z2)
-    const float t2 = tanhf(mu + sigma * eps2);
-    g_mu += gh * (-2.0f * t2);
-    g_sigma += gh * (inv - 2.0f * t2 * eps2);
-    grow[a] = g_mu;
-    grow[A + a] = g_sigma * sigmoidf(s) * std_scale;
-  }
+  float* grow = g_ms + b * 2 * p.A;
+  bwd_row(b, p, [grow](int j, float v) { grow[j] = v; });
 }
 
 __global__ void philox_normal_kernel(const uint64_t* rng, uint64_t offset_add,
@@ -103,11 +78,10 @@ extern "C" int mi_tanh_gauss_bwd_f32(const float* mean_and_std, const float* ext
   MI_REQUIRE(rng_state || eps2, "mi_tanh_gauss_bwd_f32: need rng_state or injected eps2");
   // the action noise is irrelevant in replay (z is given); alias it to eps2 so
   // Noise::get() never touches Philox when the entropy noise is injected.
-  Noise nz = {rng_state, offset_add, eps2, eps2};
+  BwdParams p = {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
+                 (int)A, min_std, std_scale, entropy_weight};
   hipLaunchKernelGGL(sampler_bwd_kernel, dim3((unsigned)mippo::ceil_div(B, kThreads)),
-                     dim3(kThreads), 0, mippo::as_stream(stream), mean_and_std, extras, nz,
-                     g_loglik, g_reg, g_mean_and_std, B, (int)A, min_std, std_scale,
-                     entropy_weight);
+                     dim3(kThreads), 0, mippo::as_stream(stream), p, g_mean_and_std, B);
   return mippo::check_launch("mi_tanh_gauss_bwd_f32");
 }
 

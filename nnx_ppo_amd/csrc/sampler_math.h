@@ -84,4 +84,44 @@ __device__ inline void fwd_row(const float* row, int64_t b, const FwdParams& p) 
   if (p.reg) p.reg[b] = -p.entropy_weight * h_acc;
 }
 
+struct BwdParams {
+  const float* ms;      // [B, 2A] the forward's input (mean | pre-softplus std)
+  const float* extras;  // [B, A] raw actions that were scored
+  Noise noise;          // entropy noise (eps2) regenerated from the forward's counter
+  const float* g_ll;    // [B] d loss / d log-likelihood, or null
+  float g_reg;          // d loss / d regulariser element
+  int A;
+  float min_std, std_scale, entropy_weight;
+};
+
+// Gradient w.r.t. the 2A inputs of row b, written to grow[0..2A) through `store`
+// (fp32 global row in the stand-alone kernel, bf16 LDS row in the fused backward).
+template <typename Store>
+__device__ inline void bwd_row(int64_t b, const BwdParams& p, Store store) {
+  const int A = p.A;
+  const float* row = p.ms + b * 2 * A;
+  const float gl = p.g_ll ? p.g_ll[b] : 0.0f;
+  const float gh = -p.entropy_weight * p.g_reg;  // d loss / d H
+  for (int a = 0; a < A; ++a) {
+    const int64_t e = b * A + a;
+    const float mu = row[a];
+    const float s = row[A + a];
+    const float sigma = (softplus(s) + p.min_std) * p.std_scale;
+    float eps, eps2;
+    p.noise.get(e, eps, eps2);
+    const float z = p.extras[e];
+    const float inv = 1.0f / sigma;
+    const float q = (z - mu) * inv;
+    // ll: d/dmu = q/sigma ; d/dsigma = (q^2 - 1)/sigma
+    float g_mu = gl * q * inv;
+    float g_sigma = gl * (q * q - 1.0f) * inv;
+    // H: z2 = mu + sigma*eps2 ; d logdetjac / dz2 = -2 tanh(z2)
+    const float t2 = tanhf(mu + sigma * eps2);
+    g_mu += gh * (-2.0f * t2);
+    g_sigma += gh * (inv - 2.0f * t2 * eps2);
+    store(a, g_mu);
+    store(A + a, g_sigma * sigmoidf(s) * p.std_scale);
+  }
+}
+
 }  // namespace mippo_sampler

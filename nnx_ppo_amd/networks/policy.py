@@ -172,6 +172,33 @@ class MLPActorCritic(Sequential):
         g_v = g_out.value_estimates.reshape(M, -1)
         if not g_v.is_contiguous():
             g_v = g_v.contiguous()
+        g_ll = g_out.loglikelihoods
+        g_ll = None if g_ll is None else g_ll.reshape(M)
+        linear_heads = (a_layers[-1].act_code == ops.ACT_NONE
+                        and c_layers[-1].act_code == ops.ACT_NONE
+                        and len(a_layers) >= 2 and len(c_layers) >= 2)
+        if not linear_heads:
+            return self._backward_per_port(s_ctx, a_ctx, v_ctx, g_out, g_reg, g_v, M)
+        ms2, ex2, off, eps2, _ = s_ctx
+        dense_chain.refresh(list(a_layers) + list(c_layers))
+        desc = lambda ls, c: ([l._fb for l in ls],
+                              [ls[0].in_features] + [l.out_features for l in ls],
+                              [l.act_code for l in ls], [sv[1] for sv in c[0]])
+        a_dz, c_dz = ops.policy_bwd_bf16(
+            ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, g_v,
+            desc(a_layers, a_ctx), desc(c_layers, v_ctx), eps2=eps2, **sampler._kw())
+        # dW / db of every layer of both trunks: one grouped launch per tile class
+        problems = []
+        for ls, c, dz in ((c_layers, v_ctx, c_dz), (a_layers, a_ctx, a_dz)):
+            for i in range(len(ls) - 1, -1, -1):
+                l = ls[i]
+                problems.append((c[0][i][0], dz[i], l.kernel.grad,
+                                 l.bias.grad if l.bias is not None else None))
+        ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
+        return None
+
+    def _backward_per_port(self, s_ctx, a_ctx, v_ctx, g_out, g_reg, g_v, M):
+        a_layers, sampler, c_layers = self._parts()
         g_ms = sampler.replay_backward(s_ctx, {"action": None,
                                                "log_likelihood": g_out.loglikelihoods}, g_reg)
         g_ms = g_ms.reshape(M, g_ms.shape[-1])

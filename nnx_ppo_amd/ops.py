@@ -497,6 +497,44 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
     return out
 
 
+def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float,
+                    g_value, actor, critic, *, min_std: float, std_scale: float,
+                    entropy_weight: float, eps2=None):
+    """Sampler backward + both dX chains in ONE launch (`mi_policy_bwd_bf16`).
+    `actor` / `critic` = (backward frag images, dims, acts, auxs per layer).  Returns
+    (actor dz list, critic dz list): bf16 [M, pad8(N_l)] per layer."""
+    M, A2 = mean_and_std.shape
+    dev = mean_and_std.device
+    (a_w, a_dims, a_acts, a_aux), (c_w, c_dims, c_acts, c_aux) = actor, critic
+    La, Lc = len(a_w), len(c_w)
+    _need(extras.shape == (M, A2 // 2) and g_value.shape == (M, c_dims[-1]),
+          "policy_bwd_bf16: shapes")
+    if g_ll is not None:
+        _need(g_ll.shape == (M,), "policy_bwd_bf16: g_ll must be [M]")
+    a_dz = [_bf_buf(M, a_dims[l + 1], dev) for l in range(La)]
+    c_dz = [_bf_buf(M, c_dims[l + 1], dev) for l in range(Lc)]
+    arr = lambda ts, n: (ctypes.c_void_p * max(n, 1))(*[ptr(t) for t in ts])
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    if profiler.active:
+        flop = sum(a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
+            + sum(c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
+        profiler.next_flops = 2.0 * M * flop
+        moved = sum(t.numel() * 2 for t in [*a_aux[:La - 1], *c_aux[:Lc - 1], *a_dz, *c_dz]
+                    if t is not None)
+        w_bytes = sum(2 * a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
+            + sum(2 * c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
+        profiler.next_bytes = (4.0 * M * (A2 + A2 // 2 + 1 + c_dims[-1]) + w_bytes + moved)
+    check(lib().mi_policy_bwd_bf16(
+        ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
+        ptr(eps2, f32), ptr(g_ll, f32), float(g_reg), float(min_std), float(std_scale),
+        float(entropy_weight), ptr(g_value, f32), M,
+        La, arr(a_w, La), i64s(a_dims), i64s(a_acts), arr(a_aux[:La - 1], La - 1),
+        ptr(a_dz[La - 1], bf16), arr(a_dz[:La - 1], La - 1),
+        Lc, arr(c_w, Lc), i64s(c_dims), i64s(c_acts), arr(c_aux[:Lc - 1], Lc - 1),
+        ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1), stream()), "mi_policy_bwd_bf16")
+    return a_dz, c_dz
+
+
 def mlp_bwd_dx_bf16(g_out: torch.Tensor, aux_last, act_last: int, w_bfs: list, dims: list,
                     acts: list, auxs: list, need_input_grad: bool):
     """Fused dX chain of an MLP trunk.  Returns (dz list per layer [L], g_in | None):
@@ -579,14 +617,17 @@ def global_norm(grads: torch.Tensor, out: torch.Tensor | None = None) -> torch.T
 
 def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: float = 0.999,
               eps: float = 1e-8, weight_decay: float = 0.0, grad_norm=None,
-              max_norm: float = 0.0) -> None:
+              max_norm: float = 0.0, begin_next: bool = False) -> None:
+    """`begin_next`: `step` counts completed steps; this launch advances it and leaves
+    `grads` zeroed (it doubles as the next step's `begin_grad_step`)."""
     n = params.numel()
     for t in (grads, m, v):
         _need(t.numel() == n, "adam_step: arena sizes differ")
+    ticket = workspace(params.device, "adam_ticket", 16, zeroed=True) if begin_next else None
     check(lib().mi_adam_step_f32(ptr(params, f32), ptr(grads, f32), ptr(m, f32), ptr(v, f32), n,
                                  float(lr), float(b1), float(b2), float(eps),
                                  float(weight_decay), ptr(step, i64), ptr(grad_norm, f32),
-                                 float(max_norm), stream()), "mi_adam_step_f32")
+                                 float(max_norm), ptr(ticket), stream()), "mi_adam_step_f32")
 
 
 # ------------------------------------------------------ a5 / a7: movement

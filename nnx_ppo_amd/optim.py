@@ -56,6 +56,7 @@ class Optimizer:
         self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.step = torch.zeros(1, dtype=torch.int64, device=device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=device)
+        self._clean = True  # the gradient arena is all zeros
         for (_, p), off in zip(named, offsets):
             n = p.numel()
             self.params[off:off + n].copy_(p.data.reshape(-1).to(device))
@@ -65,8 +66,13 @@ class Optimizer:
 
     # ---- one gradient step = begin() ... backward ... update() --------------------
     def begin(self) -> None:
-        """Zero the gradient arena and advance the step counter (one launch)."""
-        ops.begin_grad_step(self.grads, self.step)
+        """Start a gradient step with a zeroed gradient arena.  `update()` leaves the
+        arena zeroed (and counts the step) in the Adam launch itself, so in the
+        training loop this is free; it only launches when gradients were accumulated
+        since the last update (e.g. two loss evaluations without an update)."""
+        if not self._clean:
+            ops.begin_grad_step(self.grads, None)
+        self._clean = False
 
     def compute_grad_norm(self) -> torch.Tensor:
         return ops.global_norm(self.grads, out=self.grad_norm)
@@ -82,7 +88,8 @@ class Optimizer:
         ops.adam_step(self.params, self.grads, self.m, self.v, self.step,
                       lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
                       weight_decay=self.weight_decay, grad_norm=gn,
-                      max_norm=float(self.gradient_clipping or 0.0))
+                      max_norm=float(self.gradient_clipping or 0.0), begin_next=True)
+        self._clean = True
         bump_param_epoch()
 
     # ---- state export (checkpoint callbacks) ----------------------------------------
@@ -96,4 +103,5 @@ class Optimizer:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step.copy_(sd["step"])
+        self._clean = False
         bump_param_epoch()

@@ -271,6 +271,35 @@ def test_adam_vs_oracle(dev, clip, wd):
     assert np.allclose(p.cpu().numpy(), po[0].numpy(), rtol=1e-5, atol=2e-6)
 
 
+def test_adam_that_opens_the_next_step_equals_begin_plus_adam(dev):
+    """`begin_next`: one launch = adam of step t + begin of step t+1; parameters and
+    moments bit-identical to the two-launch sequence, gradients left zeroed, step
+    counter = completed steps."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(11)
+    n = 80579
+    mk = lambda: [_g(rng.normal(size=n).astype(np.float32), dev)] + \
+        [torch.zeros(n, device=dev) for _ in range(3)]
+    rng = np.random.default_rng(11)
+    pa, ma, va, ga = mk()
+    rng = np.random.default_rng(11)
+    pb, mb, vb, gb = mk()
+    sa = torch.zeros(1, dtype=torch.int64, device=dev)
+    sb = torch.zeros(1, dtype=torch.int64, device=dev)
+    for k in range(5):
+        gk = _g((rng.normal(size=n) * 0.01).astype(np.float32), dev)
+        ops.begin_grad_step(ga, sa)
+        ga.copy_(gk)
+        ops.adam_step(pa, ga, ma, va, sa, lr=3e-3, weight_decay=1e-4)
+        assert float(gb.abs().sum()) == 0.0 and int(sb.item()) == k
+        gb.copy_(gk)
+        ops.adam_step(pb, gb, mb, vb, sb, lr=3e-3, weight_decay=1e-4, begin_next=True)
+        assert int(sb.item()) == k + 1 == int(sa.item())
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert float(gb.abs().sum()) == 0.0
+
+
 # -------------------------------------------------------------------- movement
 @pytest.mark.parametrize("dtype,feat", [(torch.float32, (5,)), (torch.float32, ()), (torch.bool, ()),
                                         (torch.int64, (3,)), (torch.float32, (2, 3)),

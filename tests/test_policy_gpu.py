@@ -1,4 +1,5 @@
-"""One-launch policy evaluation (`mi_policy_fwd_bf16`, networks/policy.py) against the
+"""One-launch policy evaluation (`mi_policy_fwd_bf16` / `mi_policy_bwd_bf16`,
+networks/policy.py) against the
 generic container path it replaces: the same normaliser expression, the same trunk
 code and the same sampler row function, so every output — actions, log-likelihoods,
 values, regulariser, extras, saved images, gradients — must be BIT-identical."""
@@ -109,6 +110,12 @@ def test_replay_and_gradients_bit_identical_to_generic(dev, bf16, T, B, activati
         torch.cuda.synchronize()
         res.append((out.loglikelihoods.clone(), out.value_estimates.clone(), reg.clone(),
                     opt.grads.clone()))
-    for a, b in zip(*res):
+    for a, b in zip(res[0][:3], res[1][:3]):
         assert a.shape == b.shape and torch.equal(a, b)
-    assert float(res[0][3].abs().sum()) > 0
+    # gradients: the same bf16 operands (dz, x) in both paths, but the fused path sums
+    # the row splits of ALL layers' dW in one grouped launch, i.e. in a different fp32
+    # order: equal to accumulation-order rounding
+    ga, gb = res[0][3], res[1][3]
+    assert float(ga.abs().sum()) > 0
+    scale = float(gb.abs().max())
+    assert float((ga - gb).abs().max()) <= 2e-5 * scale
