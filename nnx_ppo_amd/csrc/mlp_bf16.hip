@@ -114,7 +114,10 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   bf16_t* const act1 = act0 + ROWS * arow;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  // wave-uniform by construction; telling the compiler so keeps the column-tile
+  // arithmetic (and with it the weight addresses and the epilogue's tile tests) on
+  // the scalar unit — the kernel is bound by VALU instruction issue, not by MFMA
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int64_t i0 = (int64_t)blockIdx.x * ROWS;
   const int K0 = c.layer[0].K;
@@ -134,20 +137,25 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         u32x4 r = u32x4{0u, 0u, 0u, 0u};
         // one contiguous 1 KiB per wave-instruction (the image is zero padded)
         if (ct < NT && kg < KS)
-          r = *reinterpret_cast<const u32x4*>(ly.w + (((int64_t)ct * KS + kg) * 64 + lane) * 8);
+          r = *reinterpret_cast<const u32x4*>(ly.w + (int64_t)(ct * KS + kg) * 512 + lane * 8);
         B.f[ks][b] = __builtin_bit_cast(bf16x8, r);
       }
     }
   };
   // coalesced copy of a published LDS buffer (rows x ld columns) to global
+  // (a power-of-two number of threads per row: shifts instead of divisions)
   auto flush = [&](const bf16_t* buf, bf16_t* dst, int64_t ld) {
-    const int nch = (int)(ld / 8);
-    for (int cidx = tid; cidx < ROWS * nch; cidx += kThreads) {
-      const int row = cidx / nch, cc = cidx % nch;
-      const int64_t gi = i0 + row;
-      if (gi < c.M)
-        *reinterpret_cast<u32x4*>(dst + gi * ld + cc * 8) =
-            *reinterpret_cast<const u32x4*>(buf + row * arow + cc * 8);
+    const int nch = (int)(ld / 8);            // 16-byte chunks per row, <= 64
+    int sh = 0;
+    while ((1 << sh) < nch) ++sh;             // scalar
+    const int cc = tid & ((1 << sh) - 1);
+    if (cc < nch) {
+      for (int row = tid >> sh; row < ROWS; row += kThreads >> sh) {
+        const int64_t gi = i0 + row;
+        if (gi < c.M)
+          *reinterpret_cast<u32x4*>(dst + gi * ld + cc * 8) =
+              *reinterpret_cast<const u32x4*>(buf + row * arow + cc * 8);
+      }
     }
   };
 
@@ -174,8 +182,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         act0[(i / (K0p - K0)) * arow + K0 + i % (K0p - K0)] = (bf16_t)0.0f;
     }
   }
-  for (int i = tid; i < (from_sampler ? 0 : ROWS * K0p); i += kThreads) {
-    const int row = i / K0p, k = i % K0p;
+  for (int row = tid >> 5; row < (from_sampler ? 0 : ROWS); row += kThreads >> 5)
+  for (int k = tid & 31; k < K0p; k += 32) {
     const int64_t gi = i0 + row;
     float v = (gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f;
     if constexpr (POLICY && !BWD) {
@@ -218,53 +226,80 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     const bool store_pre = !BWD && TRANS && ly.pre_bf;
     const bool use_aux = BWD && ly.aux && ly.act != MI_ACT_NONE;
     const int Np = (ly.N + 31) / 32 * 32;  // the next layer reduces over Np columns
+    const int relu = ly.act == MI_ACT_RELU;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int j0 = ((st.p * 4 + b) * 4 + wave) * 16 + 4 * lq;
-      if (j0 < Np) {
-        float bj[4];
+      const int ct = (st.p * 4 + b) * 4 + wave;  // scalar: the tests on it are uniform
+      if (ct * 16 >= Np) continue;
+      const int j0 = ct * 16 + 4 * lq;
+      const bool full = ct * 16 + 16 <= ly.N;    // no pad column in this tile
+      f32x4 bj = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!BWD && ly.bias) {
+        if (full) {
+          bj = *reinterpret_cast<const f32x4*>(ly.bias + j0);  // arena rows are 256-B aligned
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          bj[e] = (!BWD && ly.bias && j0 + e < ly.N) ? ly.bias[j0 + e] : 0.0f;
+          for (int e = 0; e < 4; ++e) bj[e] = j0 + e < ly.N ? ly.bias[j0 + e] : 0.0f;
+        }
+      }
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          const int row = r * 16 + li;
-          const int64_t gi = i0 + row;
-          bf16x4 vo, zo;
+      for (int r = 0; r < RT; ++r) {
+        const int row = r * 16 + li;
+        f32x4 v4 = acc[r][b];
+        bf16x4 vo, zo;
+        if constexpr (BWD) {
+          if (use_aux) {
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, auxr[r][b]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[r][b][e];
-            if constexpr (BWD) {
-              if (use_aux) {
-                const float a = (float)__builtin_bit_cast(bf16x4, auxr[r][b])[e];
-                if constexpr (TRANS) {  // swish: aux is the pre-activation
-                  const float sg = fast_sigmoid(a);
-                  v *= sg * (1.0f + a * (1.0f - sg));
-                } else {
-                  v *= ly.act == MI_ACT_RELU ? (a > 0.0f ? 1.0f : 0.0f) : 1.0f - a * a;
-                }
-              }
-            } else {
-              const float z = v + bj[e];
-              if constexpr (TRANS) {
-                const float sg = fast_sigmoid(ly.act == MI_ACT_TANH ? 2.0f * z : z);
-                v = ly.act == MI_ACT_TANH ? 2.0f * sg - 1.0f : z * sg;
-                zo[e] = (bf16_t)z;
+            for (int e = 0; e < 4; ++e) {
+              const float a = (float)a4[e];
+              if constexpr (TRANS) {  // swish: aux is the pre-activation
+                const float sg = fast_sigmoid(a);
+                v4[e] *= sg * (1.0f + a * (1.0f - sg));
               } else {
-                v = ly.act == MI_ACT_RELU ? fmaxf(z, 0.0f) : z;
+                v4[e] *= relu ? (a > 0.0f ? 1.0f : 0.0f) : 1.0f - a * a;
               }
-            }
-            if (j0 + e >= ly.N) v = 0.0f;  // pad columns (weights are zero there)
-            vo[e] = (bf16_t)v;
-            if (to_out && gi < c.M && j0 + e < ly.N) c.out[gi * ly.N + j0 + e] = v;
-            if constexpr (POLICY && !BWD) {
-              if (to_ms && j0 + e < ly.N) ms_s[row * ly.N + j0 + e] = v;
             }
           }
-          if (keep) *reinterpret_cast<bf16x4*>(nbuf + row * arow + j0) = vo;
-          if constexpr (!BWD && TRANS) {
-            if (store_pre && gi < c.M && j0 < ly.ldo)
-              *reinterpret_cast<bf16x4*>(ly.pre_bf + gi * ly.ldo + j0) = zo;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = v4[e] + bj[e];
+            if constexpr (TRANS) {
+              const float sg = fast_sigmoid(ly.act == MI_ACT_TANH ? 2.0f * z : z);
+              v4[e] = ly.act == MI_ACT_TANH ? 2.0f * sg - 1.0f : z * sg;
+              zo[e] = (bf16_t)z;
+            } else {
+              v4[e] = relu ? fmaxf(z, 0.0f) : z;
+            }
+          }
+        }
+        if (!full) {  // pad columns (weights are zero there)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j0 + e >= ly.N) v4[e] = 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)v4[e];
+        if (keep) *reinterpret_cast<bf16x4*>(nbuf + row * arow + j0) = vo;
+        if constexpr (!BWD && TRANS) {
+          const int64_t gi = i0 + row;
+          if (store_pre && gi < c.M && j0 < ly.ldo)
+            *reinterpret_cast<bf16x4*>(ly.pre_bf + gi * ly.ldo + j0) = zo;
+        }
+        // fp32 results of the chain's last layer (a handful of columns): kept out
+        // of the loop above so that the other layers do not pay for its predicates
+        if (to_out) {
+          const int64_t gi = i0 + row;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gi < c.M && j0 + e < ly.N) c.out[gi * ly.N + j0 + e] = v4[e];
+        }
+        if constexpr (POLICY && !BWD) {
+          if (to_ms) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j0 + e < ly.N) ms_s[row * ly.N + j0 + e] = v4[e];
           }
         }
       }
