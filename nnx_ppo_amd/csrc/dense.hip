@@ -63,7 +63,7 @@ __device__ inline void block_gemm(int64_t r_begin, int64_t r_end, FA load_a, FB 
   __shared__ float Bs[BK][BN + PAD];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar unit
   const int wm = wave / WN;
   const int wn = wave % WN;
 #pragma unroll

@@ -71,7 +71,7 @@ nt_gemm_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restri
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar unit
   const int wm = wave / WN, wn = wave % WN;
   const int64_t i0 = (int64_t)blockIdx.x * BM;
   const int64_t j0 = (int64_t)blockIdx.y * BN;
@@ -274,7 +274,7 @@ tn_gemm_dw_kernel(DwTable tab) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar unit
   const int wm = wave / WN, wn = wave % WN;
   const int64_t i0 = (int64_t)bx * BM;
   const int64_t j0 = (int64_t)by * BN;
@@ -366,7 +366,9 @@ tn_gemm_dw_kernel(DwTable tab) {
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+          // transposed tile (dZ fragment as the A operand): a lane then holds 4
+          // CONSECUTIVE output columns of one row — 16-byte slab stores below
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
@@ -374,16 +376,24 @@ tn_gemm_dw_kernel(DwTable tab) {
   }
 
   float* slab = slabs + (int64_t)zsplit * (I * J + J);
+  const int In = (int)I, Jn = (int)J;  // <= 512: 32-bit index arithmetic
+  // rows of the slab are 16-byte aligned
+  const bool vec = (Jn & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
+    const int i = (int)i0 + (wm * TM + a) * 16 + (lane & 15);
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int64_t j = j0 + (wn * TN + b) * 16 + (lane & 15);
-      const int64_t ib = i0 + (wm * TM + a) * 16 + 4 * (lane >> 4);
-      if (j < J) {
+      const int j = (int)j0 + (wn * TN + b) * 16 + 4 * (lane >> 4);
+      if (i < In && j < Jn) {
+        float* dst = slab + i * Jn + j;
+        if (vec) {  // j % 4 == 0 and J % 4 == 0: the four columns exist
+          *reinterpret_cast<f32x4*>(dst) = acc[a][b];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (ib + e < I) slab[(ib + e) * J + j] = acc[a][b][e];
+          for (int e = 0; e < 4; ++e)
+            if (j + e < Jn) dst[e] = acc[a][b][e];
+        }
       }
     }
   }
