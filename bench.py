@@ -264,8 +264,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # a short timeout: a wedged collective should fail this run, not hang the node
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=180))
     elif args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     device = torch.device("cuda", local_rank)
@@ -284,10 +288,18 @@ def main():
             graphed = GraphedPPOStep(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, False, N_EPOCHS,
                                      N_MB, warmup=2)
         except Exception as exc:  # capture unsupported for something in the iteration
-            if rank == 0:
-                print(f"[bench] HIP-graph capture failed ({exc!r}); running eager",
-                      file=sys.stderr)
+            print(f"[bench] rank {rank}: HIP-graph capture failed ({exc!r}); running eager",
+                  file=sys.stderr)
             graphed = None
+        if world > 1:
+            # every rank must take the same path (the collectives of a replayed graph and
+            # of eager launches pair up only if all ranks issue them the same way)
+            import torch.distributed as dist
+
+            ok = torch.tensor([1 if graphed is not None else 0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graphed = None
     if graphed is None:
         args.eager = True
         ts_box = [ts]

@@ -71,7 +71,13 @@ class GraphedPPOStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # sharded run: the collectives are captured with the iteration; the process
+        # group's watchdog thread keeps polling its own events meanwhile, which only a
+        # thread-local capture mode tolerates
+        from .. import parallel
+
+        mode = "thread_local" if parallel.is_distributed() else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             new_ts, metrics = ppo_step(env, self.ts, *args, **kwargs)
             _copy_state(self.ts, new_ts)
         self.metrics = metrics
