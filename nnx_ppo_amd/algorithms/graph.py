@@ -77,9 +77,36 @@ class GraphedPPOStep:
         from .. import parallel
 
         mode = "thread_local" if parallel.is_distributed() else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            new_ts, metrics = ppo_step(env, self.ts, *args, **kwargs)
-            _copy_state(self.ts, new_ts)
+        # Capture by hand rather than with `torch.cuda.graph`: if anything in the
+        # iteration cannot be captured, the capture must still be ENDED (that is what
+        # takes the streams out of capture mode) and the current stream restored, so
+        # that the caller can fall back to eager launches in the same process.
+        cap = torch.cuda.Stream()
+        cap.wait_stream(cur)
+        failure = None
+        with torch.cuda.stream(cap):
+            self.graph.capture_begin(capture_error_mode=mode)
+            try:
+                new_ts, metrics = ppo_step(env, self.ts, *args, **kwargs)
+                _copy_state(self.ts, new_ts)
+            except BaseException as exc:  # noqa: BLE001 - re-raised below
+                failure = exc
+            try:
+                self.graph.capture_end()
+            except Exception as exc:  # an invalidated capture reports itself here
+                failure = failure or exc
+        cur.wait_stream(cap)
+        if failure is not None:
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # the sticky error of the aborted capture
+                pass
+            # streams that had been forked into the aborted capture do not accept
+            # launches any more: let the port-overlap code create fresh ones
+            from ..networks import adapter
+
+            adapter._SIDE_STREAMS.clear()
+            raise RuntimeError(f"HIP-graph capture of ppo_step failed: {failure!r}") from failure
         self.metrics = metrics
 
     def __call__(self):
