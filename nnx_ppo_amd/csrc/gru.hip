@@ -10,29 +10,34 @@
 //     n = tanh(gi_n + r * (gh_n + b_hn))
 //     h' = (1 - z) n + z h ;  carry <- done ? 0 : h'      (reset-on-done, ppo.py:411-413)
 //
-// One workgroup owns 16 envs for ALL T steps: the hidden state tile lives in LDS
+// One workgroup owns 4..16 envs for ALL T steps: the hidden state tile lives in LDS
 // across the time loop (and W_h too when it fits), so a sequence costs one launch
 // and no per-step HBM round trip of the carry.  fp32 throughout.
 // Thread map: 256 threads = 4 row-lanes x 64 unit-lanes; a thread owns rows
-// 4*rl..4*rl+3 and units ul, ul+64, ...
+// RPT*rl..RPT*rl+RPT-1 and units ul, ul+64, ...
 #include "common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int ROWS = 16;
-constexpr int RPT = 4;          // rows per thread
 constexpr int MAXU = 4;         // units per thread: H <= 256
+// Rows (envs) per workgroup = 4 row-lanes x RPT rows per thread.  The recurrence is
+// T dependent steps of VALU work per workgroup, so the only parallelism is across
+// workgroups: RPT is chosen so that a launch has >= ~256 of them (RPT = 1 at a
+// 1024-env minibatch, 4 at a 4096-env rollout) — fewer rows per thread also means
+// fewer serial FMAs per step.
 
 __device__ inline float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // LDS layout: hs[ROWS][H] (carry), then W[H][3H] if w_in_lds.
+template <int RPT>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                const float* __restrict__ b_hn, const float* __restrict__ h0,
                const uint8_t* __restrict__ done, float* __restrict__ h_out,
                float* __restrict__ h_prev_out, float* __restrict__ gates_out,
                float* __restrict__ h_final, int64_t T, int64_t B, int H, int w_in_lds) {
+  constexpr int ROWS = 4 * RPT;
   extern __shared__ float lds[];
   float* hs = lds;                 // [ROWS][H]
   float* hn = lds + ROWS * H;      // [ROWS][H] next carry
@@ -56,7 +61,7 @@ gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     for (int ui = 0; ui < nu; ++ui) {
       const int u = ul + 64 * ui;
       if (u >= H) continue;
-      float ar[RPT] = {0, 0, 0, 0}, az[RPT] = {0, 0, 0, 0}, an[RPT] = {0, 0, 0, 0};
+      float ar[RPT] = {}, az[RPT] = {}, an[RPT] = {};
       for (int k = 0; k < H; ++k) {
         const float wr = W[k * H3 + u], wz = W[k * H3 + H + u], wn = W[k * H3 + 2 * H + u];
 #pragma unroll
@@ -115,22 +120,29 @@ gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 // dgi / dgh are written out; dW_h = h_prev^T dgh, db_hn = colsum(dgh_n), dW_i,
 // db_i, dx are time-batched GEMMs done by the dense kernels afterwards.
 // LDS: dh[ROWS][H], dgh tile [ROWS][3H], W[H][3H] if it fits.
+template <int RPT>
 __global__ void __launch_bounds__(kThreads)
 gru_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
                const float* __restrict__ h_prev, const float* __restrict__ w_h,
                const uint8_t* __restrict__ done, float* __restrict__ dgi,
                float* __restrict__ dgh, float* __restrict__ dh0, int64_t T, int64_t B, int H,
                int w_in_lds) {
+  constexpr int ROWS = 4 * RPT;
   extern __shared__ float lds[];
   float* dh = lds;                    // [ROWS][H]
   float* dg = lds + ROWS * H;         // [ROWS][3H]
-  float* wl = lds + ROWS * H * 4;     // [H][3H]
+  float* wl = lds + ROWS * H * 4;     // [H][3H + 1]
   const int tid = threadIdx.x;
   const int ul = tid & 63, rl = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int H3 = 3 * H;
+  // Phase 2 reads W[k][j] with k = the lane's unit: with the natural row stride 3H
+  // (a multiple of 64 words for H = 64) all 64 lanes hit one LDS bank — a 64-way
+  // conflict that made this kernel 8x slower than the forward.  Rows are padded by
+  // one word in LDS so that consecutive k fall in consecutive banks.
+  const int WS = w_in_lds ? H3 + 1 : H3;
   if (w_in_lds) {
-    for (int i = tid; i < H * H3; i += kThreads) wl[i] = w_h[i];
+    for (int i = tid; i < H * H3; i += kThreads) wl[(i / H3) * WS + i % H3] = w_h[i];
   }
   for (int i = tid; i < ROWS * H; i += kThreads) dh[i] = 0.0f;
   __syncthreads();
@@ -183,9 +195,9 @@ gru_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
     for (int ui = 0; ui < nu; ++ui) {
       const int k = ul + 64 * ui;
       if (k >= H) continue;
-      float acc[RPT] = {0, 0, 0, 0};
+      float acc[RPT] = {};
       for (int j = 0; j < H3; ++j) {
-        const float w = W[k * H3 + j];
+        const float w = W[k * WS + j];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) acc[q] += dg[(rl * RPT + q) * H3 + j] * w;
       }
@@ -204,11 +216,50 @@ gru_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
 
 }  // namespace
 
-static size_t gru_lds_bytes(int H, int bwd, int* w_in_lds) {
-  const size_t base = (size_t)(bwd ? 4 : 2) * ROWS * H * sizeof(float);
-  const size_t w = (size_t)H * 3 * H * sizeof(float);
+static size_t gru_lds_bytes(int rows, int H, int bwd, int* w_in_lds) {
+  const size_t base = (size_t)(bwd ? 4 : 2) * rows * H * sizeof(float);
+  const size_t w = (size_t)H * (3 * H + (bwd ? 1 : 0)) * sizeof(float);
   *w_in_lds = base + w <= 150 * 1024 ? 1 : 0;
   return base + (*w_in_lds ? w : 0);
+}
+
+static int gru_rpt(int64_t B) {
+  if (B >= 16 * 256) return 4;
+  if (B >= 8 * 256) return 2;
+  return 1;
+}
+
+template <int RPT>
+static int launch_gru_fwd(const float* gi, const float* w_h, const float* b_hn, const float* h0,
+                          const uint8_t* done, float* h_out, float* h_prev_out,
+                          float* gates_out, float* h_final, int64_t T, int64_t B, int H,
+                          hipStream_t st) {
+  int w_in_lds = 0;
+  const size_t lds = gru_lds_bytes(4 * RPT, H, 0, &w_in_lds);
+  static const hipError_t attr =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_kernel<RPT>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  MI_REQUIRE(attr == hipSuccess, "mi_gru_seq_fwd_f32: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL((gru_fwd_kernel<RPT>), dim3((unsigned)mippo::ceil_div(B, 4 * RPT)),
+                     dim3(kThreads), lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out,
+                     gates_out, h_final, T, B, H, w_in_lds);
+  return mippo::check_launch("mi_gru_seq_fwd_f32");
+}
+
+template <int RPT>
+static int launch_gru_bwd(const float* g_h, const float* gates, const float* h_prev,
+                          const float* w_h, const uint8_t* done, float* dgi, float* dgh,
+                          float* dh0, int64_t T, int64_t B, int H, hipStream_t st) {
+  int w_in_lds = 0;
+  const size_t lds = gru_lds_bytes(4 * RPT, H, 1, &w_in_lds);
+  static const hipError_t attr =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_kernel<RPT>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  MI_REQUIRE(attr == hipSuccess, "mi_gru_seq_bwd_f32: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL((gru_bwd_kernel<RPT>), dim3((unsigned)mippo::ceil_div(B, 4 * RPT)),
+                     dim3(kThreads), lds, st, g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, T, B,
+                     H, w_in_lds);
+  return mippo::check_launch("mi_gru_seq_bwd_f32");
 }
 
 extern "C" int mi_gru_seq_fwd_f32(const float* gi, const float* w_h, const float* b_hn,
@@ -221,18 +272,12 @@ extern "C" int mi_gru_seq_fwd_f32(const float* gi, const float* w_h, const float
   if (B == 0) return 0;
   MI_REQUIRE(gi || T == 0, "mi_gru_seq_fwd_f32: null gi");
   MI_REQUIRE(w_h && b_hn && h0 && h_final && (h_out || T == 0), "mi_gru_seq_fwd_f32: null pointer");
-  int w_in_lds = 0;
-  const size_t lds = gru_lds_bytes((int)H, 0, &w_in_lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  hipStream_t st = mippo::as_stream(stream);
+  switch (gru_rpt(B)) {
+    case 4: return launch_gru_fwd<4>(gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H, st);
+    case 2: return launch_gru_fwd<2>(gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H, st);
+    default: return launch_gru_fwd<1>(gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H, st);
   }
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3((unsigned)mippo::ceil_div(B, ROWS)), dim3(kThreads), lds,
-                     mippo::as_stream(stream), gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out,
-                     h_final, T, B, (int)H, w_in_lds);
-  return mippo::check_launch("mi_gru_seq_fwd_f32");
 }
 
 extern "C" int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const float* h_prev,
@@ -241,16 +286,10 @@ extern "C" int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const fl
                                   mi_stream_t stream) {
   MI_REQUIRE(T >= 1 && B >= 1 && H >= 1 && H <= 64 * MAXU, "mi_gru_seq_bwd_f32: bad shape");
   MI_REQUIRE(g_h && gates && h_prev && w_h && dgi && dgh, "mi_gru_seq_bwd_f32: null pointer");
-  int w_in_lds = 0;
-  const size_t lds = gru_lds_bytes((int)H, 1, &w_in_lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  hipStream_t st = mippo::as_stream(stream);
+  switch (gru_rpt(B)) {
+    case 4: return launch_gru_bwd<4>(g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, T, B, (int)H, st);
+    case 2: return launch_gru_bwd<2>(g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, T, B, (int)H, st);
+    default: return launch_gru_bwd<1>(g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, T, B, (int)H, st);
   }
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)mippo::ceil_div(B, ROWS)), dim3(kThreads), lds,
-                     mippo::as_stream(stream), g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, T, B,
-                     (int)H, w_in_lds);
-  return mippo::check_launch("mi_gru_seq_bwd_f32");
 }

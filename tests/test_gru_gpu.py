@@ -28,7 +28,9 @@ def _gru(in_f, H, seed=0):
 
 
 @pytest.mark.parametrize("T,B,I,H", [(1, 1, 3, 16), (30, 64, 64, 64), (12, 37, 5, 64),
-                                     (7, 100, 16, 32), (5, 33, 8, 128), (6, 20, 7, 80)])
+                                     (7, 100, 16, 32), (5, 33, 8, 128), (6, 20, 7, 80),
+                                     # 8 and 16 envs per workgroup (B >= 2048 / 4096)
+                                     (4, 2051, 5, 64), (3, 4099, 5, 64)])
 def test_gru_sequence_fwd_bwd_vs_oracle(dev, T, B, I, H):
     from nnx_ppo_amd.optim import Optimizer
 
