@@ -140,7 +140,11 @@ extern "C" int mi_adam_step_f32(float* params, float* grads, float* m, float* v,
                                 int64_t* step, const float* grad_norm, float max_norm,
                                 void* begin_next_ticket, mi_stream_t stream) {
   MI_REQUIRE(n >= 1 && params && grads && m && v && step, "mi_adam_step_f32: bad arguments");
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kThreads), 0,
+  // every block takes a ticket when this launch also opens the next step: keep the
+  // grid at one block per CU so the tickets do not serialise on the counter's L2 line
+  int grid = stream_grid(n);
+  if (begin_next_ticket && grid > mippo::kNumCU) grid = mippo::kNumCU;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0,
                      mippo::as_stream(stream), params, grads, m, v, n, lr, b1, b2, eps,
                      weight_decay, step, grad_norm, max_norm,
                      static_cast<unsigned int*>(begin_next_ticket));
