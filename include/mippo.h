@@ -373,6 +373,13 @@ int mi_select_rows_multi(const uint8_t* mask, const void* const* on_true,
                          void* const* out, const int64_t* row_bytes, int64_t n_leaves, int64_t B,
                          mi_stream_t stream);
 
+/* dst[l][0..nbytes[l]) = src[l][...] for n_leaves <= 16 contiguous buffers in one
+ * launch: the hand-over of the new env / carry / key tensors into the training
+ * state's buffers at the end of an iteration (`ppo.py:343-348` returns a new
+ * TrainingState; a captured HIP graph needs the same buffers every replay). */
+int mi_copy_multi(const void* const* src, void* const* dst, const int64_t* nbytes,
+                  int64_t n_leaves, mi_stream_t stream);
+
 /* The minibatch gather for several leaves in one launch (n_leaves <= 16); leaf l
  * is time-major [T[l], N, row_bytes[l]]. */
 int mi_gather_cols_multi(const void* const* src, void* const* dst, const int64_t* T,

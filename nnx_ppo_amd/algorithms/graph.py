@@ -30,6 +30,7 @@ from .types import TrainingState
 
 
 def _copy_state(dst: TrainingState, src: TrainingState) -> None:
+    pairs = []
     for name in ("network_states", "env_states", "rng_key", "steps_taken"):
         d = tree_leaves(getattr(dst, name))
         s = tree_leaves(getattr(src, name))
@@ -45,7 +46,14 @@ def _copy_state(dst: TrainingState, src: TrainingState) -> None:
                     f"training_state.{name}: leaf changed from {a.dtype}{tuple(a.shape)} to "
                     f"{b.dtype}{tuple(b.shape)}; HIP-graph capture needs stable leaves")
             if a.data_ptr() != b.data_ptr():
-                a.copy_(b)
+                if a.is_cuda and a.is_contiguous() and b.is_contiguous():
+                    pairs.append((a, b))
+                else:
+                    a.copy_(b)
+    if pairs:  # one launch for all leaves
+        from .. import ops
+
+        ops.copy_multi(pairs)
 
 
 class GraphedPPOStep:

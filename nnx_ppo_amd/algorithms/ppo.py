@@ -211,16 +211,26 @@ def ppo_step(
 
     keys = rnd.split(training_state.rng_key)
     reset_key, new_key = keys[0], keys[1]
-    next_net_state, next_env_state, rollout_data = rollout.unroll_env(
-        env, training_state.env_states, networks, training_state.network_states,
-        rollout_length, reset_key)
-
     total_iterations = n_epochs * n_minibatches
+    # the minibatch permutations depend on the key only: draw them on the second stream
+    # while the rollout (30 dependent steps of small launches) runs on this one
+    perm_fork = None
     if minibatch_inds is None:
-        all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
+        if _can_fork(new_key):
+            perm_fork = _Fork(new_key)
+            with perm_fork:
+                all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
+        else:
+            all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
     else:
         all_indices = minibatch_inds
     assert all_indices.shape[0] == total_iterations
+
+    next_net_state, next_env_state, rollout_data = rollout.unroll_env(
+        env, training_state.env_states, networks, training_state.network_states,
+        rollout_length, reset_key)
+    if perm_fork is not None:
+        perm_fork.join(all_indices)
 
     # only the Transition fields the loss reads are gathered (ppo.py:297 gathers
     # every leaf; `metrics`, `actions`, `value_estimates` are dead there)

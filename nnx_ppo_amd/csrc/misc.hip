@@ -75,6 +75,31 @@ select_rows_multi_kernel(const uint8_t* __restrict__ mask, SelectTable tab, int6
   }
 }
 
+// Several contiguous buffers copied in one launch (blockIdx.y = buffer): the state
+// hand-over at the end of a captured iteration is ~10 small tensors, and one
+// launch per tensor costs more than the bytes do.
+struct CopyLeaf {
+  const void* src;
+  void* dst;
+  int64_t words;
+  int word_bytes;
+};
+struct CopyTable {
+  CopyLeaf leaf[kMaxSelectLeaves];
+};
+
+__global__ void __launch_bounds__(kThreads)
+copy_multi_kernel(CopyTable tab) {
+  const CopyLeaf lf = tab.leaf[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < lf.words;
+       i += (int64_t)gridDim.x * kThreads) {
+    if (lf.word_bytes == 4)
+      static_cast<uint32_t*>(lf.dst)[i] = static_cast<const uint32_t*>(lf.src)[i];
+    else
+      static_cast<uint8_t*>(lf.dst)[i] = static_cast<const uint8_t*>(lf.src)[i];
+  }
+}
+
 struct GatherLeaf {
   const void* src;
   void* dst;
@@ -216,4 +241,29 @@ extern "C" int mi_gather_cols_multi(const void* const* src, void* const* dst, co
   hipLaunchKernelGGL(gather_cols_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream),
                      tab, idx, N, L);
   return mippo::check_launch("mi_gather_cols_multi");
+}
+
+extern "C" int mi_copy_multi(const void* const* src, void* const* dst, const int64_t* nbytes,
+                             int64_t n_leaves, mi_stream_t stream) {
+  MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves, "mi_copy_multi: 0 <= n_leaves <= %d",
+             kMaxSelectLeaves);
+  if (n_leaves == 0) return 0;
+  MI_REQUIRE(src && dst && nbytes, "mi_copy_multi: null pointer");
+  CopyTable tab = {};
+  int64_t max_words = 0;
+  for (int64_t l = 0; l < n_leaves; ++l) {
+    MI_REQUIRE(nbytes[l] >= 0 && (nbytes[l] == 0 || (src[l] && dst[l])),
+               "mi_copy_multi: bad leaf %lld", (long long)l);
+    const bool w4 = nbytes[l] % 4 == 0 && aligned4(src[l]) && aligned4(dst[l]);
+    CopyLeaf& lf = tab.leaf[l];
+    lf.src = src[l];
+    lf.dst = dst[l];
+    lf.word_bytes = w4 ? 4 : 1;
+    lf.words = nbytes[l] / lf.word_bytes;
+    if (lf.words > max_words) max_words = lf.words;
+  }
+  if (max_words == 0) return 0;
+  dim3 grid((unsigned)stream_grid(max_words), (unsigned)n_leaves);
+  hipLaunchKernelGGL(copy_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream), tab);
+  return mippo::check_launch("mi_copy_multi");
 }

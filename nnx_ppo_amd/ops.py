@@ -763,6 +763,22 @@ def select_rows_multi(mask: torch.Tensor, pairs: list) -> list:
 KEY_SPLIT, KEY_BITS, KEY_RANDINT, KEY_UNIFORM, KEY_UNIT_UNIFORM = 0, 1, 2, 3, 4
 
 
+def copy_multi(pairs: list) -> None:
+    """`dst.copy_(src)` for a list of (dst, src) contiguous same-shape tensors, 16 per
+    launch."""
+    for i in range(0, len(pairs), 16):
+        grp = pairs[i:i + 16]
+        n = len(grp)
+        for d, s in grp:
+            _need(d.shape == s.shape and d.dtype == s.dtype and d.is_contiguous()
+                  and s.is_contiguous(), "copy_multi: pairs must match and be contiguous")
+        P = ctypes.c_void_p * n
+        check(lib().mi_copy_multi(P(*[ptr(s) for _, s in grp]), P(*[ptr(d) for d, _ in grp]),
+                                  (ctypes.c_int64 * n)(*[d.numel() * d.element_size()
+                                                         for d, _ in grp]), n, stream()),
+              "mi_copy_multi")
+
+
 def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: int = 0,
                child_major: bool = False, fold: Optional[torch.Tensor] = None):
     """keys (int64, any shape) -> `[*keys.shape, m]` children / bits / integers / floats

@@ -130,3 +130,19 @@ def test_split2_and_gather_multi(dev):
     outs = ops.gather_cols_multi([x.to(dev) for x in leaves], idx.to(dev))
     for x, o in zip(leaves, outs):
         assert torch.equal(o.cpu(), x[:, idx])
+
+
+def test_copy_multi_bit_exact(dev):
+    """mi_copy_multi: several buffers (odd sizes, every dtype) in one launch."""
+    from nnx_ppo_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    srcs = []
+    for i in range(19):  # > 16: exercises the batching
+        shape = [(), (7,), (4096,), (4096, 5), (3, 3, 3)][i % 5]
+        dt = [torch.float32, torch.int64, torch.bool, torch.uint8][i % 4]
+        srcs.append((torch.randn(shape, generator=g) * 50).to(dt).to(dev))
+    dsts = [torch.zeros_like(s) for s in srcs]
+    ops.copy_multi(list(zip(dsts, srcs)))
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
