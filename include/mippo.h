@@ -309,6 +309,28 @@ int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const float* h_prev
                        const float* w_h, const uint8_t* done, float* dgi, float* dgh, float* dh0,
                        int64_t T, int64_t B, int64_t H, mi_stream_t stream);
 
+/* ---- f2: LSTM carry (`nnx_ppo/networks/recurrent.py:16-161`) -------------- */
+
+/* The recurrence of the reference's LSTM layer over a whole sequence with
+ * reset-on-done (`ppo.py:411-413`): a = gi[t] + h W_h (gate order i, f, g, o),
+ * c' = f c + i g, h' = o tanh(c'); carry <- done[t] ? 0 : (h', c').
+ * gi [T,B,4H] = x W_i + b_h (a time-batched dense launch); w_h [H,4H]; h0, c0 [B,H];
+ * done [T,B] nullable.  Outputs: h_out [T,B,H]; training (nullable): h_prev_out,
+ * c_prev_out [T,B,H] (the carry entering each step) and gates_out [T,B,5H] =
+ * (i, f, g, o, tanh(c')); h_final, c_final [B,H].  H <= 256. */
+int mi_lstm_seq_fwd_f32(const float* gi, const float* w_h, const float* h0, const float* c0,
+                        const uint8_t* done, float* h_out, float* h_prev_out, float* c_prev_out,
+                        float* gates_out, float* h_final, float* c_final, int64_t T, int64_t B,
+                        int64_t H, mi_stream_t stream);
+
+/* BPTT of the above: from g_h [T,B,H] to d_gates [T,B,4H] (gradient w.r.t. the gate
+ * pre-activations, i.e. w.r.t. gi and w.r.t. h W_h); dh0, dc0 [B,H] nullable.
+ * dW_h = h_prev^T d_gates, db_h = colsum(d_gates), dW_i, dx follow as time-batched
+ * GEMMs (dense kernels). */
+int mi_lstm_seq_bwd_f32(const float* g_h, const float* gates, const float* c_prev,
+                        const float* w_h, const uint8_t* done, float* d_gates, float* dh0,
+                        float* dc0, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
 /* ---- a14: loss terms ---------------------------------------------------- */
 
 /* Advantage statistics for `ppo.py:477-480`: stats[3] = (sum, sum of squares,

@@ -38,5 +38,21 @@ def lecun_normal():
     return variance_scaling(1.0, "fan_in", "truncated_normal")
 
 
+def orthogonal(scale: float = 1.0):
+    """flax/jax `orthogonal`: Q of the QR decomposition of a Gaussian matrix, columns
+    sign-fixed by diag(R) — flax.nnx.LSTMCell's default recurrent_kernel_init."""
+
+    def init(gen: np.random.Generator, shape):
+        rows, cols = shape[0], shape[-1]
+        a = gen.standard_normal(size=(max(rows, cols), min(rows, cols)))
+        q, r = np.linalg.qr(a)
+        q = q * np.sign(np.diag(r))
+        if rows < cols:
+            q = q.T
+        return (scale * q[:rows, :cols]).astype(np.float32)
+
+    return init
+
+
 def zeros(gen, shape):
     return np.zeros(shape, dtype=np.float32)

@@ -1,6 +1,7 @@
-"""Recurrent modules (counterpart of `nnx_ppo/networks/recurrent.py`).
+"""Recurrent modules (counterpart of `nnx_ppo/networks/recurrent.py`): `LSTM`, the
+reference's recurrent layer (recurrent.py:16-161), and `GRU`.
 
-The reference ships an LSTM wrapper only; BASELINE.json asks for a GRU carry, so
+The reference ships the LSTM wrapper only; BASELINE.json asks for a GRU carry, so
 `GRU` obeys that wrapper's StatefulModule contract (recurrent.py:89-161): state
 `[B, H]` zeros at `initialize_state`, zeros-like at `reset_state`, output = new
 hidden state, `regularization_loss = zeros(B)`, no rollout extras.  The cell is
@@ -92,4 +93,94 @@ class GRU(StatefulModule):
         if not need_input_grad:
             return None
         g_x = ops.dense_bwd_dx(dgi2, None, self.w_i.data, ops.ACT_NONE)
+        return g_x.view(T, B, self.in_features)
+
+
+class LSTM(StatefulModule):
+    """recurrent.py:16-161 — a wrapper of flax's (Optimized)LSTMCell with the carry
+    `(h, c)`, each `[B, H]`: zeros at `initialize_state`, zeros-like at `reset_state`,
+    output = new hidden state, `regularization_loss = zeros(B)`, no rollout extras.
+    Cell (flax, third-party: arithmetic PARITY UNPINNED), gate order (i, f, g, o),
+    bias on the hidden-side projection only:
+
+        a = x W_i + h W_h + b_h
+        c' = sigmoid(a_f) c + sigmoid(a_i) tanh(a_g) ;  h' = sigmoid(a_o) tanh(c')
+
+    Weights are packed `w_i [in, 4H]`, `w_h [H, 4H]`, `b_h [4H]`.  The input projection
+    (with the bias) is one time-batched GEMM; the recurrence runs in a persistent kernel
+    (csrc/lstm.hip); BPTT is its mirror plus time-batched GEMMs for the weights.
+    `use_optimized` is accepted and ignored (both flax cells compute the same function).
+    Not in this build: custom `gate_fn` / `activation_fn`, `trainable_initial_state`."""
+
+    def __init__(self, in_features: int, hidden_features: int, rngs: Rngs, *, gate_fn=None,
+                 activation_fn=None, kernel_init=None, recurrent_kernel_init=None,
+                 bias_init=None, use_optimized: bool = True,
+                 trainable_initial_state: bool = False):
+        if hidden_features > 256:
+            raise ValueError("LSTM: hidden_features <= 256 in this build")
+        if gate_fn is not None or activation_fn is not None:
+            raise NotImplementedError("LSTM: sigmoid gates / tanh activation only in this build")
+        if trainable_initial_state:
+            raise NotImplementedError("LSTM: trainable_initial_state is not in this build")
+        self.in_features = in_features
+        self.hidden_features = hidden_features
+        self.trainable_initial_state = False
+        gen = rngs.generator()
+        ki = kernel_init or initializers.lecun_normal()
+        kr = recurrent_kernel_init or initializers.orthogonal()
+        H = hidden_features
+        import numpy as np
+
+        self.w_i = Parameter(np.concatenate([ki(gen, (in_features, H)) for _ in range(4)], axis=1))
+        self.w_h = Parameter(np.concatenate([kr(gen, (H, H)) for _ in range(4)], axis=1))
+        b = np.zeros(4 * H, dtype=np.float32) if bias_init is None else \
+            np.asarray(bias_init(gen, (4 * H,)), dtype=np.float32)
+        self.b_h = Parameter(b)
+
+    def _gi(self, x2: torch.Tensor) -> torch.Tensor:
+        return ops.dense_fwd(x2, self.w_i.data, self.b_h.data, ops.ACT_NONE)
+
+    def __call__(self, state, x: torch.Tensor, rollout_extras: Any = None):
+        h, c = state
+        B = x.shape[0]
+        gi = self._gi(x.reshape(B, self.in_features)).view(1, B, 4 * self.hidden_features)
+        h_out, _, _, _, h_f, c_f = ops.lstm_seq_fwd(gi, self.w_h.data, h.contiguous(),
+                                                    c.contiguous(), None, train=False)
+        return StatefulModuleOutput(next_state=(h_f, c_f), output=h_out[0],
+                                    regularization_loss=torch.zeros(B, device=x.device),
+                                    metrics={}, rollout_extras=None)
+
+    def initialize_state(self, batch_size: int):
+        z = lambda: torch.zeros(batch_size, self.hidden_features, dtype=torch.float32,
+                                device=self.device)
+        return (z(), z())
+
+    def reset_state(self, prev_state):
+        return (torch.zeros_like(prev_state[0]), torch.zeros_like(prev_state[1]))
+
+    # ---- training protocol --------------------------------------------------------
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+        T, B, _ = x_seq.shape
+        H = self.hidden_features
+        x2 = x_seq.reshape(T * B, self.in_features)
+        gi = self._gi(x2).view(T, B, 4 * H)
+        h0, c0 = state0
+        h_out, h_prev, c_prev, gates, h_f, c_f = ops.lstm_seq_fwd(
+            gi, self.w_h.data, h0.contiguous(), c0.contiguous(), done_seq.contiguous(),
+            train=True)
+        ctx = (x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad)
+        return ctx, h_out, None, (h_f, c_f)
+
+    def replay_backward(self, ctx, g_out, g_reg):
+        x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad = ctx
+        H = self.hidden_features
+        da = ops.lstm_seq_bwd(g_out.contiguous(), gates, c_prev, self.w_h.data,
+                              done_seq.contiguous())
+        da2 = da.view(T * B, 4 * H)
+        ops.dense_bwd_dw(h_prev.view(T * B, H), da2, None, self.w_h.grad, self.b_h.grad,
+                         ops.ACT_NONE, accumulate=True)
+        ops.dense_bwd_dw(x2, da2, None, self.w_i.grad, None, ops.ACT_NONE, accumulate=True)
+        if not need_input_grad:
+            return None
+        g_x = ops.dense_bwd_dx(da2, None, self.w_i.data, ops.ACT_NONE)
         return g_x.view(T, B, self.in_features)

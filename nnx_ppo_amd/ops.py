@@ -858,3 +858,39 @@ def gru_seq_bwd(g_h, gates, h_prev, w_h, done):
                                    ptr(d), ptr(dgi, f32), ptr(dgh, f32), None, T, B, H, stream()),
           "mi_gru_seq_bwd_f32")
     return dgi, dgh
+
+
+# ------------------------------------------------------------- f2: LSTM
+def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool):
+    """gi [T,B,4H] -> (h_out [T,B,H], h_prev | None, c_prev | None, gates [T,B,5H] | None,
+    h_final [B,H], c_final [B,H])."""
+    T, B, H4 = gi.shape
+    H = H4 // 4
+    _need(w_h.shape == (H, H4) and h0.shape == (B, H) and c0.shape == (B, H),
+          "lstm_seq_fwd: shapes")
+    dev = gi.device
+    mk = lambda *s: torch.empty(*s, dtype=f32, device=dev)
+    h_out = mk(T, B, H)
+    h_prev = mk(T, B, H) if train else None
+    c_prev = mk(T, B, H) if train else None
+    gates = mk(T, B, 5 * H) if train else None
+    h_final, c_final = mk(B, H), mk(B, H)
+    d = None if done is None else _as_u8(done)
+    if d is not None:
+        _need(d.shape == (T, B), "lstm_seq_fwd: done must be [T, B]")
+    check(lib().mi_lstm_seq_fwd_f32(ptr(gi, f32), ptr(w_h, f32), ptr(h0, f32), ptr(c0, f32),
+                                    ptr(d), ptr(h_out, f32), ptr(h_prev, f32), ptr(c_prev, f32),
+                                    ptr(gates, f32), ptr(h_final, f32), ptr(c_final, f32), T, B,
+                                    H, stream()), "mi_lstm_seq_fwd_f32")
+    return h_out, h_prev, c_prev, gates, h_final, c_final
+
+
+def lstm_seq_bwd(g_h, gates, c_prev, w_h, done):
+    """Returns d_gates [T,B,4H] (gradient w.r.t. the gate pre-activations)."""
+    T, B, H = g_h.shape
+    da = torch.empty(T, B, 4 * H, dtype=f32, device=g_h.device)
+    d = None if done is None else _as_u8(done)
+    check(lib().mi_lstm_seq_bwd_f32(ptr(g_h, f32), ptr(gates, f32), ptr(c_prev, f32),
+                                    ptr(w_h, f32), ptr(d), ptr(da, f32), None, None, T, B, H,
+                                    stream()), "mi_lstm_seq_bwd_f32")
+    return da

@@ -396,6 +396,42 @@ class GRU(Module):
         return torch.zeros_like(prev)
 
 
+class LSTM(Module):
+    """`nnx_ppo/networks/recurrent.py:16-161`: carry (h, c), zeros init, zeros-like
+    reset, reg = zeros(B), extras None, output = new h.  Cell arithmetic of
+    flax.nnx.LSTMCell (third-party, PARITY UNPINNED), gate order (i, f, g, o):
+        a = x W_i + h W_h + b_h ;  c' = sig(a_f) c + sig(a_i) tanh(a_g) ;  h' = sig(a_o) tanh(c')"""
+
+    def __init__(self, w_i, w_h, b_h, dtype=DTYPE):
+        self.w_i = _t(w_i, dtype).requires_grad_(True)
+        self.w_h = _t(w_h, dtype).requires_grad_(True)
+        self.b_h = _t(b_h, dtype).requires_grad_(True)
+        self.H = self.w_h.shape[0]
+        self.dtype = dtype
+
+    def own_parameters(self):
+        return [self.w_i, self.w_h, self.b_h]
+
+    def __call__(self, state, x, extras=None):
+        h, c = state
+        H = self.H
+        a = x @ self.w_i + h @ self.w_h + self.b_h
+        i = torch.sigmoid(a[:, :H])
+        f = torch.sigmoid(a[:, H:2 * H])
+        g = torch.tanh(a[:, 2 * H:3 * H])
+        o = torch.sigmoid(a[:, 3 * H:])
+        c2 = f * c + i * g
+        h2 = o * torch.tanh(c2)
+        return Out((h2, c2), h2, torch.zeros(x.shape[0], dtype=self.dtype), {}, None)
+
+    def initialize_state(self, batch_size):
+        z = lambda: torch.zeros(batch_size, self.H, dtype=self.dtype)
+        return (z(), z())
+
+    def reset_state(self, prev):
+        return (torch.zeros_like(prev[0]), torch.zeros_like(prev[1]))
+
+
 def from_product(net: Any, dtype=DTYPE) -> Module:
     """Build the oracle twin of a product network by duck-typing on class names
     and copying its weights / statistics / noise seeds (no product import)."""
@@ -427,4 +463,6 @@ def from_product(net: Any, dtype=DTYPE) -> Module:
         return Flattener()
     if name == "GRU":
         return GRU(net.w_i.data, net.b_i.data, net.w_h.data, net.b_hn.data, dtype)
+    if name == "LSTM":
+        return LSTM(net.w_i.data, net.w_h.data, net.b_h.data, dtype)
     raise NotImplementedError(f"oracle twin of {name}")
