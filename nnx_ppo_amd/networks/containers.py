@@ -41,7 +41,9 @@ class Sequential(StatefulModule):
 
                 j = runs[i]
                 lead = x.shape[:-1]
-                y = dense_chain.forward_infer(self.layers[i:j], x.reshape(-1, x.shape[-1]))
+                x2 = x.reshape(-1, x.shape[-1])
+                y = dense_chain.forward_infer(self.layers[i:j],
+                                              x2 if x2.is_contiguous() else x2.contiguous())
                 x = y.view(*lead, y.shape[-1])
                 for k in range(i, j):
                     new_state.append(network_state[k])
@@ -113,8 +115,10 @@ class Sequential(StatefulModule):
 
                 j = runs[i]
                 lead = x.shape[:-1]
-                cctx, y = dense_chain.forward_train(self.layers[i:j],
-                                                    x.reshape(-1, x.shape[-1]), upstream_needs)
+                x2 = x.reshape(-1, x.shape[-1])
+                cctx, y = dense_chain.forward_train(
+                    self.layers[i:j], x2 if x2.is_contiguous() else x2.contiguous(),
+                    upstream_needs)
                 x = y.view(*lead, y.shape[-1])
                 ctxs.append(("chain", i, j, cctx, lead))
                 final_state.extend(state0[i:j])
@@ -150,3 +154,172 @@ class Sequential(StatefulModule):
             if g is None:
                 return None
         return g
+
+
+def _resolve_components(kind: str, modules, kwargs) -> dict:
+    """containers.py:70-80 / utils.py `_resolve_components`: a positional dict or
+    keyword arguments, not both, at least one."""
+    if modules is not None and kwargs:
+        raise ValueError(f"{kind}: pass either a positional dict or keyword arguments, not both")
+    components = modules if modules is not None else kwargs
+    if not components:
+        raise ValueError(f"{kind} requires at least one component")
+    return dict(components)
+
+
+def _add_tree(a, b):
+    from ..tree import tree_map
+
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return tree_map(lambda u, v: u + v, a, b)
+
+
+class _Keyed(StatefulModule):
+    """Shared routing of the dict-of-sub-modules containers: carry state, rollout
+    extras and metrics are dicts keyed by component name; regularisers are summed
+    (containers.py:86-118, 145-176; utils.py Merge / Map)."""
+
+    _KIND = "_Keyed"
+    _PER_KEY_INPUT = False  # True: component k sees x[k]; False: every component sees x
+
+    def __init__(self, modules: dict | None = None, /, **kwargs: StatefulModule):
+        self.components = _resolve_components(self._KIND, modules, kwargs)
+
+    def _combine(self, outputs: dict):
+        raise NotImplementedError
+
+    def _split_grad(self, g_out, outputs_meta: dict) -> dict:
+        raise NotImplementedError
+
+    def __call__(self, state, x, rollout_extras=None) -> StatefulModuleOutput:
+        new_state, new_extras, outputs, metrics = {}, {}, {}, {}
+        reg = zero_scalar(_device_of(x))
+        for key, component in self.components.items():
+            child_extras = None if rollout_extras is None else rollout_extras[key]
+            out = component(state[key], x[key] if self._PER_KEY_INPUT else x, child_extras)
+            new_state[key] = out.next_state
+            new_extras[key] = out.rollout_extras
+            outputs[key] = out.output
+            reg = add_reg(reg, out.regularization_loss)
+            metrics[key] = out.metrics
+        return StatefulModuleOutput(new_state, self._combine(outputs), reg, metrics, new_extras)
+
+    def initialize_state(self, batch_size: int) -> dict:
+        return {k: c.initialize_state(batch_size) for k, c in self.components.items()}
+
+    def reset_state(self, prev_state: dict) -> dict:
+        return {k: c.reset_state(prev_state[k]) for k, c in self.components.items()}
+
+    def update_statistics(self, rollout_extras: Any) -> None:
+        for key, component in self.components.items():
+            component.update_statistics(rollout_extras[key])
+
+    # ---- training protocol ---------------------------------------------------------
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+        ctxs, outputs, final_state = {}, {}, {}
+        reg = None
+        for key, component in self.components.items():
+            child_extras = None if extras_seq is None else extras_seq[key]
+            ctx, out, r, fs = component.replay(
+                state0[key], x_seq[key] if self._PER_KEY_INPUT else x_seq, done_seq,
+                child_extras, need_input_grad=need_input_grad)
+            ctxs[key] = ctx
+            outputs[key] = out
+            final_state[key] = fs
+            reg = add_reg(reg, r)
+        meta = {k: (v.shape[-1] if hasattr(v, "shape") else None) for k, v in outputs.items()}
+        return (ctxs, meta), self._combine(outputs), reg, final_state
+
+    def replay_backward(self, ctx, g_out, g_reg):
+        ctxs, meta = ctx
+        grads = self._split_grad(g_out, meta)
+        g_in = {} if self._PER_KEY_INPUT else None
+        for key, component in self.components.items():
+            g = component.replay_backward(ctxs[key], grads[key], g_reg)
+            if self._PER_KEY_INPUT:
+                g_in[key] = g
+            else:
+                g_in = _add_tree(g_in, g)
+        if self._PER_KEY_INPUT and all(v is None for v in g_in.values()):
+            return None
+        return g_in
+
+
+class Concat(_Keyed):
+    """containers.py:55-122 — per-key dispatch + concatenation along the last axis:
+    dict input, single-tensor output."""
+
+    _KIND = "Concat"
+    _PER_KEY_INPUT = True
+
+    def _combine(self, outputs: dict):
+        import torch
+
+        return torch.cat(list(outputs.values()), dim=-1)
+
+    def _split_grad(self, g_out, meta: dict) -> dict:
+        out, o = {}, 0
+        for k, n in meta.items():
+            out[k] = g_out[..., o:o + n]
+            o += n
+        return out
+
+
+class Parallel(_Keyed):
+    """containers.py:125-180 — several sub-modules on the SAME input, outputs as a
+    dict keyed by sub-module name."""
+
+    _KIND = "Parallel"
+
+    def _combine(self, outputs: dict):
+        return outputs
+
+    def _split_grad(self, g_out, meta: dict) -> dict:
+        return {k: g_out[k] for k in meta}
+
+
+class Splitter(StatefulModule):
+    """containers.py:183-218 — named slices of the last axis, in keyword order; excess
+    input features are ignored (plain slicing semantics)."""
+
+    def __init__(self, **sizes: int):
+        if not sizes:
+            raise ValueError("Splitter requires at least one named slice")
+        for k, v in sizes.items():
+            if v <= 0:
+                raise ValueError(f"slice size for {k!r} must be positive, got {v}")
+        self._sizes = dict(sizes)
+
+    def _split(self, x):
+        out, o = {}, 0
+        for key, size in self._sizes.items():
+            out[key] = x[..., o:o + size]
+            o += size
+        return out
+
+    def __call__(self, state, x, rollout_extras=None) -> StatefulModuleOutput:
+        return StatefulModuleOutput((), self._split(x), zero_scalar(x.device), {}, None)
+
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+        return (need_input_grad, x_seq.shape[-1]), self._split(x_seq), None, ()
+
+    def replay_backward(self, ctx, g_out, g_reg):
+        import torch
+
+        need, width = ctx
+        if not need:
+            return None
+        parts = []
+        ref = next(g for g in g_out.values() if g is not None)
+        for key, size in self._sizes.items():
+            g = g_out.get(key)
+            parts.append(g if g is not None
+                         else torch.zeros(*ref.shape[:-1], size, dtype=ref.dtype, device=ref.device))
+        used = sum(self._sizes.values())
+        if used < width:
+            parts.append(torch.zeros(*ref.shape[:-1], width - used, dtype=ref.dtype,
+                                     device=ref.device))
+        return torch.cat(parts, dim=-1)

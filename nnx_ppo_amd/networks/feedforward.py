@@ -12,6 +12,13 @@ from . import activations, initializers
 from .types import Parameter, Rngs, StatefulModule, StatefulModuleOutput, zero_scalar
 
 
+def _rows(x, width: int):
+    """`[..., width]` -> contiguous `[M, width]` (a slice handed over by a routing
+    container, e.g. `Splitter`, is a strided view)."""
+    x2 = x.reshape(-1, width)
+    return x2 if x2.is_contiguous() else x2.contiguous()
+
+
 class Dense(StatefulModule):
     def __init__(self, in_features: int, out_features: int, rngs: Rngs,
                  activation: Any = None, *, kernel_init=None, bias_init=None,
@@ -40,16 +47,16 @@ class Dense(StatefulModule):
         if config.compute_dtype() == "bf16":
             from . import dense_chain
 
-            y = dense_chain.forward_infer([self], x.reshape(-1, self.in_features))
+            y = dense_chain.forward_infer([self], _rows(x, self.in_features))
         else:
-            y, _ = self._fwd(x.reshape(-1, self.in_features), want_aux=False)
+            y, _ = self._fwd(_rows(x, self.in_features), want_aux=False)
         y = y.view(*lead, self.out_features)
         return StatefulModuleOutput(state, y, zero_scalar(x.device), {}, None)
 
     # ---- training protocol ----------------------------------------------------
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
         lead = x_seq.shape[:-1]
-        x2 = x_seq.reshape(-1, self.in_features)
+        x2 = _rows(x_seq, self.in_features)
         if config.compute_dtype() == "bf16":
             from . import dense_chain
 
@@ -64,7 +71,7 @@ class Dense(StatefulModule):
             from . import dense_chain
 
             _, cctx, lead = ctx
-            g_in = dense_chain.backward([self], cctx, g_out.reshape(-1, self.out_features))
+            g_in = dense_chain.backward([self], cctx, _rows(g_out, self.out_features))
             return None if g_in is None else g_in.view(*lead, self.in_features)
         x2, aux, lead, need_input_grad = ctx
         g2 = g_out.reshape(-1, self.out_features)

@@ -396,6 +396,114 @@ class GRU(Module):
         return torch.zeros_like(prev)
 
 
+class _Keyed(Module):
+    """Dict-of-sub-modules routing shared by Concat / Parallel / Merge / Map
+    (containers.py:55-180, utils.py:186-326)."""
+
+    per_key_input = False
+
+    def __init__(self, components: dict):
+        self.components = dict(components)
+
+    def children(self):
+        return list(self.components.values())
+
+    def combine(self, outputs: dict):
+        return outputs
+
+    def __call__(self, state, x, extras=None):
+        new_state, new_extras, outputs, metrics = {}, {}, {}, {}
+        reg = torch.zeros((), dtype=DTYPE)
+        for k, c in self.components.items():
+            out = c(state[k], x[k] if self.per_key_input else x,
+                    None if extras is None else extras[k])
+            new_state[k], new_extras[k], outputs[k], metrics[k] = (
+                out.next_state, out.rollout_extras, out.output, out.metrics)
+            reg = reg + out.regularization_loss
+        return Out(new_state, self.combine(outputs), reg, metrics, new_extras)
+
+    def initialize_state(self, batch_size):
+        return {k: c.initialize_state(batch_size) for k, c in self.components.items()}
+
+    def reset_state(self, prev):
+        return {k: c.reset_state(prev[k]) for k, c in self.components.items()}
+
+    def update_statistics(self, extras):
+        for k, c in self.components.items():
+            c.update_statistics(extras[k])
+
+
+class Concat(_Keyed):
+    per_key_input = True
+
+    def combine(self, outputs):
+        return torch.cat(list(outputs.values()), dim=-1)
+
+
+class Parallel(_Keyed):
+    pass
+
+
+class Map(_Keyed):
+    per_key_input = True
+
+
+class Merge(_Keyed):
+    def combine(self, outputs):
+        merged = {}
+        for out in outputs.values():
+            for k, v in out.items():
+                assert k not in merged
+                merged[k] = v
+        return merged
+
+
+class Splitter(Module):
+    """containers.py:183-218."""
+
+    def __init__(self, sizes: dict):
+        self.sizes = dict(sizes)
+
+    def __call__(self, state, x, extras=None):
+        out, o = {}, 0
+        for k, n in self.sizes.items():
+            out[k] = x[..., o:o + n]
+            o += n
+        return Out((), out, torch.zeros((), dtype=DTYPE), {}, None)
+
+
+class Filter(Module):
+    """utils.py:119-165."""
+
+    def __init__(self, spec: dict):
+        self.spec = dict(spec)
+
+    def __call__(self, state, x, extras=None):
+        out = {}
+        for k, sub in self.spec.items():
+            if isinstance(sub, str):
+                out[k] = x[sub]
+            elif isinstance(sub, tuple):
+                v = x
+                for p in sub:
+                    v = v[p]
+                out[k] = v
+            else:
+                out[k] = sub(x)
+        return Out((), out, torch.zeros((), dtype=DTYPE), {}, None)
+
+
+class Scale(Module):
+    """utils.py:168-183."""
+
+    def __init__(self, factor: float):
+        self.factor = float(factor)
+
+    def __call__(self, state, x, extras=None):
+        return Out(state, _map(lambda v: v * self.factor, x), torch.zeros((), dtype=DTYPE), {},
+                   None)
+
+
 class LSTM(Module):
     """`nnx_ppo/networks/recurrent.py:16-161`: carry (h, c), zeros init, zeros-like
     reset, reg = zeros(B), extras None, output = new h.  Cell arithmetic of
@@ -458,6 +566,15 @@ def from_product(net: Any, dtype=DTYPE) -> Module:
         if net.rng_state is not None:
             o.offset = int(net.rng_state[1].item()) + net._pending
         return o
+    if name in ("Concat", "Parallel", "Map", "Merge"):
+        cls = {"Concat": Concat, "Parallel": Parallel, "Map": Map, "Merge": Merge}[name]
+        return cls({k: from_product(c, dtype) for k, c in net.components.items()})
+    if name == "Splitter":
+        return Splitter(net._sizes)
+    if name == "Filter":
+        return Filter(net._spec)
+    if name == "Scale":
+        return Scale(net.factor)
     if name == "Flattener":
         assert net.preserve_levels == 0
         return Flattener()
