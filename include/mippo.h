@@ -344,6 +344,10 @@ int mi_adv_stats_f32(const float* adv, int64_t n, double* stats, void* workspace
 /* Clipped surrogate + value loss + regulariser mean, `ppo.py:456-531`, over a
  * flattened [T*mb] minibatch.  adv is the raw GAE output; adv_stats (nullable)
  * turns on normalisation; reg (nullable) is the per-element regulariser.
+ * PyTree rewards / value heads / log-likelihoods (`ppo.py:440-474,494-510`) are one
+ * call per leaf: the (ll_new, ll_old, g_ll) group or the (values, g_v) group may be
+ * null — an actor term on a summed advantage has no critic part, a value head whose
+ * key has no policy term has no actor part; the absent losses come back as 0.
  * Outputs: g_ll = d total / d ll_new, g_v = d total / d values (includes
  * critic_weight), loss_out[4] = (actor, critic, regularization,
  * clipping_fraction). */

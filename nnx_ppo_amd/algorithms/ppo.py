@@ -360,34 +360,40 @@ def ppo_loss(
     values = out.value_estimates
     ll_new = out.loglikelihoods
     ll_old = rollout_data.network_output.loglikelihoods
-    if not (isinstance(rewards, torch.Tensor) and isinstance(values, torch.Tensor)
-            and isinstance(ll_new, torch.Tensor)):
-        raise NotImplementedError(
-            "PyTree rewards / value heads / per-module log-likelihoods "
-            "(ppo.py:440-474, combine_advantages) are a 'next' row of the scope table; "
-            "this build handles a single reward, value and log-likelihood tensor")
-    del combine_advantages  # single reward key: nothing to combine
-
-    values = values.contiguous()
-    stats = None
-    if normalize_advantages:
-        # the statistics of ppo.py:477-480 come out of the GAE launch itself
-        adv, stats = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
-                             done.contiguous(), truncated.contiguous(), discounting_factor,
-                             gae_lambda, with_stats=True)
-        if parallel.is_distributed():
-            parallel.allreduce_sum_(stats)
+    single = (isinstance(rewards, torch.Tensor) and isinstance(values, torch.Tensor)
+              and isinstance(ll_new, torch.Tensor))
+    if not single:
+        g_ll, g_v, loss_out = _pytree_loss_terms(
+            rewards, values, last_values, ll_new, ll_old, reg_seq, done, truncated,
+            clip_range, normalize_advantages, combine_advantages, discounting_factor,
+            gae_lambda, critic_loss_weight, loss_out)
+        if backward:
+            networks.replay_backward(
+                ctx, PPONetworkOutput(actions=None, loglikelihoods=g_ll, value_estimates=g_v),
+                1.0 / float(T * B))
     else:
-        adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
-                      done.contiguous(), truncated.contiguous(), discounting_factor, gae_lambda)
-    reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
-    g_ll, g_v, loss_out = ops.ppo_loss(
-        ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1), values.reshape(-1), reg_flat,
-        stats, clip_range, critic_loss_weight, loss_out=loss_out)
-    if backward:
-        g_out = PPONetworkOutput(actions=None, loglikelihoods=g_ll.view(T, B),
-                                 value_estimates=g_v.view(T, B))
-        networks.replay_backward(ctx, g_out, 1.0 / float(T * B))
+        del combine_advantages  # single reward key: nothing to combine
+        values = values.contiguous()
+        stats = None
+        if normalize_advantages:
+            # the statistics of ppo.py:477-480 come out of the GAE launch itself
+            adv, stats = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
+                                 done.contiguous(), truncated.contiguous(), discounting_factor,
+                                 gae_lambda, with_stats=True)
+            if parallel.is_distributed():
+                parallel.allreduce_sum_(stats)
+        else:
+            adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
+                          done.contiguous(), truncated.contiguous(), discounting_factor,
+                          gae_lambda)
+        reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
+        g_ll, g_v, loss_out = ops.ppo_loss(
+            ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1), values.reshape(-1),
+            reg_flat, stats, clip_range, critic_loss_weight, loss_out=loss_out)
+        if backward:
+            g_out = PPONetworkOutput(actions=None, loglikelihoods=g_ll.view(T, B),
+                                     value_estimates=g_v.view(T, B))
+            networks.replay_backward(ctx, g_out, 1.0 / float(T * B))
 
     loss_metrics: dict = {}
     if LoggingLevel.LOSSES in logging_level:
@@ -400,6 +406,82 @@ def ppo_loss(
     if want_total:  # three tiny launches: the training loop reads `loss_out` instead
         total = loss_out[0] + critic_loss_weight * loss_out[1] + loss_out[2]
     return total, loss_metrics
+
+
+def _pytree_loss_terms(rewards, values, last_values, ll_new, ll_old, reg_seq, done, truncated,
+                       clip_range, normalize_advantages, combine_advantages, gamma, lambda_,
+                       critic_loss_weight, loss_out):
+    """ppo.py:440-510 for PyTree rewards / value heads / log-likelihoods.
+
+    One GAE per reward key (`done` / `truncated` are shared, ppo.py:440-445); the critic
+    term of every key against its own target; the actor term of every log-likelihood
+    leaf against its advantage — the key's own, or, with `combine_advantages`, the sum
+    over keys (broadcast to every leaf of a structured log-likelihood tree,
+    ppo.py:462-474); each advantage tree leaf is normalised on its own (477-480).
+    One loss launch per leaf; the scalars are summed (`jax.tree.reduce`, 505-507).
+    Returns (g_ll tree, g_v tree, loss_out[4] = summed actor, critic, reg, mean clip
+    fraction)."""
+    T, B = done.shape
+    d_, t_ = done.contiguous(), truncated.contiguous()
+    adv = tree_map(
+        lambda r, v, lv: ops.gae(r.contiguous(), v.contiguous(), lv.contiguous(), d_, t_, gamma,
+                                 lambda_),
+        rewards, values, last_values)
+    dev = done.device
+    if loss_out is None:
+        loss_out = torch.empty(4, dtype=torch.float32, device=dev)
+    parts = []
+    # critic terms, per reward key, on the raw advantages
+
+    def critic(v, a):
+        _, gv, lo = ops.ppo_loss(None, None, a.reshape(-1), v.contiguous().reshape(-1), None,
+                                 None, clip_range, critic_loss_weight)
+        parts.append(lo)
+        return gv.view(T, B)
+
+    g_v = tree_map(critic, values, adv)
+    # actor advantages
+    if combine_advantages:
+        leaves = tree_leaves(adv)
+        summed = leaves[0]
+        for a in leaves[1:]:
+            summed = summed + a
+        actor_adv = summed if isinstance(ll_new, torch.Tensor) else \
+            tree_map(lambda _: summed, ll_new)
+    else:
+        actor_adv = adv
+        same = (isinstance(ll_new, dict) and isinstance(adv, dict)
+                and set(ll_new) == set(adv)) or \
+            (isinstance(ll_new, torch.Tensor) and isinstance(adv, torch.Tensor))
+        if not same:
+            raise ValueError(
+                "ppo_loss: the log-likelihood tree and the per-reward-key advantage tree do "
+                "not match (ppo.py:494-499 maps over both); give one policy term per reward "
+                "key or set combine_advantages=True")
+    reg_left = [None if reg_seq is None else reg_seq.reshape(-1)]
+
+    def actor(ln, lo_, a):
+        stats = None
+        if normalize_advantages:
+            stats = ops.adv_stats(a.contiguous())
+            if parallel.is_distributed():
+                parallel.allreduce_sum_(stats)
+        reg, reg_left[0] = reg_left[0], None  # the (shared) regulariser is counted once
+        gl, _, lo = ops.ppo_loss(ln.contiguous().reshape(-1), lo_.contiguous().reshape(-1),
+                                 a.contiguous().reshape(-1), None, reg, stats, clip_range,
+                                 critic_loss_weight)
+        parts.append(lo)
+        return gl.view(T, B)
+
+    g_ll = tree_map(actor, ll_new, ll_old, actor_adv)
+    n_actor = len(tree_leaves(ll_new))
+    total = parts[0]
+    for p_ in parts[1:]:
+        total = total + p_
+    loss_out.copy_(total)
+    if n_actor > 1:
+        loss_out[3:4].div_(float(n_actor))  # clipping fraction: mean over the policy terms
+    return g_ll, g_v, loss_out
 
 
 def new_training_state(

@@ -119,21 +119,25 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * kThreads) {
     const float a_raw = adv[i];
-    const float a = stats ? (a_raw - mean) / denom : a_raw;
-    const float r = expf(ll_new[i] - ll_old[i]);
-    const float c1 = r * a;
-    const float c2 = fminf(fmaxf(r, lo), hi) * a;
-    s_act += (double)fminf(c1, c2);
-    // d(-mean min(c1,c2))/d ll_new: the unclipped branch carries a*r, the
-    // clipped branch is flat (ties c1 == c2 have r inside the clip range).
-    g_ll[i] = c1 <= c2 ? -(a * r) * inv_n : 0.0f;
-    const float v = values[i];
-    const float target = v + a_raw;  // ppo.py:456-458
-    const float diff = v - target;
-    s_crit += (double)(diff * diff);
-    g_v[i] = critic_weight * diff * inv_n;
+    if (ll_new) {  // actor term (absent for a value head without its own policy term)
+      const float a = stats ? (a_raw - mean) / denom : a_raw;
+      const float r = expf(ll_new[i] - ll_old[i]);
+      const float c1 = r * a;
+      const float c2 = fminf(fmaxf(r, lo), hi) * a;
+      s_act += (double)fminf(c1, c2);
+      // d(-mean min(c1,c2))/d ll_new: the unclipped branch carries a*r, the
+      // clipped branch is flat (ties c1 == c2 have r inside the clip range).
+      g_ll[i] = c1 <= c2 ? -(a * r) * inv_n : 0.0f;
+      s_clip += fabsf(r - 1.0f) > clip ? 1.0 : 0.0;
+    }
+    if (values) {  // critic term (absent when the advantage is a sum over reward keys)
+      const float v = values[i];
+      const float target = v + a_raw;  // ppo.py:456-458
+      const float diff = v - target;
+      s_crit += (double)(diff * diff);
+      g_v[i] = critic_weight * diff * inv_n;
+    }
     if (reg) s_reg += (double)reg[i];
-    s_clip += fabsf(r - 1.0f) > clip ? 1.0 : 0.0;
   }
   const double t0 = block_sum(s_act, scratch);
   const double t1 = block_sum(s_crit, scratch);
@@ -203,8 +207,11 @@ extern "C" int mi_ppo_loss_f32(const float* ll_new, const float* ll_old, const f
                                float* loss_out, void* workspace, int64_t n,
                                mi_stream_t stream) {
   MI_REQUIRE(n >= 1, "mi_ppo_loss_f32: n must be >= 1");
-  MI_REQUIRE(ll_new && ll_old && adv && values && g_ll && g_v && loss_out && workspace,
-             "mi_ppo_loss_f32: null pointer");
+  MI_REQUIRE(adv && loss_out && workspace, "mi_ppo_loss_f32: null pointer");
+  MI_REQUIRE((ll_new && ll_old && g_ll) || (!ll_new && !ll_old && !g_ll),
+             "mi_ppo_loss_f32: ll_new, ll_old, g_ll go together");
+  MI_REQUIRE((values && g_v) || (!values && !g_v), "mi_ppo_loss_f32: values, g_v go together");
+  MI_REQUIRE(ll_new || values, "mi_ppo_loss_f32: neither an actor nor a critic term");
   hipStream_t st = mippo::as_stream(stream);
   const int G = grid_for(n);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(G), dim3(kThreads), 0, st, ll_new, ll_old, adv, values,

@@ -146,3 +146,32 @@ class MoveToCenterEnv:
     @property
     def action_size(self):
         return 2
+
+
+class TwoArmEnv:
+    """`nnx_ppo/test_dummies/dict_obs_act_env.py:128-170`: two point masses;
+    obs = {"arm1": {"pos", "vel"}, "arm2": {...}} (each `[N, 2]`), action =
+    {"arm1": [N, 2], "arm2": [N, 2]}, reward = {"arm1": [N], "arm2": [N]} =
+    exp(-|pos|), done when either arm is farther than 3 from the origin.  The PyTree
+    reward exercises per-key value heads and `combine_advantages` (ppo.py:440-474)."""
+
+    def _make(self, pos, vel) -> State:
+        dist = {k: torch.sqrt(torch.square(p).sum(-1)) for k, p in pos.items()}
+        reward = {k: torch.exp(-d) for k, d in dist.items()}
+        done = torch.logical_or(dist["arm1"] > 3.0, dist["arm2"] > 3.0)
+        obs = {k: {"pos": pos[k], "vel": vel[k]} for k in pos}
+        return State(data={}, obs=obs, reward=reward, done=done, metrics={}, info={})
+
+    def reset(self, rng: torch.Tensor) -> State:
+        # the reference draws both arms from the same key (dict_obs_act_env.py:139-142)
+        p = rnd.uniform(rng, (2,)) * 2.0 - 1.0
+        zero = torch.zeros_like(p)
+        return self._make({"arm1": p, "arm2": p.clone()}, {"arm1": zero, "arm2": zero.clone()})
+
+    def step(self, state: State, action: dict) -> State:
+        vel = {k: state.obs[k]["vel"] + 0.1 * action[k] for k in ("arm1", "arm2")}
+        pos = {k: state.obs[k]["pos"] + 0.1 * vel[k] for k in ("arm1", "arm2")}
+        return self._make(pos, vel)
+
+    observation_size = {"arm1": {"pos": 2, "vel": 2}, "arm2": {"pos": 2, "vel": 2}}
+    action_size = {"arm1": 2, "arm2": 2}

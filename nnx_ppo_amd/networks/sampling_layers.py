@@ -99,6 +99,8 @@ class NormalTanhSampler(ActionSampler):
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
         T, B, A2 = x_seq.shape
         ms2 = x_seq.reshape(T * B, A2)
+        if not ms2.is_contiguous():  # a slice handed over by a routing container
+            ms2 = ms2.contiguous()
         ex2 = extras_seq.reshape(T * B, A2 // 2)
         if not ex2.is_contiguous():
             ex2 = ex2.contiguous()

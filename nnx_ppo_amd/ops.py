@@ -582,14 +582,14 @@ def adv_stats(adv: torch.Tensor) -> torch.Tensor:
 def ppo_loss(ll_new, ll_old, adv, values, reg, stats, clip_range: float, critic_weight: float,
              loss_out: torch.Tensor | None = None):
     """Returns (g_ll, g_v, loss_out[4] = actor, critic, regularization, clip_frac)."""
-    n = ll_new.numel()
-    for t in (ll_old, adv, values):
-        _need(t.numel() == n, "ppo_loss: operand sizes differ")
-    if reg is not None:
-        _need(reg.numel() == n, "ppo_loss: reg size differs")
-    dev = ll_new.device
-    g_ll = torch.empty(n, dtype=f32, device=dev)
-    g_v = torch.empty(n, dtype=f32, device=dev)
+    n = adv.numel()
+    _need((ll_new is None) == (ll_old is None), "ppo_loss: ll_new and ll_old go together")
+    _need(ll_new is not None or values is not None, "ppo_loss: nothing to evaluate")
+    for t in (ll_new, ll_old, values, reg):
+        _need(t is None or t.numel() == n, "ppo_loss: operand sizes differ")
+    dev = adv.device
+    g_ll = torch.empty(n, dtype=f32, device=dev) if ll_new is not None else None
+    g_v = torch.empty(n, dtype=f32, device=dev) if values is not None else None
     if loss_out is None:
         loss_out = torch.empty(4, dtype=f32, device=dev)
     check(lib().mi_ppo_loss_f32(ptr(ll_new, f32), ptr(ll_old, f32), ptr(adv, f32),

@@ -168,7 +168,7 @@ class Sequential(Module):
 
 
 class PPOAdapter(Module):
-    """adapter.py:75-133 (single sampler on the action port)."""
+    """adapter.py:75-133."""
 
     def __init__(self, action, value):
         self.action, self.value = action, value
@@ -176,23 +176,35 @@ class PPOAdapter(Module):
     def children(self):
         return [self.action, self.value]
 
+    @staticmethod
+    def _pick(tree, key):
+        """adapter.py:92-98: map over a tree whose leaves are sampler dicts."""
+        if isinstance(tree, dict) and {"action", "log_likelihood"} <= set(tree):
+            return tree[key]
+        if isinstance(tree, dict):
+            return {k: PPOAdapter._pick(v, key) for k, v in tree.items()}
+        if isinstance(tree, (list, tuple)):
+            return type(tree)(PPOAdapter._pick(v, key) for v in tree)
+        raise TypeError("the action port must emit sampler dicts")
+
+    @staticmethod
+    def _squeeze(val):
+        return val.squeeze(-1) if val.shape and val.shape[-1] == 1 else val  # adapter.py:55-58
+
     def __call__(self, state, x, extras=None):
         a_re = None if extras is None else extras["action"]
         v_re = None if extras is None else extras["value"]
         a = self.action(state["action"], x, a_re)
         v = self.value(state["value"], x, v_re)
-        val = v.output
-        if val.shape and val.shape[-1] == 1:  # adapter.py:55-58
-            val = val.squeeze(-1)
         return Out({"action": a.next_state, "value": v.next_state},
-                   PPOOut(a.output["action"], a.output["log_likelihood"], val),
+                   PPOOut(self._pick(a.output, "action"), self._pick(a.output, "log_likelihood"),
+                          _map(self._squeeze, v.output)),
                    a.regularization_loss + v.regularization_loss,
                    {"action": a.metrics, "value": v.metrics},
                    {"action": a.rollout_extras, "value": v.rollout_extras})
 
     def forward_value(self, state, x):
-        val = self.value(state["value"], x, None).output
-        return val.squeeze(-1) if val.shape and val.shape[-1] == 1 else val
+        return _map(self._squeeze, self.value(state["value"], x, None).output)
 
     def initialize_state(self, batch_size):
         return {"action": self.action.initialize_state(batch_size),

@@ -68,7 +68,7 @@ def single_transition(env, networks: Module, carry, reset_keys):
     net_state, env_state = carry
     with torch.no_grad():
         out = networks(net_state, env_state.obs)
-    nxt = env.step(env_state, out.output.actions.to(torch.float32))
+    nxt = env.step(env_state, _tmap(lambda a: a.to(torch.float32), out.output.actions))
     done = _as_bool(nxt.done)
     trunc = nxt.info.get("truncated", None)
     trunc = torch.zeros_like(done) if trunc is None else _as_bool(trunc)
@@ -91,7 +91,9 @@ def unroll_env(env, env_state, networks: Module, network_state, unroll_length: i
         steps.append(tr)
     stacked = {k: _tmap(lambda *xs: torch.stack(xs, 0), steps[0][k], *[s[k] for s in steps[1:]])
                for k in steps[0]}
-    assert stacked["value_estimates"].shape == stacked["rewards"].shape  # rollout.py:67-72
+    # rollout.py:67-72: value_estimates leaves must match rewards leaves
+    for v, r in zip(_leaves(stacked["value_estimates"]), _leaves(stacked["rewards"])):
+        assert v.shape == r.shape
     return carry[0], carry[1], Transition(**stacked)
 
 
@@ -116,9 +118,17 @@ def _samplers(networks: Module):
     return [m for m in networks.modules() if type(m).__name__ == "NormalTanhSampler"]
 
 
+def _leaves(t):
+    if isinstance(t, dict):
+        return [x for k in t for x in _leaves(t[k])]
+    if isinstance(t, (list, tuple)):
+        return [x for v in t for x in _leaves(v)]
+    return [] if t is None else [t]
+
+
 def ppo_loss(networks: Module, network_state, mb: Transition, clip_range, normalize_advantages,
-             discounting_factor, gae_lambda, critic_loss_weight):
-    """ppo.py:397-531 for a single reward / value / log-likelihood tensor.
+             discounting_factor, gae_lambda, critic_loss_weight, combine_advantages=False):
+    """ppo.py:397-531 (rewards / value heads / log-likelihoods: tensors or PyTrees).
     Returns (total, dict(actor, critic, regularization, clipping_fraction, advantages))."""
     T = mb.done.shape[0]
     for s in _samplers(networks):
@@ -134,31 +144,46 @@ def ppo_loss(networks: Module, network_state, mb: Transition, clip_range, normal
         vals.append(out.output.value_estimates)
         lls.append(out.output.loglikelihoods)
         regs.append(out.regularization_loss)
-    values = torch.stack(vals, 0)
-    ll_new = torch.stack(lls, 0)
-    reg = torch.stack([r.expand(values.shape[1]) if r.dim() == 0 else r for r in regs], 0)
+    stack = lambda xs: _map(lambda *v: torch.stack(v, 0), xs[0], *xs[1:])
+    values = stack(vals)
+    ll_new = stack(lls)
+    n_env = mb.done.shape[1]
+    reg = torch.stack([r.expand(n_env) if r.dim() == 0 else r for r in regs], 0)
 
     last_obs = _map(lambda x: x[-1], mb.next_obs)
     last_values = networks.forward_value(state, last_obs)  # ppo.py:433-437, value branch only
 
-    dt = values.dtype
-    adv = gae(mb.rewards.to(dt), values.detach(), last_values.detach(),
-              mb.done, mb.truncated, gae_lambda, discounting_factor)
-    target = (values + adv).detach()  # ppo.py:456-458
+    dt = reg.dtype
+    det = lambda t: _map(lambda x: x.detach(), t)
+    # one GAE per reward key; done / truncated are shared (ppo.py:440-456)
+    adv = _map(lambda r, v, lv: gae(r.to(dt), v, lv, mb.done, mb.truncated, gae_lambda,
+                                    discounting_factor),
+               mb.rewards, det(values), det(last_values))
+    target = _map(lambda v, a: (v + a).detach(), values, adv)  # ppo.py:456-458
     a = adv
-    if normalize_advantages:  # ppo.py:477-480 (population std)
-        a = (a - a.mean()) / (a.std(unbiased=False) + 1e-8)
-    ratio = torch.exp(ll_new - mb.loglikelihoods.to(dt))
-    c1 = ratio * a
-    c2 = torch.clamp(ratio, 1 - clip_range, 1 + clip_range) * a
-    actor = -torch.mean(torch.minimum(c1, c2))
-    critic = 0.5 * torch.mean((values - target) ** 2)
+    if combine_advantages:  # ppo.py:460-474
+        summed = sum(_leaves(adv))
+        a = summed if isinstance(ll_new, torch.Tensor) else _map(lambda _: summed, ll_new)
+    if normalize_advantages:  # ppo.py:477-480 (population std, per leaf)
+        a = _map(lambda x: (x - x.mean()) / (x.std(unbiased=False) + 1e-8), a)
+
+    def clipped(ln, lo, ad):
+        ratio = torch.exp(ln - lo.to(dt))
+        c1 = ratio * ad
+        c2 = torch.clamp(ratio, 1 - clip_range, 1 + clip_range) * ad
+        return -torch.mean(torch.minimum(c1, c2))
+
+    actor = sum(_leaves(_map(clipped, ll_new, mb.loglikelihoods, a)))
+    critic = sum(_leaves(_map(lambda v, t: 0.5 * torch.mean((v - t) ** 2), values, target)))
     regl = reg.mean()
     total = actor + critic_loss_weight * critic + regl
-    clipfrac = (torch.abs(ratio.detach() - 1.0) > clip_range).to(dt).mean()
+    clip_leaves = _leaves(_map(
+        lambda ln, lo: (torch.abs(torch.exp(ln.detach() - lo.to(dt)) - 1.0) > clip_range)
+        .to(dt).mean(), ll_new, mb.loglikelihoods))
+    clipfrac = sum(clip_leaves) / len(clip_leaves)
     return total, dict(actor=actor.detach(), critic=critic.detach(),
                        regularization=regl.detach(), clipping_fraction=clipfrac,
-                       advantages=adv, values=values.detach(), ll_new=ll_new.detach())
+                       advantages=adv, values=det(values), ll_new=det(ll_new))
 
 
 # ------------------------------------------------------------------ optimiser
@@ -223,7 +248,8 @@ def new_training_state(env, networks: Module, n_envs, seed, keys, learning_rate=
 
 def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discounting_factor,
              clip_range, normalize_advantages, n_epochs, n_minibatches, keys,
-             critic_loss_weight=1.0, minibatch_inds: Optional[torch.Tensor] = None):
+             critic_loss_weight=1.0, minibatch_inds: Optional[torch.Tensor] = None,
+             combine_advantages: bool = False):
     """ppo.py:254-348.  Returns (state, dict(loss rows [n_grad_steps] per term, rollout))."""
     networks = ts.networks
     ks = keys.split(ts.rng_key)
@@ -246,7 +272,8 @@ def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discoun
         st = _tmap(lambda x: x[inds], ts.network_states)  # PRE-rollout carry, ppo.py:298-300
         params = networks.parameters()
         total, lm = ppo_loss(networks, st, mb, clip_range, normalize_advantages,
-                             discounting_factor, gae_lambda, critic_loss_weight)
+                             discounting_factor, gae_lambda, critic_loss_weight,
+                             combine_advantages)
         grads = torch.autograd.grad(total, params, allow_unused=True)
         grads = [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
         if grads_first is None:
