@@ -250,6 +250,7 @@ def ppo_step(
     if LoggingLevel.GRAD_NORM in logging_level:
         grad_norms = torch.zeros(total_iterations, dtype=torch.float32, device=device)
 
+    critic_extra: dict = {}
     for i in range(total_iterations):
         inds = all_indices[i].contiguous()
         # minibatch gather x[:, inds] (ppo.py:297-300): every leaf in one launch
@@ -261,9 +262,13 @@ def ppo_step(
         net_state_subset = tree_map(lambda x: next(it).squeeze(0),
                                     training_state.network_states)
         optimizer.begin()
-        ppo_loss(networks, net_state_subset, minibatch, clip_range, normalize_advantages,
-                 combine_advantages, discounting_factor, gae_lambda, critic_loss_weight,
-                 logging_level, loss_out=loss_rows[i], want_total=False)
+        _, lm = ppo_loss(networks, net_state_subset, minibatch, clip_range,
+                         normalize_advantages, combine_advantages, discounting_factor,
+                         gae_lambda, critic_loss_weight, logging_level, loss_out=loss_rows[i],
+                         want_total=False)
+        for k in ("losses/advantages", "losses/critic_R^2"):
+            if k in lm:
+                critic_extra.setdefault(k, []).append(lm[k])
         have_norm = False
         if grad_norms is not None:
             grad_norms[i:i + 1].copy_(optimizer.compute_grad_norm())
@@ -283,12 +288,16 @@ def ppo_step(
         loss_metrics["losses/clipping_fraction"] = loss_rows[:, 3]
     if grad_norms is not None:
         loss_metrics["grad_norm"] = grad_norms
+    for k, v in critic_extra.items():  # stacked over the gradient steps, as the scan does
+        loss_metrics[k] = torch.stack(v, dim=0)
 
     total_steps = training_state.steps_taken + rollout_length * n_envs * parallel.world_size()
     metrics = compute_metrics(loss_metrics, rollout_data, logging_level, logging_percentiles)
     metrics["total_steps"] = total_steps
     if LoggingLevel.WEIGHTS in logging_level:
-        log_weight_stats(metrics, optimizer.params, logging_percentiles)
+        # the parameters themselves, not the arena (its alignment padding is zeros)
+        log_weight_stats(metrics, torch.cat([p.data.reshape(-1) for p in networks.parameters()]),
+                         logging_percentiles)
     networks.update_statistics(rollout_data.rollout_extras)
     _advance_noise(networks)
 
@@ -394,8 +403,19 @@ def ppo_loss(
             g_out = PPONetworkOutput(actions=None, loglikelihoods=g_ll.view(T, B),
                                      value_estimates=g_v.view(T, B))
             networks.replay_backward(ctx, g_out, 1.0 / float(T * B))
+        if LoggingLevel.CRITIC_EXTRA in logging_level:
+            # ppo.py:520-528 (diagnostics only: plain torch reductions on the side)
+            a = adv
+            if normalize_advantages:
+                a = (a - a.mean()) / (a.std(unbiased=False) + 1e-8)
+            target = values + adv
+            extra = {"losses/advantages": a,
+                     "losses/critic_R^2": 1.0 - 2.0 * loss_out[1] /
+                     (target.var(unbiased=False) + 1e-8)}
 
     loss_metrics: dict = {}
+    if LoggingLevel.CRITIC_EXTRA in logging_level and single:
+        loss_metrics.update(extra)
     if LoggingLevel.LOSSES in logging_level:
         loss_metrics["losses/actor"] = loss_out[0]
         loss_metrics["losses/critic"] = loss_out[1]

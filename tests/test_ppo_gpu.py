@@ -232,8 +232,16 @@ def test_train_ppo_end_to_end_and_callbacks(dev):
     for s, m in logs[1:]:
         for k in ("losses/actor/mean", "losses/critic/mean", "losses/regularization/mean",
                   "losses/actor/std", "total_steps", "grad_norm/mean", "weights/mean",
-                  "losses/clipping_fraction/mean", "throughput/train_sps"):
+                  "losses/clipping_fraction/mean", "throughput/train_sps",
+                  # CRITIC_EXTRA / ACTOR_EXTRA / TRAIN_ROLLOUT_STATS (ppo.py:509-528,
+                  # metrics.py:36-66)
+                  "losses/advantages/mean", "losses/critic_R^2/mean",
+                  "losses/predicted_value/mean", "loglikelihood/mean",
+                  "rollout_batch/reward/mean", "rollout_batch/done_rate"):
             assert k in m, k
+        # normalised advantages: zero mean over every gradient step's minibatch
+        assert abs(float(m["losses/advantages/mean"])) < 1e-4
+        assert float(m["losses/critic_R^2/mean"]) <= 1.0
         for k, v in m.items():
             val = v if isinstance(v, float) else float(v)
             assert np.isfinite(val), k
