@@ -87,13 +87,14 @@ struct IStep {
   int l, p, kc;  // layer, column pass (256 columns per pass), k-chunk
 };
 
-__device__ inline IStep istep_next(const Chain& c, IStep s) {
-  const int Kp = (c.layer[s.l].K + 31) / 32 * 32;
+// `ly` = descriptor of layer s.l
+__device__ inline IStep istep_next(const ChainLayer& ly, IStep s) {
+  const int Kp = (ly.K + 31) / 32 * 32;
   s.kc += IF_KC;
   if (s.kc >= Kp) {
     s.kc = 0;
     s.p += 1;
-    if (s.p * 256 >= c.layer[s.l].N) {
+    if (s.p * 256 >= ly.N) {
       s.p = 0;
       s.l += 1;
     }
@@ -124,8 +125,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   const int K0p = (K0 + 31) / 32 * 32;
 
   // column tile b of this wave in pass p starts at column ((p*4 + b)*4 + wave) * 16
-  auto load_frags = [&](const IStep& s, BFrags& B) {
-    const ChainLayer& ly = c.layer[s.l];
+  auto load_frags = [&](const IStep& s, const ChainLayer& ly, BFrags& B) {
     const int KS = (ly.K + 31) / 32;        // k-steps of this layer
     const int NT = (ly.N + 15) / 16;        // column tiles of this layer
 #pragma unroll
@@ -159,9 +159,16 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     }
   };
 
+  // Layer descriptors live in the kernel-argument segment; indexing them per step
+  // costs a scalar-memory round trip in front of every step (PMC: ~100 s_load per
+  // wave, WAIT_ANY 53 % of wave cycles).  The current and the next layer's
+  // descriptors are kept in registers instead and rolled forward at layer changes,
+  // so the load for layer l+2 is issued a whole layer before it is needed.
+  ChainLayer Lc = c.layer[0];
+  ChainLayer Ln = c.layer[c.L > 1 ? 1 : 0];
   IStep s = {0, 0, 0};
   BFrags B, Bn;
-  load_frags(s, B);
+  load_frags(s, Lc, B);
 
   // stage 0: fp32 input tile (x act'(aux0) in the backward) -> bf16, zero padded
   bool from_sampler = false;
@@ -209,9 +216,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   // instance of the step body (the two weight-fragment register sets are swapped by
   // register moves) — fully unrolled epilogues in several instances overflowed the
   // instruction cache and ran 5x slower than their MFMA + memory time.
-  auto epilogue = [&](const IStep& st, auto trans_tag) {
+  auto epilogue = [&](const IStep& st, const ChainLayer& ly, auto trans_tag) {
     constexpr bool TRANS = decltype(trans_tag)::value;
-    const ChainLayer& ly = c.layer[st.l];
     bf16_t* const nbuf = (st.l & 1) ? act0 : act1;
     const bool last = st.l == c.L - 1;
     const bool keep = !last || ly.out_bf;
@@ -308,12 +314,15 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
 
   while (s.l < c.L) {
     const IStep st = s;
-    const ChainLayer& ly = c.layer[st.l];
+    const ChainLayer& ly = Lc;
     const int Kp = (ly.K + 31) / 32 * 32;
     const bf16_t* const cbuf = (st.l & 1) ? act1 : act0;
     const bool pass_done = st.kc + IF_KC >= Kp;  // this step completes the wave's columns
-    const IStep sn = istep_next(c, st);
-    if (sn.l < c.L) load_frags(sn, Bn);
+    const IStep sn = istep_next(ly, st);
+    if (sn.l < c.L) {
+      if (sn.l == st.l) load_frags(sn, Lc, Bn);
+      else load_frags(sn, Ln, Bn);
+    }
     if constexpr (BWD) {
       if (pass_done && ly.aux && ly.act != MI_ACT_NONE) {
         // act' operands of this pass: 8 bytes per (row, column tile), in flight
@@ -360,9 +369,9 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     if (pass_done) {
       const bool trans = BWD ? ly.act == MI_ACT_SWISH : ly.act >= MI_ACT_TANH;
       if (trans) {
-        epilogue(st, std::true_type{});
+        epilogue(st, ly, std::true_type{});
       } else {
-        epilogue(st, std::false_type{});
+        epilogue(st, ly, std::false_type{});
       }
       if (sn.l != st.l) {  // layer finished: publish, copy out
         __syncthreads();
@@ -374,6 +383,10 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     for (int ks = 0; ks < IF_KS; ++ks)
 #pragma unroll
       for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
+    if (sn.l != st.l) {  // roll the descriptors: the load for layer l+2 starts now
+      Lc = Ln;
+      if (sn.l + 1 < c.L) Ln = c.layer[sn.l + 1];
+    }
     s = sn;
   }
   if constexpr (POLICY && !BWD) {
