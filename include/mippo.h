@@ -309,6 +309,17 @@ int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const float* h_prev
                        const float* w_h, const uint8_t* done, float* dgi, float* dgh, float* dh0,
                        int64_t T, int64_t B, int64_t H, mi_stream_t stream);
 
+/* The same recurrence and BPTT with h W_h (dgh W_h^T) on the bf16 matrix cores
+ * (operands rounded to bf16, fp32 accumulation, fp32 cell arithmetic and carry):
+ * same arguments as mi_gru_seq_fwd_f32 / mi_gru_seq_bwd_f32; H in {32, 64, 96, 128};
+ * h_prev_out and gates_out are both null (inference) or both given (training). */
+int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const float* b_hn, const float* h0,
+                        const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out,
+                        float* h_final, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_prev,
+                        const float* w_h, const uint8_t* done, float* dgi, float* dgh, float* dh0,
+                        int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
 /* ---- f2: LSTM carry (`nnx_ppo/networks/recurrent.py:16-161`) -------------- */
 
 /* The recurrence of the reference's LSTM layer over a whole sequence with

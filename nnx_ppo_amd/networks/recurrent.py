@@ -48,12 +48,18 @@ class GRU(StatefulModule):
     def _gi(self, x2: torch.Tensor) -> torch.Tensor:
         return ops.dense_fwd(x2, self.w_i.data, self.b_i.data, ops.ACT_NONE)
 
+    def _mfma(self) -> bool:
+        """bf16 compute: the recurrent product runs on the matrix cores (gru_mfma.hip)."""
+        from .. import config
+
+        return config.compute_dtype() == "bf16" and ops.gru_mfma_ok(self.hidden_features)
+
     def __call__(self, state: torch.Tensor, x: torch.Tensor,
                  rollout_extras: Any = None) -> StatefulModuleOutput:
         B = x.shape[0]
         gi = self._gi(x.reshape(B, self.in_features)).view(1, B, 3 * self.hidden_features)
         h_out, _, _, _ = ops.gru_seq_fwd(gi, self.w_h.data, self.b_hn.data, state.contiguous(),
-                                         None, train=False)
+                                         None, train=False, mfma=self._mfma())
         h = h_out[0]
         return StatefulModuleOutput(next_state=h, output=h,
                                     regularization_loss=torch.zeros(B, device=x.device),
@@ -72,17 +78,18 @@ class GRU(StatefulModule):
         H = self.hidden_features
         x2 = x_seq.reshape(T * B, self.in_features)
         gi = self._gi(x2).view(T, B, 3 * H)
+        mfma = self._mfma()
         h_out, h_prev, gates, h_final = ops.gru_seq_fwd(
             gi, self.w_h.data, self.b_hn.data, state0.contiguous(), done_seq.contiguous(),
-            train=True)
-        ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad)
+            train=True, mfma=mfma)
+        ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma)
         return ctx, h_out, None, h_final
 
     def replay_backward(self, ctx, g_out, g_reg):
-        x2, h_prev, gates, done_seq, (T, B), need_input_grad = ctx
+        x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma = ctx
         H = self.hidden_features
         dgi, dgh = ops.gru_seq_bwd(g_out.contiguous(), gates, h_prev, self.w_h.data,
-                                   done_seq.contiguous())
+                                   done_seq.contiguous(), mfma=mfma)
         dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)
         gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
         ops.dense_bwd_dw(h_prev.view(T * B, H), dgh2, None, self.w_h.grad, gb_h, ops.ACT_NONE,

@@ -828,8 +828,14 @@ def episode_step(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc, m
 
 
 # ------------------------------------------------------------- a20: GRU
-def gru_seq_fwd(gi, w_h, b_hn, h0, done, train: bool):
-    """gi [T,B,3H] -> (h_out [T,B,H], h_prev | None, gates | None, h_final [B,H])."""
+def gru_mfma_ok(H: int) -> bool:
+    """Hidden sizes the matrix-core GRU kernels take (csrc/gru_mfma.hip)."""
+    return H in (32, 64, 96, 128)
+
+
+def gru_seq_fwd(gi, w_h, b_hn, h0, done, train: bool, mfma: bool = False):
+    """gi [T,B,3H] -> (h_out [T,B,H], h_prev | None, gates | None, h_final [B,H]).
+    `mfma`: h W_h on the bf16 matrix cores (`mi_gru_seq_fwd_bf16`)."""
     T, B, H3 = gi.shape
     H = H3 // 3
     _need(w_h.shape == (H, H3) and b_hn.shape == (H,) and h0.shape == (B, H), "gru_seq_fwd: shapes")
@@ -841,22 +847,24 @@ def gru_seq_fwd(gi, w_h, b_hn, h0, done, train: bool):
     d = None if done is None else _as_u8(done)
     if d is not None:
         _need(d.shape == (T, B), "gru_seq_fwd: done must be [T, B]")
-    check(lib().mi_gru_seq_fwd_f32(ptr(gi, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32),
-                                   ptr(d), ptr(h_out, f32), ptr(h_prev, f32), ptr(gates, f32),
-                                   ptr(h_final, f32), T, B, H, stream()), "mi_gru_seq_fwd_f32")
+    fn = lib().mi_gru_seq_fwd_bf16 if mfma else lib().mi_gru_seq_fwd_f32
+    check(fn(ptr(gi, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32), ptr(d), ptr(h_out, f32),
+             ptr(h_prev, f32), ptr(gates, f32), ptr(h_final, f32), T, B, H, stream()),
+          "mi_gru_seq_fwd_bf16" if mfma else "mi_gru_seq_fwd_f32")
     return h_out, h_prev, gates, h_final
 
 
-def gru_seq_bwd(g_h, gates, h_prev, w_h, done):
+def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False):
     """Returns (dgi [T,B,3H], dgh [T,B,3H])."""
     T, B, H = g_h.shape
     dev = g_h.device
     dgi = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
     dgh = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
     d = None if done is None else _as_u8(done)
-    check(lib().mi_gru_seq_bwd_f32(ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32),
-                                   ptr(d), ptr(dgi, f32), ptr(dgh, f32), None, T, B, H, stream()),
-          "mi_gru_seq_bwd_f32")
+    fn = lib().mi_gru_seq_bwd_bf16 if mfma else lib().mi_gru_seq_bwd_f32
+    check(fn(ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d),
+             ptr(dgi, f32), ptr(dgh, f32), None, T, B, H, stream()),
+          "mi_gru_seq_bwd_bf16" if mfma else "mi_gru_seq_bwd_f32")
     return dgi, dgh
 
 

@@ -148,3 +148,61 @@ def test_gru_graph_capture(dev):
     for pa, pb in zip(na.parameters(), nb.parameters()):
         assert torch.equal(pa.data, pb.data)
     assert torch.equal(ta.network_states[1]["action"][1], tb.network_states[1]["action"][1])
+
+
+@pytest.mark.parametrize("T,B,I,H", [(1, 1, 3, 32), (30, 64, 64, 64), (12, 37, 5, 64),
+                                     (5, 33, 8, 128), (6, 20, 7, 96), (3, 4099, 5, 64)])
+def test_gru_matrix_core_path_vs_oracle(dev, T, B, I, H):
+    """bf16 compute: h W_h and dgh W_h^T on the matrix cores (operands rounded to bf16,
+    fp32 accumulation, fp32 cell) — against the fp64 oracle with the bf16 bound of the
+    Dense layers (2e-2 abs on O(1) activations, 5 % on gradients)."""
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.optim import Optimizer
+
+    prev = config.compute_dtype()
+    config.set_compute_dtype("bf16")
+    try:
+        g = _gru(I, H, seed=T + B)
+        g.to(dev)
+        assert g._mfma()
+        opt = Optimizer(g, 1e-3, device=dev)
+        og = on.from_product(g)
+        rng = np.random.default_rng(B)
+        x = rng.normal(size=(T, B, I)).astype(np.float32)
+        h0 = rng.normal(size=(B, H)).astype(np.float32)
+        done = rng.random((T, B)) < 0.2
+        gy = rng.normal(size=(T, B, H)).astype(np.float32)
+        t = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt).to(dev)
+        ctx, out, _, h_final = g.replay(t(h0), t(x), t(done, torch.bool), None, True)
+        x64 = torch.tensor(x, dtype=D, requires_grad=True)
+        h = torch.tensor(h0, dtype=D)
+        outs = []
+        for k in range(T):
+            o = og(h, x64[k])
+            outs.append(o.output)
+            h = torch.where(torch.tensor(done[k])[:, None], torch.zeros_like(o.next_state),
+                            o.next_state)
+        want = torch.stack(outs)
+        assert np.allclose(out.cpu().numpy(), want.detach().numpy(), atol=2e-2)
+        assert np.allclose(h_final.cpu().numpy(), h.detach().numpy(), atol=2e-2)
+        # single-step calls == sequence replay (same kernel, bit for bit)
+        hs = t(h0)
+        for k in range(min(T, 3)):
+            r = g(hs, t(x[k]))
+            assert torch.equal(r.output, out[k])
+            hs = torch.where(t(done[k], torch.bool)[:, None], torch.zeros_like(r.next_state),
+                             r.next_state)
+        opt.begin()
+        gx = g.replay_backward(ctx, t(gy), 0.0)
+        grads = torch.autograd.grad((want * torch.tensor(gy, dtype=D)).sum(),
+                                    [x64, og.w_i, og.b_i, og.w_h, og.b_hn])
+        def close(a, b):
+            a, b = a.cpu().numpy().ravel(), b.numpy().ravel()
+            cos = float(a @ b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+            rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+            return cos > 0.995 and rel < 0.08
+        assert close(gx, grads[0])
+        for p_, w in zip((g.w_i, g.b_i, g.w_h, g.b_hn), grads[1:]):
+            assert close(p_.grad, w)
+    finally:
+        config.set_compute_dtype(prev)
