@@ -24,17 +24,28 @@ namespace {
 using namespace mippo_bf16;
 
 constexpr int GROWS = 16;
-constexpr int MAXUT = 2;  // unit tiles per wave: H <= 128
+// Steps of look-ahead for the per-step global operands (gi forward; gates, g_h, h_prev
+// backward).  They do not depend on the recurrence, and a step's arithmetic (~0.3 us)
+// is far shorter than an HBM round trip (~2 us): with one step of look-ahead every
+// step waited for memory (3.4 us / step measured); the time loop is unrolled PF times
+// over a ring of register slots instead.
+constexpr int PF = 4;
 
-__device__ inline float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <bool TRAIN>
+// Addressing: a lane's element offsets (row * stride + unit) are fixed for the whole
+// sequence and fit 32 bits; per step only a wave-uniform base pointer moves.  Rows past
+// B (last workgroup) are clamped for loads and masked for stores, so the step body has
+// no per-element branches — with one wave per SIMD every instruction's latency is
+// exposed and the first version of this kernel spent ~2000 instructions per step on
+// predicates and 64-bit address arithmetic.
+template <bool TRAIN, int UTW>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
                     const uint8_t* __restrict__ done, float* __restrict__ h_out,
                     float* __restrict__ h_prev_out, float* __restrict__ gates_out,
                     float* __restrict__ h_final, int64_t T, int64_t B, int H) {
+  constexpr int PFW = UTW == 1 ? PF : PF / 2;  // look-ahead that still fits the registers
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int HROW = H + 8;
   bf16_t* hb0 = reinterpret_cast<bf16_t*>(lds_raw);  // [2][16][H + 8]
@@ -49,9 +60,9 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   const int UT = H / 16;
 
   // W_h fragments of this wave's units: B operand = W_h[k][gate*H + unit]
-  bf16x8 wf[MAXUT][3][4];
+  bf16x8 wf[UTW][3][4];
 #pragma unroll
-  for (int ui = 0; ui < MAXUT; ++ui) {
+  for (int ui = 0; ui < UTW; ++ui) {
     const int ut = wave + 4 * ui;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -67,47 +78,58 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
         wf[ui][g][ks] = f;
       }
   }
-  // carry of (row 4*lq + e, unit ut*16 + li), e = 0..3
-  float h[MAXUT][4];
-  float bn[MAXUT];
+  // element (ui, e): row 4*lq + e, unit (wave + 4*ui)*16 + li
+  bool valid[4];
+  unsigned rowc[4];  // row clamped into [0, B): loads never leave the tensors
 #pragma unroll
-  for (int ui = 0; ui < MAXUT; ++ui) {
+  for (int e = 0; e < 4; ++e) {
+    const int64_t row = row0 + 4 * lq + e;
+    valid[e] = row < B;
+    rowc[e] = (unsigned)(valid[e] ? row : B - 1);
+  }
+  float h[UTW][4];
+  float bn[UTW];
+  unsigned unit[UTW];
+#pragma unroll
+  for (int ui = 0; ui < UTW; ++ui) {
     const int ut = wave + 4 * ui;
-    bn[ui] = ut < UT ? b_hn[ut * 16 + li] : 0.0f;
+    const bool on = ut < UT;
+    unit[ui] = (unsigned)((on ? ut : 0) * 16 + li);
+    bn[ui] = on ? b_hn[unit[ui]] : 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t row = row0 + 4 * lq + e;
-      const float v = (ut < UT && row < B) ? h0[row * H + ut * 16 + li] : 0.0f;
+      const float v = (on && valid[e]) ? h0[rowc[e] * (unsigned)H + unit[ui]] : 0.0f;
       h[ui][e] = v;
-      if (ut < UT) hb0[(4 * lq + e) * HROW + ut * 16 + li] = (bf16_t)v;
+      if (on) hb0[(4 * lq + e) * HROW + unit[ui]] = (bf16_t)v;
     }
   }
-  // gi of step t for the owned elements, prefetched one step ahead
-  float gcur[MAXUT][3][4], gnxt[MAXUT][3][4];
-  auto load_gi = [&](int64_t t, float (&dst)[MAXUT][3][4]) {
+  const int64_t last_t = T - 1;
+  // gi / done of steps t .. t+PFW-1 for the owned elements (ring of PFW register slots)
+  float gq[PFW][UTW][3][4];
+  float dq[PFW][4];
+  auto load_step = [&](int64_t t, float (&dst)[UTW][3][4], float (&dn)[4]) {
+    const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
+    const float* gt = gi + tc * B * H3;
+    const uint8_t* dt = done ? done + tc * B : nullptr;
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui) {
-      const int ut = wave + 4 * ui;
+    for (int e = 0; e < 4; ++e) dn[e] = (dt && dt[rowc[e]] != 0) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int64_t row = row0 + 4 * lq + e;
-          dst[ui][g][e] = (ut < UT && row < B && t < T)
-                              ? gi[(t * B + row) * H3 + g * H + ut * 16 + li]
-                              : 0.0f;
-        }
-    }
+        for (int e = 0; e < 4; ++e)
+          dst[ui][g][e] = gt[rowc[e] * (unsigned)H3 + (unsigned)(g * H) + unit[ui]];
   };
-  load_gi(0, gcur);
+#pragma unroll
+  for (int d = 0; d < PFW; ++d) load_step(d, gq[d], dq[d]);
   __syncthreads();
   bf16_t* hb = hb0;
   bf16_t* hbn = hb1;
-  for (int64_t t = 0; t < T; ++t) {
-    load_gi(t + 1, gnxt);
-    f32x4 acc[MAXUT][3];
+  auto step = [&](int64_t t, float (&gcur)[UTW][3][4], float (&dcur)[4]) {
+    f32x4 acc[UTW][3];
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui)
+    for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[ui][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -115,81 +137,74 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
       if (ks < KS) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
 #pragma unroll
-        for (int ui = 0; ui < MAXUT; ++ui) {
-          if (wave + 4 * ui < UT) {
+        for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)  // D[row = 4*lq + e][col = li]
-              acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ui][g][ks], acc[ui][g],
-                                                                  0, 0, 0);
-          }
-        }
+          for (int g = 0; g < 3; ++g)  // D[row = 4*lq + e][col = li]
+            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ui][g][ks], acc[ui][g],
+                                                                0, 0, 0);
       }
     }
+    float* ho = h_out + t * B * H;
+    float* hpo = TRAIN ? h_prev_out + t * B * H : nullptr;
+    float* gto = TRAIN ? gates_out + t * B * 4 * H : nullptr;
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui) {
-      const int ut = wave + 4 * ui;
-      if (ut >= UT) continue;
-      const int u = ut * 16 + li;
+    for (int ui = 0; ui < UTW; ++ui) {
+      if (wave + 4 * ui >= UT) continue;  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int lr = 4 * lq + e;
-        const int64_t row = row0 + lr;
         const float hp = h[ui][e];
-        const float r = sigm(gcur[ui][0][e] + acc[ui][0][e]);
-        const float z = sigm(gcur[ui][1][e] + acc[ui][1][e]);
+        const float r = fast_sigmoid(gcur[ui][0][e] + acc[ui][0][e]);
+        const float z = fast_sigmoid(gcur[ui][1][e] + acc[ui][1][e]);
         const float qn = acc[ui][2][e] + bn[ui];
-        const float n = tanhf(gcur[ui][2][e] + r * qn);
+        const float n = fast_tanh(gcur[ui][2][e] + r * qn);
         const float hnew = (1.0f - z) * n + z * hp;
-        bool d = false;
-        if (row < B) {
-          const int64_t o = (t * B + row) * H + u;
-          h_out[o] = hnew;
+        if (valid[e]) {
+          const unsigned o = rowc[e] * (unsigned)H + unit[ui];
+          ho[o] = hnew;
           if constexpr (TRAIN) {
-            h_prev_out[o] = hp;
-            float* go = gates_out + (t * B + row) * 4 * H;
-            go[u] = r;
-            go[H + u] = z;
-            go[2 * H + u] = n;
-            go[3 * H + u] = qn;
+            hpo[o] = hp;
+            const unsigned og = rowc[e] * (unsigned)(4 * H) + unit[ui];
+            gto[og] = r;
+            gto[og + (unsigned)H] = z;
+            gto[og + (unsigned)(2 * H)] = n;
+            gto[og + (unsigned)(3 * H)] = qn;
           }
-          d = done ? done[t * B + row] != 0 : false;
         }
-        const float hc = d ? 0.0f : hnew;
+        const float hc = dcur[e] != 0.0f ? 0.0f : hnew;
         h[ui][e] = hc;
-        hbn[lr * HROW + u] = (bf16_t)hc;
+        hbn[(4 * lq + e) * HROW + unit[ui]] = (bf16_t)hc;
       }
     }
     __syncthreads();
     bf16_t* tmp = hb;
     hb = hbn;
     hbn = tmp;
+    load_step(t + PFW, gcur, dcur);  // refill this slot: consumed PFW steps from now
+  };
+  for (int64_t t0 = 0; t0 < T; t0 += PFW) {
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui)
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gcur[ui][g][e] = gnxt[ui][g][e];
+    for (int d = 0; d < PFW; ++d)
+      if (t0 + d < T) step(t0 + d, gq[d], dq[d]);
   }
 #pragma unroll
-  for (int ui = 0; ui < MAXUT; ++ui) {
-    const int ut = wave + 4 * ui;
-    if (ut >= UT) continue;
+  for (int ui = 0; ui < UTW; ++ui) {
+    if (wave + 4 * ui >= UT) continue;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t row = row0 + 4 * lq + e;
-      if (row < B) h_final[row * H + ut * 16 + li] = h[ui][e];
-    }
+    for (int e = 0; e < 4; ++e)
+      if (valid[e]) h_final[rowc[e] * (unsigned)H + unit[ui]] = h[ui][e];
   }
 }
 
 // BPTT (formulas in gru.hip).  dh carry in registers; dgh tile (bf16) in LDS is the A
 // operand of dh_prev += dgh . W_h^T; B operand = W_h[unit][j] rows (contiguous in j).
+template <int UTW>
 __global__ void __launch_bounds__(kThreads)
 gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
                     const float* __restrict__ h_prev, const float* __restrict__ w_h,
                     const uint8_t* __restrict__ done, float* __restrict__ dgi,
                     float* __restrict__ dgh, float* __restrict__ dh0, int64_t T, int64_t B,
                     int H) {
+  constexpr int PFW = UTW == 1 ? PF : 1;  // 2 unit tiles: no registers left for a ring
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int H3 = 3 * H;
   const int GROW = H3 + 8;
@@ -204,9 +219,9 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
   const int UT = H / 16;
 
   // W_h^T fragments: B[k_red = j][col = unit] = W_h[unit][j]
-  bf16x8 wf[MAXUT][12];
+  bf16x8 wf[UTW][12];
 #pragma unroll
-  for (int ui = 0; ui < MAXUT; ++ui) {
+  for (int ui = 0; ui < UTW; ++ui) {
     const int ut = wave + 4 * ui;
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks) {
@@ -219,87 +234,128 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
       wf[ui][ks] = f;
     }
   }
-  float dh[MAXUT][4];
+  bool valid[4];
+  unsigned rowc[4];
 #pragma unroll
-  for (int ui = 0; ui < MAXUT; ++ui)
+  for (int e = 0; e < 4; ++e) {
+    const int64_t row = row0 + 4 * lq + e;
+    valid[e] = row < B;
+    rowc[e] = (unsigned)(valid[e] ? row : B - 1);
+  }
+  unsigned unit[UTW];
+  float dh[UTW][4];
+#pragma unroll
+  for (int ui = 0; ui < UTW; ++ui) {
+    const int ut = wave + 4 * ui;
+    unit[ui] = (unsigned)((ut < UT ? ut : 0) * 16 + li);
 #pragma unroll
     for (int e = 0; e < 4; ++e) dh[ui][e] = 0.0f;
+  }
+  // per-step operands of the owned elements: (r, z, n, qn, g_h, h_prev), done; ring of PFW
+  struct In {
+    float v[UTW][4][6];
+    float dn[4];
+  };
+  In inq[PFW];
+  auto load_in = [&](int64_t t, In& dst) {
+    const int64_t tc = t > 0 ? t : 0;  // before the start: reload step 0
+    const float* gt = gates + tc * B * 4 * H;
+    const float* ght = g_h + tc * B * H;
+    const float* hpt = h_prev + tc * B * H;
+    const uint8_t* dt = done ? done + tc * B : nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst.dn[e] = (dt && dt[rowc[e]] != 0) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int ui = 0; ui < UTW; ++ui)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned og = rowc[e] * (unsigned)(4 * H) + unit[ui];
+        const unsigned o = rowc[e] * (unsigned)H + unit[ui];
+        dst.v[ui][e][0] = gt[og];
+        dst.v[ui][e][1] = gt[og + (unsigned)H];
+        dst.v[ui][e][2] = gt[og + (unsigned)(2 * H)];
+        dst.v[ui][e][3] = gt[og + (unsigned)(3 * H)];
+        dst.v[ui][e][4] = ght[o];
+        dst.v[ui][e][5] = hpt[o];
+      }
+  };
+#pragma unroll
+  for (int d = 0; d < PFW; ++d) load_in(T - 1 - d, inq[d]);
   bf16_t* dg = dg0;
   bf16_t* dgn_buf = dg1;
-  for (int64_t t = T - 1; t >= 0; --t) {
-    float dhp[MAXUT][4];
+  auto step = [&](int64_t t, In& in) {
+    float dhp[UTW][4];
+    float* gio = dgi + t * B * H3;
+    float* gho = dgh + t * B * H3;
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui) {
-      const int ut = wave + 4 * ui;
-      if (ut >= UT) continue;
-      const int u = ut * 16 + li;
+    for (int ui = 0; ui < UTW; ++ui) {
+      if (wave + 4 * ui >= UT) continue;  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int lr = 4 * lq + e;
-        const int64_t row = row0 + lr;
-        float da_r = 0.f, da_z = 0.f, da_n = 0.f, dgn = 0.f, dp = 0.f;
-        if (row < B) {
-          const int64_t o = (t * B + row) * H + u;
-          const float* go = gates + (t * B + row) * 4 * H;
-          const float r = go[u], z = go[H + u], n = go[2 * H + u], qn = go[3 * H + u];
-          const bool d = done ? done[t * B + row] != 0 : false;
-          const float dht = g_h[o] + (d ? 0.0f : dh[ui][e]);
-          const float hp = h_prev[o];
-          const float dn = dht * (1.0f - z);
-          const float dz = dht * (hp - n);
-          dp = dht * z;
-          da_n = dn * (1.0f - n * n);
-          const float dr = da_n * qn;
-          da_z = dz * z * (1.0f - z);
-          da_r = dr * r * (1.0f - r);
-          dgn = da_n * r;
-          float* gi_o = dgi + (t * B + row) * H3;
-          gi_o[u] = da_r;
-          gi_o[H + u] = da_z;
-          gi_o[2 * H + u] = da_n;
-          float* gh_o = dgh + (t * B + row) * H3;
-          gh_o[u] = da_r;
-          gh_o[H + u] = da_z;
-          gh_o[2 * H + u] = dgn;
+        const float r = in.v[ui][e][0], z = in.v[ui][e][1], n = in.v[ui][e][2],
+                    qn = in.v[ui][e][3];
+        const float dht = in.v[ui][e][4] + (in.dn[e] != 0.0f ? 0.0f : dh[ui][e]);
+        const float hp = in.v[ui][e][5];
+        const float dn = dht * (1.0f - z);
+        const float dz = dht * (hp - n);
+        float dp = dht * z;
+        float da_n = dn * (1.0f - n * n);
+        const float dr = da_n * qn;
+        float da_z = dz * z * (1.0f - z);
+        float da_r = dr * r * (1.0f - r);
+        float dgn = da_n * r;
+        if (valid[e]) {
+          const unsigned o3 = rowc[e] * (unsigned)H3 + unit[ui];
+          gio[o3] = da_r;
+          gio[o3 + (unsigned)H] = da_z;
+          gio[o3 + (unsigned)(2 * H)] = da_n;
+          gho[o3] = da_r;
+          gho[o3 + (unsigned)H] = da_z;
+          gho[o3 + (unsigned)(2 * H)] = dgn;
+        } else {
+          da_r = da_z = dgn = dp = 0.0f;
         }
-        dg[lr * GROW + u] = (bf16_t)da_r;
-        dg[lr * GROW + H + u] = (bf16_t)da_z;
-        dg[lr * GROW + 2 * H + u] = (bf16_t)dgn;
+        dg[lr * GROW + unit[ui]] = (bf16_t)da_r;
+        dg[lr * GROW + H + unit[ui]] = (bf16_t)da_z;
+        dg[lr * GROW + 2 * H + unit[ui]] = (bf16_t)dgn;
         dhp[ui][e] = dp;
       }
     }
+    load_in(t - PFW, in);  // refill this slot: consumed PFW steps from now
     __syncthreads();
-    f32x4 acc[MAXUT];
+    f32x4 acc[UTW];
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks) {
       if (ks < KS) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
 #pragma unroll
-        for (int ui = 0; ui < MAXUT; ++ui)
-          if (wave + 4 * ui < UT)
-            acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ui][ks], acc[ui], 0, 0, 0);
+        for (int ui = 0; ui < UTW; ++ui)
+          acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ui][ks], acc[ui], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui)
+    for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
       for (int e = 0; e < 4; ++e) dh[ui][e] = dhp[ui][e] + acc[ui][e];
     bf16_t* tmp = dg;  // the next step writes the other tile: one barrier per step
     dg = dgn_buf;
     dgn_buf = tmp;
+  };
+  for (int64_t t0 = T - 1; t0 >= 0; t0 -= PFW) {
+#pragma unroll
+    for (int d = 0; d < PFW; ++d)
+      if (t0 - d >= 0) step(t0 - d, inq[d]);
   }
   if (dh0) {
 #pragma unroll
-    for (int ui = 0; ui < MAXUT; ++ui) {
-      const int ut = wave + 4 * ui;
-      if (ut >= UT) continue;
+    for (int ui = 0; ui < UTW; ++ui) {
+      if (wave + 4 * ui >= UT) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t row = row0 + 4 * lq + e;
-        if (row < B) dh0[row * H + ut * 16 + li] = dh[ui][e];
-      }
+      for (int e = 0; e < 4; ++e)
+        if (valid[e]) dh0[rowc[e] * (unsigned)H + unit[ui]] = dh[ui][e];
     }
   }
 }
@@ -312,7 +368,7 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
                                    const float* h0, const uint8_t* done, float* h_out,
                                    float* h_prev_out, float* gates_out, float* h_final,
                                    int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
-  MI_REQUIRE(T >= 0 && B >= 0 && mfma_shape_ok(H),
+  MI_REQUIRE(T >= 0 && B >= 0 && mfma_shape_ok(H) && B * 4 * H < (1LL << 31),
              "mi_gru_seq_fwd_bf16: bad shape T=%lld B=%lld H=%lld (H in {32, 64, 96, 128})",
              (long long)T, (long long)B, (long long)H);
   if (B == 0) return 0;
@@ -324,13 +380,15 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
   const size_t lds = (size_t)2 * GROWS * (H + 8) * sizeof(bf16_t);
   const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
   hipStream_t st = mippo::as_stream(stream);
+#define MI_GRU_FWD(TRAIN, UTW)                                                                  \
+  hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, UTW>), grid, dim3(kThreads), lds, st, gi, w_h, \
+                     b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H)
   if (h_prev_out) {
-    hipLaunchKernelGGL((gru_fwd_mfma_kernel<true>), grid, dim3(kThreads), lds, st, gi, w_h, b_hn,
-                       h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H);
+    if (H <= 64) MI_GRU_FWD(true, 1); else MI_GRU_FWD(true, 2);
   } else {
-    hipLaunchKernelGGL((gru_fwd_mfma_kernel<false>), grid, dim3(kThreads), lds, st, gi, w_h, b_hn,
-                       h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H);
+    if (H <= 64) MI_GRU_FWD(false, 1); else MI_GRU_FWD(false, 2);
   }
+#undef MI_GRU_FWD
   return mippo::check_launch("mi_gru_seq_fwd_bf16");
 }
 
@@ -338,11 +396,18 @@ extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const f
                                    const float* w_h, const uint8_t* done, float* dgi, float* dgh,
                                    float* dh0, int64_t T, int64_t B, int64_t H,
                                    mi_stream_t stream) {
-  MI_REQUIRE(T >= 1 && B >= 1 && mfma_shape_ok(H), "mi_gru_seq_bwd_bf16: bad shape");
+  MI_REQUIRE(T >= 1 && B >= 1 && mfma_shape_ok(H) && B * 4 * H < (1LL << 31),
+             "mi_gru_seq_bwd_bf16: bad shape");
   MI_REQUIRE(g_h && gates && h_prev && w_h && dgi && dgh, "mi_gru_seq_bwd_bf16: null pointer");
   const size_t lds = (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t);
-  hipLaunchKernelGGL(gru_bwd_mfma_kernel, dim3((unsigned)mippo::ceil_div(B, GROWS)),
-                     dim3(kThreads), lds, mippo::as_stream(stream), g_h, gates, h_prev, w_h, done,
-                     dgi, dgh, dh0, T, B, (int)H);
+  const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
+  hipStream_t st = mippo::as_stream(stream);
+  if (H <= 64) {
+    hipLaunchKernelGGL((gru_bwd_mfma_kernel<1>), grid, dim3(kThreads), lds, st, g_h, gates, h_prev,
+                       w_h, done, dgi, dgh, dh0, T, B, (int)H);
+  } else {
+    hipLaunchKernelGGL((gru_bwd_mfma_kernel<2>), grid, dim3(kThreads), lds, st, g_h, gates, h_prev,
+                       w_h, done, dgi, dgh, dh0, T, B, (int)H);
+  }
   return mippo::check_launch("mi_gru_seq_bwd_bf16");
 }
