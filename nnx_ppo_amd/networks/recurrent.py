@@ -27,6 +27,17 @@ from . import initializers
 from .types import Parameter, Rngs, StatefulModule, StatefulModuleOutput
 
 
+class _Projection:
+    """A weight / bias pair of a recurrent layer presented to `dense_chain` as a
+    linear Dense layer (bf16 shadows, whole-trunk kernels, grouped dW)."""
+
+    act_code = ops.ACT_NONE
+
+    def __init__(self, kernel: Parameter, bias, in_features: int, out_features: int):
+        self.kernel, self.bias = kernel, bias
+        self.in_features, self.out_features = in_features, out_features
+
+
 class GRU(StatefulModule):
     def __init__(self, in_features: int, hidden_features: int, rngs: Rngs, *, kernel_init=None,
                  recurrent_kernel_init=None):
@@ -46,7 +57,18 @@ class GRU(StatefulModule):
         self.b_hn = Parameter(np.zeros(H, dtype=np.float32))
 
     def _gi(self, x2: torch.Tensor) -> torch.Tensor:
+        if self._mfma():  # bf16 compute: the input projection is a one-layer bf16 trunk
+            from . import dense_chain
+
+            return dense_chain.forward_infer([self._proj()], x2)
         return ops.dense_fwd(x2, self.w_i.data, self.b_i.data, ops.ACT_NONE)
+
+    def _proj(self) -> _Projection:
+        p = self.__dict__.get("_proj_i")
+        if p is None or p.kernel is not self.w_i:
+            p = _Projection(self.w_i, self.b_i, self.in_features, 3 * self.hidden_features)
+            self.__dict__["_proj_i"] = p
+        return p
 
     def _mfma(self) -> bool:
         """bf16 compute: the recurrent product runs on the matrix cores (gru_mfma.hip)."""
@@ -77,20 +99,40 @@ class GRU(StatefulModule):
         T, B, _ = x_seq.shape
         H = self.hidden_features
         x2 = x_seq.reshape(T * B, self.in_features)
-        gi = self._gi(x2).view(T, B, 3 * H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
         mfma = self._mfma()
+        pctx = None
+        if mfma:
+            from . import dense_chain
+
+            pctx, gi2 = dense_chain.forward_train([self._proj()], x2, need_input_grad)
+            gi = gi2.view(T, B, 3 * H)
+        else:
+            gi = self._gi(x2).view(T, B, 3 * H)
         h_out, h_prev, gates, h_final = ops.gru_seq_fwd(
             gi, self.w_h.data, self.b_hn.data, state0.contiguous(), done_seq.contiguous(),
             train=True, mfma=mfma)
-        ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma)
+        ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx)
         return ctx, h_out, None, h_final
 
     def replay_backward(self, ctx, g_out, g_reg):
-        x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma = ctx
+        x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx
         H = self.hidden_features
         dgi, dgh = ops.gru_seq_bwd(g_out.contiguous(), gates, h_prev, self.w_h.data,
                                    done_seq.contiguous(), mfma=mfma)
         dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)
+        if mfma:
+            # bf16 compute: weight gradients on the bf16 matrix cores too
+            from . import dense_chain
+
+            gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
+            ops.dense_bwd_dw_grouped_bf16(
+                [(ops.cast_pad_bf16(h_prev.view(T * B, H)), ops.cast_pad_bf16(dgh2),
+                  self.w_h.grad, gb_h)], accumulate=True)
+            self.b_hn.grad += gb_h[2 * H:]
+            g_x = dense_chain.backward([self._proj()], pctx, dgi2)
+            return None if g_x is None else g_x.view(T, B, self.in_features)
         gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
         ops.dense_bwd_dw(h_prev.view(T * B, H), dgh2, None, self.w_h.grad, gb_h, ops.ACT_NONE,
                          accumulate=True)
