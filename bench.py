@@ -281,6 +281,10 @@ def main():
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from Python instead of replaying the captured "
                          "HIP graph of the iteration")
+    ap.add_argument("--capture-collectives", action="store_true",
+                    help="N > 1: capture the RCCL all-reduces INTO the iteration's HIP graph "
+                         "(one graph launch per iteration) instead of the default sequence of "
+                         "graphs with eager collectives between them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -320,12 +324,14 @@ def main():
     env, net, ts = build(device)
     graphed = None
     if not args.eager:
-        from nnx_ppo_amd.algorithms.graph import GraphedPPOStep
+        from nnx_ppo_amd.algorithms.graph import GraphedPPOStep, SegmentedPPOStep
 
+        # N > 1: by default a sequence of graphs with the collectives between them (needs
+        # nothing from RCCL); --capture-collectives records them into ONE graph
+        Recorder = GraphedPPOStep if (world == 1 or args.capture_collectives) else SegmentedPPOStep
         try:
-            # N > 1: the RCCL all-reduces of the iteration are captured with it
-            graphed = GraphedPPOStep(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, False, N_EPOCHS,
-                                     N_MB, warmup=2)
+            graphed = Recorder(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, False, N_EPOCHS,
+                               N_MB, warmup=2)
         except Exception as exc:  # capture unsupported for something in the iteration
             print(f"[bench] rank {rank}: HIP-graph capture failed ({exc!r}); running eager",
                   file=sys.stderr)
@@ -408,7 +414,13 @@ def main():
                 "n_envs_per_gpu": N_ENVS, "rollout_length": T,
                 "global_n_envs": world * N_ENVS, "parallelism": f"env-sharded dp{world}",
             },
-            "launch_mode": "eager" if args.eager else "hip-graph (one hipGraphLaunch per iteration)",
+            "launch_mode": "eager" if args.eager else (
+                "hip-graph (one hipGraphLaunch per iteration)"
+                if (world == 1 or args.capture_collectives) else
+                f"{sum(1 for x in graphed.program if isinstance(x, torch.cuda.CUDAGraph))} HIP "
+                f"graphs per iteration with "
+                f"{sum(1 for x in graphed.program if not isinstance(x, torch.cuda.CUDAGraph))} "
+                "eager collectives between them"),
             "roofline": roof,
             "kernels_ms_per_iter": per_kernel,
             "final_losses": {k: float(v) for k, v in metrics.items() if k.startswith("losses/")},

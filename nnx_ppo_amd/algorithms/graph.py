@@ -120,3 +120,76 @@ class GraphedPPOStep:
     def __call__(self):
         self.graph.replay()
         return self.ts, self.metrics
+
+
+class SegmentedPPOStep:
+    """A sharded iteration as a SEQUENCE of HIP graphs with the collectives between them.
+
+    Capturing RCCL calls into a HIP graph is the fastest form (`GraphedPPOStep` in a
+    sharded run), but an aborted capture leaves the process unusable and a wedged
+    replay cannot be recovered from.  This recorder needs nothing from the collective
+    library: `parallel._collective` closes the graph under capture, runs the collective
+    eagerly, and opens the next graph in the same memory pool.  An iteration of the
+    BASELINE workload becomes ~35 graph launches + 34 eager collectives instead of ~500
+    kernel launches from Python.  Same contract as `GraphedPPOStep`."""
+
+    def __init__(self, env, training_state: TrainingState, *args: Any, warmup: int = 2,
+                 **kwargs: Any):
+        from .. import parallel
+
+        self.env = env
+        self.ts = training_state
+        self.program: list = []
+        cur = torch.cuda.current_stream()
+        self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            for _ in range(warmup):
+                new_ts, _ = ppo_step(env, self.ts, *args, **kwargs)
+                _copy_state(self.ts, new_ts)
+        cur.wait_stream(self._stream)
+        torch.cuda.synchronize()
+        self._pool = torch.cuda.graph_pool_handle()
+        self._cur = None
+        failure = None
+        with torch.cuda.stream(self._stream):
+            self._begin()
+            parallel._segmenter = self
+            try:
+                new_ts, metrics = ppo_step(env, self.ts, *args, **kwargs)
+                _copy_state(self.ts, new_ts)
+            except BaseException as exc:  # noqa: BLE001 - re-raised below
+                failure = exc
+            finally:
+                parallel._segmenter = None
+            try:
+                self._end()
+            except Exception as exc:
+                failure = failure or exc
+        cur.wait_stream(self._stream)
+        if failure is not None:
+            raise RuntimeError(f"segmented capture of ppo_step failed: {failure!r}") from failure
+        self.metrics = metrics
+
+    def _begin(self) -> None:
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+
+    def _end(self) -> None:
+        g, self._cur = self._cur, None
+        g.capture_end()
+        self.program.append(g)
+
+    def collective(self, fn) -> None:
+        self._end()
+        fn()  # every rank takes part once while recording, too
+        self.program.append(fn)
+        self._begin()
+
+    def __call__(self):
+        for item in self.program:
+            if isinstance(item, torch.cuda.CUDAGraph):
+                item.replay()
+            else:
+                item()
+        return self.ts, self.metrics

@@ -30,18 +30,31 @@ def rank() -> int:
     return dist.get_rank() if is_distributed() else 0
 
 
+# While an iteration is being recorded as a SEQUENCE of HIP graphs
+# (algorithms/graph.py:SegmentedPPOStep) the recorder sits here: every collective
+# closes the graph being captured, runs eagerly, and opens the next one.
+_segmenter = None
+
+
+def _collective(fn) -> None:
+    if _segmenter is not None:
+        _segmenter.collective(fn)
+    else:
+        fn()
+
+
 def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """In-place mean over ranks (gradient arena; equal shard sizes, so the mean of
     per-shard mean-losses' gradients is the global-minibatch gradient)."""
     if is_distributed():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        _collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
         flat.mul_(1.0 / dist.get_world_size())
     return flat
 
 
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
     return t
 
 
@@ -64,5 +77,6 @@ def merge_batch_stats(stats: torch.Tensor) -> torch.Tensor:
     if not is_distributed():
         return stats
     parts = [torch.empty_like(stats) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, stats.contiguous())
+    src = stats.contiguous()
+    _collective(lambda: dist.all_gather(parts, src))
     return chan_merge(parts).contiguous()
