@@ -315,3 +315,62 @@ def test_graphed_step_equals_eager(dev):
     assert torch.equal(ts_a.rng_key, ts_b.rng_key)
     for k in m_a:
         assert torch.equal(torch.as_tensor(m_a[k]), torch.as_tensor(m_b[k])), k
+
+
+def test_segmented_capture_equals_eager(dev, monkeypatch):
+    """A sharded iteration recorded as graph / collective / graph / ... replays to the
+    same bits as eager launches.  The collectives are stand-ins of a one-rank group
+    (identity all-reduce, copy all-gather) so the segmentation itself is what is
+    tested: 16 gradient steps x 2 + normaliser merge + loss rows = 34 cuts."""
+    from nnx_ppo_amd import parallel
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.graph import SegmentedPPOStep
+    from nnx_ppo_amd.envs import MockEnv
+
+    calls = []
+
+    class _Dist:
+        class ReduceOp:
+            SUM = "sum"
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            calls.append("ar")
+
+        @staticmethod
+        def all_gather(parts, src):
+            calls.append("ag")
+            parts[0].copy_(src)
+
+        @staticmethod
+        def get_world_size():
+            return 1
+
+    monkeypatch.setattr(parallel, "dist", _Dist)
+    monkeypatch.setattr(parallel, "is_distributed", lambda: True)
+    monkeypatch.setattr(parallel, "world_size", lambda: 1)
+    monkeypatch.setattr(parallel, "rank", lambda: 0)
+
+    def setup():
+        env = MockEnv(5, 1, max_steps=7)
+        net = _make(5, 1, [32, 32], [32])
+        return env, net, ppo.new_training_state(env, net, 64, 9, 1e-3, device=dev)
+
+    args = (64, 8, 0.95, 0.99, 0.2, True, False, 4, 4)
+    ea, na, ta = setup()
+    for _ in range(4):
+        ta, ma = ppo.ppo_step(ea, ta, *args)
+    calls.clear()
+    eb, nb, tb = setup()
+    step = SegmentedPPOStep(eb, tb, *args, warmup=1)
+    n_coll = sum(1 for x in step.program if not isinstance(x, torch.cuda.CUDAGraph))
+    assert n_coll == 34 and len(step.program) == 2 * n_coll + 1
+    for _ in range(3):
+        tb, mb = step()
+    torch.cuda.synchronize()
+    for pa, pb in zip(na.parameters(), nb.parameters()):
+        assert torch.equal(pa.data, pb.data)
+    assert int(tb.steps_taken) == int(ta.steps_taken)
+    for k in ma:
+        if k.startswith("losses/"):
+            assert torch.equal(torch.as_tensor(ma[k]), torch.as_tensor(mb[k])), k
