@@ -65,7 +65,6 @@ def _bias(layer):
 
 FUSED_MAX_LAYERS = 8
 FUSED_MAX_WIDTH = 512
-FUSED_WIDE_MAX_ROWS = 8192  # wider-than-256 trunks: whole-trunk kernel up to this M
 
 
 def _fusable(layers, M: int) -> bool:

@@ -71,7 +71,7 @@ class MLPActorCritic(Sequential):
             width = max(max(l.in_features, l.out_features) for l in layers)
             if len(layers) > dense_chain.FUSED_MAX_LAYERS:
                 return False
-            if width > 256 and M > dense_chain.FUSED_WIDE_MAX_ROWS:
+            if width > 256 and M > 8192:  # mi_policy_*_bf16: 64-row workgroups up to 256 wide
                 return False
             if width > dense_chain.FUSED_MAX_WIDTH:
                 return False
