@@ -342,6 +342,18 @@ int mi_lstm_seq_bwd_f32(const float* g_h, const float* gates, const float* c_pre
                         const float* w_h, const uint8_t* done, float* d_gates, float* dh0,
                         float* dc0, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
 
+/* The LSTM recurrence and BPTT with h W_h (d_gates W_h^T) on the bf16 matrix cores
+ * (operands rounded to bf16, fp32 accumulation, fp32 cell arithmetic and carries):
+ * same arguments as mi_lstm_seq_fwd_f32 / mi_lstm_seq_bwd_f32; H in {32, 64, 96, 128};
+ * h_prev_out, c_prev_out and gates_out are all null (inference) or all given. */
+int mi_lstm_seq_fwd_bf16(const float* gi, const float* w_h, const float* h0, const float* c0,
+                         const uint8_t* done, float* h_out, float* h_prev_out,
+                         float* c_prev_out, float* gates_out, float* h_final, float* c_final,
+                         int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+int mi_lstm_seq_bwd_bf16(const float* g_h, const float* gates, const float* c_prev,
+                         const float* w_h, const uint8_t* done, float* d_gates, float* dh0,
+                         float* dc0, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
 /* ---- a14: loss terms ---------------------------------------------------- */
 
 /* Advantage statistics for `ppo.py:477-480`: stats[3] = (sum, sum of squares,

@@ -186,7 +186,25 @@ class LSTM(StatefulModule):
             np.asarray(bias_init(gen, (4 * H,)), dtype=np.float32)
         self.b_h = Parameter(b)
 
+    def _mfma(self) -> bool:
+        """bf16 compute: the recurrent product runs on the matrix cores (lstm_mfma.hip)."""
+        from .. import config
+
+        return config.compute_dtype() == "bf16" and ops.gru_mfma_ok(self.hidden_features)
+
+    def _proj(self) -> _Projection:
+        p = self.__dict__.get("_proj_i")
+        if p is None or p.kernel is not self.w_i:
+            # the hidden-side bias is added with the input projection (a = x W_i + b_h + h W_h)
+            p = _Projection(self.w_i, self.b_h, self.in_features, 4 * self.hidden_features)
+            self.__dict__["_proj_i"] = p
+        return p
+
     def _gi(self, x2: torch.Tensor) -> torch.Tensor:
+        if self._mfma():
+            from . import dense_chain
+
+            return dense_chain.forward_infer([self._proj()], x2)
         return ops.dense_fwd(x2, self.w_i.data, self.b_h.data, ops.ACT_NONE)
 
     def __call__(self, state, x: torch.Tensor, rollout_extras: Any = None):
@@ -194,7 +212,8 @@ class LSTM(StatefulModule):
         B = x.shape[0]
         gi = self._gi(x.reshape(B, self.in_features)).view(1, B, 4 * self.hidden_features)
         h_out, _, _, _, h_f, c_f = ops.lstm_seq_fwd(gi, self.w_h.data, h.contiguous(),
-                                                    c.contiguous(), None, train=False)
+                                                    c.contiguous(), None, train=False,
+                                                    mfma=self._mfma())
         return StatefulModuleOutput(next_state=(h_f, c_f), output=h_out[0],
                                     regularization_loss=torch.zeros(B, device=x.device),
                                     metrics={}, rollout_extras=None)
@@ -212,20 +231,38 @@ class LSTM(StatefulModule):
         T, B, _ = x_seq.shape
         H = self.hidden_features
         x2 = x_seq.reshape(T * B, self.in_features)
-        gi = self._gi(x2).view(T, B, 4 * H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        mfma = self._mfma()
+        pctx = None
+        if mfma:
+            from . import dense_chain
+
+            pctx, gi2 = dense_chain.forward_train([self._proj()], x2, need_input_grad)
+            gi = gi2.view(T, B, 4 * H)
+        else:
+            gi = self._gi(x2).view(T, B, 4 * H)
         h0, c0 = state0
         h_out, h_prev, c_prev, gates, h_f, c_f = ops.lstm_seq_fwd(
             gi, self.w_h.data, h0.contiguous(), c0.contiguous(), done_seq.contiguous(),
-            train=True)
-        ctx = (x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad)
+            train=True, mfma=mfma)
+        ctx = (x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx)
         return ctx, h_out, None, (h_f, c_f)
 
     def replay_backward(self, ctx, g_out, g_reg):
-        x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad = ctx
+        x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx
         H = self.hidden_features
         da = ops.lstm_seq_bwd(g_out.contiguous(), gates, c_prev, self.w_h.data,
-                              done_seq.contiguous())
+                              done_seq.contiguous(), mfma=mfma)
         da2 = da.view(T * B, 4 * H)
+        if mfma:
+            from . import dense_chain
+
+            ops.dense_bwd_dw_grouped_bf16(
+                [(ops.cast_pad_bf16(h_prev.view(T * B, H)), ops.cast_pad_bf16(da2),
+                  self.w_h.grad, None)], accumulate=True)
+            g_x = dense_chain.backward([self._proj()], pctx, da2)  # dW_i, db_h, dx
+            return None if g_x is None else g_x.view(T, B, self.in_features)
         ops.dense_bwd_dw(h_prev.view(T * B, H), da2, None, self.w_h.grad, self.b_h.grad,
                          ops.ACT_NONE, accumulate=True)
         ops.dense_bwd_dw(x2, da2, None, self.w_i.grad, None, ops.ACT_NONE, accumulate=True)

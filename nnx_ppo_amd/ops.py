@@ -869,9 +869,9 @@ def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False):
 
 
 # ------------------------------------------------------------- f2: LSTM
-def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool):
+def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool, mfma: bool = False):
     """gi [T,B,4H] -> (h_out [T,B,H], h_prev | None, c_prev | None, gates [T,B,5H] | None,
-    h_final [B,H], c_final [B,H])."""
+    h_final [B,H], c_final [B,H]).  `mfma`: h W_h on the bf16 matrix cores."""
     T, B, H4 = gi.shape
     H = H4 // 4
     _need(w_h.shape == (H, H4) and h0.shape == (B, H) and c0.shape == (B, H),
@@ -886,19 +886,21 @@ def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool):
     d = None if done is None else _as_u8(done)
     if d is not None:
         _need(d.shape == (T, B), "lstm_seq_fwd: done must be [T, B]")
-    check(lib().mi_lstm_seq_fwd_f32(ptr(gi, f32), ptr(w_h, f32), ptr(h0, f32), ptr(c0, f32),
-                                    ptr(d), ptr(h_out, f32), ptr(h_prev, f32), ptr(c_prev, f32),
-                                    ptr(gates, f32), ptr(h_final, f32), ptr(c_final, f32), T, B,
-                                    H, stream()), "mi_lstm_seq_fwd_f32")
+    fn = lib().mi_lstm_seq_fwd_bf16 if mfma else lib().mi_lstm_seq_fwd_f32
+    check(fn(ptr(gi, f32), ptr(w_h, f32), ptr(h0, f32), ptr(c0, f32), ptr(d), ptr(h_out, f32),
+             ptr(h_prev, f32), ptr(c_prev, f32), ptr(gates, f32), ptr(h_final, f32),
+             ptr(c_final, f32), T, B, H, stream()),
+          "mi_lstm_seq_fwd_bf16" if mfma else "mi_lstm_seq_fwd_f32")
     return h_out, h_prev, c_prev, gates, h_final, c_final
 
 
-def lstm_seq_bwd(g_h, gates, c_prev, w_h, done):
+def lstm_seq_bwd(g_h, gates, c_prev, w_h, done, mfma: bool = False):
     """Returns d_gates [T,B,4H] (gradient w.r.t. the gate pre-activations)."""
     T, B, H = g_h.shape
     da = torch.empty(T, B, 4 * H, dtype=f32, device=g_h.device)
     d = None if done is None else _as_u8(done)
-    check(lib().mi_lstm_seq_bwd_f32(ptr(g_h, f32), ptr(gates, f32), ptr(c_prev, f32),
-                                    ptr(w_h, f32), ptr(d), ptr(da, f32), None, None, T, B, H,
-                                    stream()), "mi_lstm_seq_bwd_f32")
+    fn = lib().mi_lstm_seq_bwd_bf16 if mfma else lib().mi_lstm_seq_bwd_f32
+    check(fn(ptr(g_h, f32), ptr(gates, f32), ptr(c_prev, f32), ptr(w_h, f32), ptr(d),
+             ptr(da, f32), None, None, T, B, H, stream()),
+          "mi_lstm_seq_bwd_bf16" if mfma else "mi_lstm_seq_bwd_f32")
     return da

@@ -166,3 +166,66 @@ def test_lstm_graph_capture(dev):
         ts2, m = step()
     assert int(ts2.steps_taken) == 4 * N * T
     assert all(np.isfinite(float(v)) for k, v in m.items() if k.startswith("losses/"))
+
+
+@pytest.mark.parametrize("T,B,I,H", [(1, 1, 3, 32), (30, 64, 64, 64), (12, 37, 5, 64),
+                                     (5, 33, 8, 128), (6, 20, 7, 96), (3, 4099, 5, 64)])
+def test_lstm_matrix_core_path_vs_oracle(dev, T, B, I, H):
+    """bf16 compute: h W_h and d_gates W_h^T on the matrix cores (operands rounded to bf16,
+    fp32 accumulation, fp32 cell and carries) — against the fp64 oracle with the bf16
+    bound of the Dense layers."""
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.optim import Optimizer
+
+    prev = config.compute_dtype()
+    config.set_compute_dtype("bf16")
+    try:
+        m = _lstm(I, H, seed=T + B)
+        m.to(dev)
+        assert m._mfma()
+        opt = Optimizer(m, 1e-3, device=dev)
+        om = on.from_product(m)
+        rng = np.random.default_rng(B)
+        x = rng.normal(size=(T, B, I)).astype(np.float32)
+        h0 = rng.normal(size=(B, H)).astype(np.float32)
+        c0 = rng.normal(size=(B, H)).astype(np.float32)
+        done = rng.random((T, B)) < 0.2
+        gy = rng.normal(size=(T, B, H)).astype(np.float32)
+        t = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt).to(dev)
+        ctx, out, _, (h_f, c_f) = m.replay((t(h0), t(c0)), t(x), t(done, torch.bool), None, True)
+        x64 = torch.tensor(x, dtype=D, requires_grad=True)
+        h, c = torch.tensor(h0, dtype=D), torch.tensor(c0, dtype=D)
+        outs = []
+        for k in range(T):
+            o = om((h, c), x64[k])
+            outs.append(o.output)
+            d = torch.tensor(done[k])[:, None]
+            h = torch.where(d, torch.zeros_like(o.next_state[0]), o.next_state[0])
+            c = torch.where(d, torch.zeros_like(o.next_state[1]), o.next_state[1])
+        want = torch.stack(outs)
+        assert np.allclose(out.cpu().numpy(), want.detach().numpy(), atol=3e-2)
+        assert np.allclose(h_f.cpu().numpy(), h.detach().numpy(), atol=3e-2)
+        assert np.allclose(c_f.cpu().numpy(), c.detach().numpy(), atol=5e-2)
+        # single-step calls == sequence replay (same kernel, bit for bit)
+        st = (t(h0), t(c0))
+        for k in range(min(T, 3)):
+            r = m(st, t(x[k]))
+            assert torch.equal(r.output, out[k])
+            dk = t(done[k], torch.bool)[:, None]
+            st = tuple(torch.where(dk, torch.zeros_like(s), s) for s in r.next_state)
+        opt.begin()
+        gx = m.replay_backward(ctx, t(gy), 0.0)
+        grads = torch.autograd.grad((want * torch.tensor(gy, dtype=D)).sum(),
+                                    [x64, om.w_i, om.w_h, om.b_h])
+
+        def close(a, b):
+            a, b = a.cpu().numpy().ravel(), b.numpy().ravel()
+            cos = float(a @ b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+            rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+            return cos > 0.995 and rel < 0.08
+
+        assert close(gx, grads[0])
+        for p_, w in zip((m.w_i, m.w_h, m.b_h), grads[1:]):
+            assert close(p_.grad, w)
+    finally:
+        config.set_compute_dtype(prev)
