@@ -449,6 +449,13 @@ int mi_key_expand(const int64_t* keys, const int64_t* fold, void* out, int64_t n
                   int mode, int64_t minval, int64_t maxval, int child_major,
                   mi_stream_t stream);
 
+/* The minibatch permutations of `ppo.py:284-294` in one launch: out[e][:] =
+ * permutation(fold_in(key, e), n) for e < n_perm (argsort of the n hashes of the
+ * folded key; (hash, index) order = torch's stable argsort).  key: one int64;
+ * out: int64 [n_perm][n]; n <= 8192. */
+int mi_key_permutations(const int64_t* key, int64_t* out, int64_t n_perm, int64_t n,
+                        mi_stream_t stream);
+
 /* out[i] = mix(a[i] ^ mix(b[i] + GOLDEN)): fold a per-env integer into a key. */
 int mi_key_fold(const int64_t* a, const int64_t* b, int64_t* out, int64_t n,
                 mi_stream_t stream);

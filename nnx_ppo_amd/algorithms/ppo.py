@@ -168,11 +168,9 @@ def minibatch_indices(new_key: torch.Tensor, n_envs: int, n_epochs: int,
     whole), reshaped `[n_minibatches, n_envs // n_minibatches]`; int64
     `[n_epochs * n_minibatches, minibatch_size]`."""
     minibatch_size = n_envs // n_minibatches
-    rows = []
-    for e in range(n_epochs):
-        perm = rnd.permutation(rnd.fold_in(new_key, e), n_envs)
-        rows.append(perm[: n_minibatches * minibatch_size].reshape(n_minibatches, minibatch_size))
-    return torch.cat(rows, dim=0)
+    perms = rnd.permutations(new_key, n_epochs, n_envs)  # [n_epochs, n_envs]
+    used = n_minibatches * minibatch_size
+    return perms[:, :used].reshape(n_epochs * n_minibatches, minibatch_size)
 
 
 def _advance_noise(networks: StatefulModule) -> None:
@@ -212,16 +210,9 @@ def ppo_step(
     keys = rnd.split(training_state.rng_key)
     reset_key, new_key = keys[0], keys[1]
     total_iterations = n_epochs * n_minibatches
-    # the minibatch permutations depend on the key only: draw them on the second stream
-    # while the rollout (30 dependent steps of small launches) runs on this one
-    perm_fork = None
     if minibatch_inds is None:
-        if _can_fork(new_key):
-            perm_fork = _Fork(new_key)
-            with perm_fork:
-                all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
-        else:
-            all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
+        # every epoch's permutation in one launch (they depend on the key only)
+        all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
     else:
         all_indices = minibatch_inds
     assert all_indices.shape[0] == total_iterations
@@ -229,8 +220,6 @@ def ppo_step(
     next_net_state, next_env_state, rollout_data = rollout.unroll_env(
         env, training_state.env_states, networks, training_state.network_states,
         rollout_length, reset_key)
-    if perm_fork is not None:
-        perm_fork.join(all_indices)
 
     # only the Transition fields the loss reads are gathered (ppo.py:297 gathers
     # every leaf; `metrics`, `actions`, `value_estimates` are dead there)

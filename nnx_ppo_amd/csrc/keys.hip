@@ -92,6 +92,49 @@ episode_step_kernel(const int64_t* __restrict__ counter, const void* __restrict_
   }
 }
 
+// Minibatch permutations (ppo.py:284-294): block e sorts the n hashes of key
+// fold_in(key, e) and writes the argsort — `random.permutation(fold_in(key, e), n)`
+// for every epoch in ONE launch.  (key, index) pairs make the order total, so the
+// result equals torch's stable argsort bit for bit.  One workgroup per permutation,
+// bitonic network over the padded power of two in LDS (n <= 8192).
+constexpr int kSortThreads = 1024;
+
+__global__ void __launch_bounds__(kSortThreads)
+key_permutations_kernel(const int64_t* __restrict__ key, int64_t* __restrict__ out, int n, int P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sort_raw[];
+  int64_t* hk = reinterpret_cast<int64_t*>(sort_raw);        // [P] hashes
+  int* hi = reinterpret_cast<int*>(hk + P);                  // [P] indices
+  const uint64_t ke = mix((uint64_t)key[0] ^ mix((uint64_t)blockIdx.x + kGolden));  // fold_in
+  const uint64_t mk = mix(ke);
+  for (int i = threadIdx.x; i < P; i += kSortThreads) {
+    hk[i] = i < n ? (int64_t)mix(mk ^ ((uint64_t)(i + 1) * kM2)) : INT64_MAX;  // random.bits
+    hi[i] = i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P; i += kSortThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int64_t a = hk[i], b = hk[l];
+          const int ia = hi[i], ib = hi[l];
+          const bool a_gt_b = a > b || (a == b && ia > ib);
+          const bool up = (i & k) == 0;
+          if (a_gt_b == up) {
+            hk[i] = b;
+            hk[l] = a;
+            hi[i] = ib;
+            hi[l] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int64_t* o = out + (int64_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += kSortThreads) o[i] = hi[i];
+}
+
 int stream_grid(int64_t n) {
   int64_t g = mippo::ceil_div(n, kThreads);
   if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
@@ -136,4 +179,22 @@ extern "C" int mi_episode_step(const int64_t* counter, const void* inner_done, i
                      mippo::as_stream(stream), counter, inner_done, done_is_float, inner_truncated,
                      max_len, counter_out, truncated_out, done_out, done_flag_out, n);
   return mippo::check_launch("mi_episode_step");
+}
+
+extern "C" int mi_key_permutations(const int64_t* key, int64_t* out, int64_t n_perm, int64_t n,
+                                   mi_stream_t stream) {
+  MI_REQUIRE(n_perm >= 0 && n >= 0 && n <= 8192 && n_perm <= 65535,
+             "mi_key_permutations: 0 <= n <= 8192 (n=%lld)", (long long)n);
+  if (n_perm == 0 || n == 0) return 0;
+  MI_REQUIRE(key && out, "mi_key_permutations: null pointer");
+  int P = 2;
+  while (P < n) P <<= 1;
+  const size_t lds = (size_t)P * (sizeof(int64_t) + sizeof(int));
+  static const hipError_t attr =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&key_permutations_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+  MI_REQUIRE(attr == hipSuccess, "mi_key_permutations: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(key_permutations_kernel, dim3((unsigned)n_perm), dim3(kSortThreads), lds,
+                     mippo::as_stream(stream), key, out, (int)n, P);
+  return mippo::check_launch("mi_key_permutations");
 }

@@ -799,6 +799,16 @@ def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: i
     return out
 
 
+def key_permutations(key: torch.Tensor, n_perm: int, n: int) -> torch.Tensor:
+    """int64 [n_perm, n]: row e = random.permutation(random.fold_in(key, e), n)."""
+    _need(key.dtype == i64 and key.numel() == 1, "key_permutations: one int64 key")
+    _need(0 <= n <= 8192, "key_permutations: n <= 8192")
+    out = torch.empty(n_perm, n, dtype=i64, device=key.device)
+    check(lib().mi_key_permutations(ptr(key.reshape(1), i64), ptr(out, i64), int(n_perm), int(n),
+                                    stream()), "mi_key_permutations")
+    return out
+
+
 def key_fold(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _need(a.dtype == i64 and b.dtype == i64 and a.shape == b.shape, "key_fold: int64 same shape")
     a = a if a.is_contiguous() else a.contiguous()

@@ -154,6 +154,16 @@ def _numel(shape) -> int:
     return n
 
 
+def permutations(k: torch.Tensor, n_perm: int, n: int) -> torch.Tensor:
+    """`stack([permutation(fold_in(k, e), n) for e in range(n_perm)])` — on the GPU (and
+    n <= 8192) one launch for all of them."""
+    if k.dim() != 0:
+        raise ValueError("permutations expects a scalar key")
+    if k.is_cuda and n <= 8192:
+        return _ops().key_permutations(k, n_perm, n)
+    return torch.stack([permutation(fold_in(k, e), n) for e in range(n_perm)], dim=0)
+
+
 def permutation(k: torch.Tensor, n: int) -> torch.Tensor:
     """Random permutation of arange(n) (`jax.random.permutation(key, n)`):
     stable argsort of n distinct-with-overwhelming-probability 64-bit hashes."""

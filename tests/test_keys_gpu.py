@@ -146,3 +146,19 @@ def test_copy_multi_bit_exact(dev):
     ops.copy_multi(list(zip(dsts, srcs)))
     for d, s in zip(dsts, srcs):
         assert torch.equal(d, s)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 100, 1000, 4096, 5000, 8192])
+def test_key_permutations_match_the_host_scheme(dev, n):
+    """mi_key_permutations == stack(permutation(fold_in(key, e), n)) of the integer
+    torch ops (stable argsort of the hashes), bit for bit; rows are permutations."""
+    from nnx_ppo_amd import random as rnd
+
+    k = rnd.key(12345 + n)
+    want = rnd.permutations(k, 4, n)                       # CPU: fold_in + bits + argsort
+    assert want.shape == (4, n)
+    got = rnd.permutations(k.to(dev), 4, n)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+    for e in range(4):
+        assert torch.equal(want[e], rnd.permutation(rnd.fold_in(k, e), n))
+        assert torch.equal(torch.sort(got[e].cpu()).values, torch.arange(n))
