@@ -246,7 +246,10 @@ int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_
  * as mi_tanh_gauss_fwd_f32 (extras != null scores stored raw actions: replay).
  * mean_and_std [M, 2A] (nullable) receives the action trunk's fp32 output (the
  * sampler backward reads it); value [M, c_dims[Lc]].  The *_y_bf / *_pre_bf /
- * *_x_bf arrays (nullable) receive the training images of mi_mlp_fwd_bf16. */
+ * *_x_bf arrays (nullable) receive the training images of mi_mlp_fwd_bf16.
+ * value_tail_obs (nullable) [M_tail, K0]: extra rows for the VALUE trunk only — the
+ * bootstrap observation of `ppo.py:433-437` rides along with the replay; value and the
+ * c_* images then have M + M_tail rows (rows M.. belong to the tail). */
 int mi_policy_fwd_bf16(
     const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
     const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,
@@ -257,7 +260,7 @@ int mi_policy_fwd_bf16(
     int deterministic, float* mean_and_std, float* raw_out, float* action, float* loglik,
     float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
     void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
-    void* c_x_bf, mi_stream_t stream);
+    void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream);
 
 /* Backward of mi_policy_fwd_bf16's replay form in ONE launch: the sampler backward
  * (arguments as mi_tanh_gauss_bwd_f32) produces the action trunk's output gradient

@@ -338,21 +338,29 @@ def ppo_loss(
     last_obs = tree_map(lambda x: x[-1], rollout_data.next_obs)
     stateless = not any(isinstance(t, torch.Tensor) for t in tree_leaves(network_state))
     fork = None
-    if stateless and _can_fork(last_obs):
+    fused = None
+    if stateless and hasattr(networks, "replay_with_bootstrap"):
+        # the bootstrap rows ride along in the replay launch (networks/policy.py)
+        fused = networks.replay_with_bootstrap(network_state, rollout_data.obs, done,
+                                               rollout_data.rollout_extras, last_obs)
+    if fused is not None:
+        ctx, out, reg_seq, final_state, last_values = fused
+    elif stateless and _can_fork(last_obs):
         # no carry: the bootstrap forward does not depend on the replay's final
         # state, so it runs beside the replay on the second stream (it is a 1/T-size
         # launch that would otherwise sit alone on the critical path)
         fork = _Fork(last_obs)
         with fork:
             last_values = networks.forward_value(network_state, last_obs)
-    # replay scan (ppo.py:411-431), layer by layer over the whole sequence
-    ctx, out, reg_seq, final_state = networks.replay(
-        network_state, rollout_data.obs, done, rollout_data.rollout_extras,
-        need_input_grad=False)
-    if fork is not None:
-        fork.join(last_values)
-    else:
-        last_values = networks.forward_value(final_state, last_obs)
+    if fused is None:
+        # replay scan (ppo.py:411-431), layer by layer over the whole sequence
+        ctx, out, reg_seq, final_state = networks.replay(
+            network_state, rollout_data.obs, done, rollout_data.rollout_extras,
+            need_input_grad=False)
+        if fork is not None:
+            fork.join(last_values)
+        else:
+            last_values = networks.forward_value(final_state, last_obs)
 
     rewards = rollout_data.rewards
     values = out.value_estimates

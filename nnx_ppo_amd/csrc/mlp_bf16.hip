@@ -54,6 +54,8 @@ struct ChainLayer {
 struct Chain {
   ChainLayer layer[CH_MAXL];
   const float* x;       // [M][K0] fp32 input (backward: gradient of the chain output)
+  const float* x_tail;  // rows M_head .. M-1 come from here ([M - M_head][K0]), or null
+  int64_t M_head;       // = M without a tail
   const bf16_t* aux0;   // backward: act' operand of the input, or null
   int64_t ldaux0;
   int act0;
@@ -121,6 +123,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int64_t i0 = (int64_t)blockIdx.x * ROWS;
+  if (i0 >= c.M) return;  // a launch covers the longer of two trunks (policy step)
   const int K0 = c.layer[0].K;
   const int K0p = (K0 + 31) / 32 * 32;
 
@@ -192,7 +195,9 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   for (int row = tid >> 5; row < (from_sampler ? 0 : ROWS); row += kThreads >> 5)
   for (int k = tid & 31; k < K0p; k += 32) {
     const int64_t gi = i0 + row;
-    float v = (gi < c.M && k < K0) ? c.x[gi * K0 + k] : 0.0f;
+    float v = 0.0f;
+    if (gi < c.M && k < K0)
+      v = gi < c.M_head ? c.x[gi * K0 + k] : c.x_tail[(gi - c.M_head) * K0 + k];
     if constexpr (POLICY && !BWD) {
       // normalizer.py:76-81,92-96 — the same fp32 expression as normalize_fwd_kernel
       if (px->norm_mean && gi < c.M && k < K0) {
@@ -461,6 +466,8 @@ int fill_fwd_chain(Chain& c, const char* who, const float* x, int64_t M, int64_t
   MI_REQUIRE(x && wt_bf && dims && acts, "%s: null pointer", who);
   c = {};
   c.x = x;
+  c.x_tail = nullptr;
+  c.M_head = M;
   c.out = out;
   c.M = M;
   c.L = (int)L;
@@ -504,7 +511,8 @@ int launch_policy(PolicyArgs& a, int maxw, hipStream_t st) {
   MI_REQUIRE(attr == hipSuccess, "policy_kernel: cannot raise the dynamic LDS limit: %s",
              hipGetErrorString(attr));
   MI_REQUIRE(lds <= (size_t)kCap, "policy_kernel: %zu bytes of LDS needed, %d available", lds, kCap);
-  hipLaunchKernelGGL((policy_kernel<RT>), dim3((unsigned)mippo::ceil_div(a.c[0].M, ROWS), 2),
+  const int64_t m_max = a.c[0].M > a.c[1].M ? a.c[0].M : a.c[1].M;
+  hipLaunchKernelGGL((policy_kernel<RT>), dim3((unsigned)mippo::ceil_div(m_max, ROWS), 2),
                      dim3(kThreads), lds, st, a);
   return mippo::check_launch("mi_policy_fwd_bf16");
 }
@@ -536,8 +544,9 @@ extern "C" int mi_policy_fwd_bf16(
     int deterministic, float* mean_and_std, float* raw_out, float* action, float* loglik,
     float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
     void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
-    void* c_x_bf, mi_stream_t stream) {
-  MI_REQUIRE(M >= 0, "mi_policy_fwd_bf16: bad M");
+    void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && M_tail >= 0 && (M_tail == 0 || value_tail_obs),
+             "mi_policy_fwd_bf16: bad M / tail");
   if (M == 0) return 0;
   MI_REQUIRE(obs && value && a_dims && c_dims, "mi_policy_fwd_bf16: null pointer");
   MI_REQUIRE(a_dims[0] == c_dims[0], "mi_policy_fwd_bf16: both trunks read the same input");
@@ -549,9 +558,11 @@ extern "C" int mi_policy_fwd_bf16(
   int rc = fill_fwd_chain(a.c[0], "mi_policy_fwd_bf16(action)", obs, M, La, a_w, a_bias, a_dims,
                           a_acts, mean_and_std, a_y_bf, a_pre_bf, a_x_bf, &wa);
   if (rc) return rc;
-  rc = fill_fwd_chain(a.c[1], "mi_policy_fwd_bf16(value)", obs, M, Lc, c_w, c_bias, c_dims, c_acts,
-                      value, c_y_bf, c_pre_bf, c_x_bf, &wc);
+  rc = fill_fwd_chain(a.c[1], "mi_policy_fwd_bf16(value)", obs, M + M_tail, Lc, c_w, c_bias,
+                      c_dims, c_acts, value, c_y_bf, c_pre_bf, c_x_bf, &wc);
   if (rc) return rc;
+  a.c[1].x_tail = value_tail_obs;
+  a.c[1].M_head = M;
   const int64_t A2 = a_dims[La];
   MI_REQUIRE(A2 >= 2 && A2 % 2 == 0 && A2 <= 128,
              "mi_policy_fwd_bf16: the action trunk must end in 2A <= 128 columns");
@@ -566,7 +577,7 @@ extern "C" int mi_policy_fwd_bf16(
                loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
   const int maxw = wa > wc ? wa : wc;
   hipStream_t st = mippo::as_stream(stream);
-  if (M <= 8192) return launch_policy<1>(a, maxw, st);
+  if (M + M_tail <= 8192) return launch_policy<1>(a, maxw, st);
   MI_REQUIRE(maxw <= 256, "mi_policy_fwd_bf16: trunks wider than 256 take at most 8192 rows "
                           "(use mi_mlp_fwd_bf16 per trunk)");
   return launch_policy<4>(a, maxw, st);
@@ -588,6 +599,8 @@ int fill_bwd_chain(Chain& c, const char* who, const float* g_out, const void* au
   const int steps = (int)(g_in ? L : L - 1);
   c = {};
   c.x = g_out;
+  c.x_tail = nullptr;
+  c.M_head = M;
   c.M = M;
   c.L = steps;
   c.aux0 = act_last == MI_ACT_NONE ? nullptr : static_cast<const bf16_t*>(aux_last);

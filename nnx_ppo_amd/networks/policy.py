@@ -77,7 +77,7 @@ class MLPActorCritic(Sequential):
                 return False
         return True
 
-    def _launch(self, x2: torch.Tensor, extras2, train: bool):
+    def _launch(self, x2: torch.Tensor, extras2, train: bool, value_tail=None):
         a_layers, sampler, c_layers = self._parts()
         dense_chain.refresh(list(a_layers) + list(c_layers))  # one launch for both trunks
         chain = lambda ls: ([l._ff for l in ls], [dense_chain._bias(l) for l in ls],
@@ -94,7 +94,7 @@ class MLPActorCritic(Sequential):
         r = ops.policy_fwd_bf16(
             x2, norm, chain(a_layers), chain(c_layers), sampler._state(x2.device), off,
             deterministic=sampler.deterministic, extras=extras2, eps=eps, eps2=eps2,
-            train=train, want_stats=not train, **sampler._kw())
+            train=train, want_stats=not train, value_tail=value_tail, **sampler._kw())
         return r, off, eps2
 
     # ---- rollout / inference (adapter.py:75-117 over the whole stack) -----------------
@@ -127,11 +127,24 @@ class MLPActorCritic(Sequential):
             rollout_extras=([obs] if pre else []) + [adapter_out["rollout_extras"]])
 
     # ---- loss replay (ppo.py:411-431) ------------------------------------------------
-    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+    def replay_with_bootstrap(self, state0, x_seq, done_seq, extras_seq, last_obs):
+        """`replay` plus the value estimate of `last_obs` [B, K0] (the bootstrap of
+        ppo.py:433-437): the extra rows ride along in the value trunk of the same launch.
+        Returns (ctx, out, reg, final_state, last_values) or None when the fused path
+        does not apply."""
+        if not (isinstance(last_obs, torch.Tensor) and last_obs.dim() == 2):
+            return None
+        return self.replay(state0, x_seq, done_seq, extras_seq, need_input_grad=False,
+                           _bootstrap=last_obs)
+
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True,
+               _bootstrap=None):
         fus = (not need_input_grad and extras_seq is not None
                and isinstance(x_seq, torch.Tensor) and x_seq.dim() == 3
                and self._fusable(x_seq, x_seq.shape[0] * x_seq.shape[1]))
         if not fus:
+            if _bootstrap is not None:
+                return None
             ctx, out, reg, fs = super().replay(state0, x_seq, done_seq, extras_seq,
                                                need_input_grad)
             return ("generic", ctx), out, reg, fs
@@ -146,7 +159,10 @@ class MLPActorCritic(Sequential):
         x2 = x_seq.reshape(M, K0)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        r, off, eps2 = self._launch(x2, ex2, train=True)
+        tail = None
+        if _bootstrap is not None:
+            tail = _bootstrap if _bootstrap.is_contiguous() else _bootstrap.contiguous()
+        r, off, eps2 = self._launch(x2, ex2, train=True, value_tail=tail)
         value = r["value"].view(T, B, -1)
         squeezed = value.shape[-1] == 1
         if squeezed:
@@ -161,6 +177,10 @@ class MLPActorCritic(Sequential):
         pre = self._norm is not None
         final_state = ([()] if pre else []) + [{"action": list(state0[-1]["action"]),
                                                 "value": list(state0[-1]["value"])}]
+        if _bootstrap is not None:
+            lv = r["value_tail_out"]
+            return ctx, out, r["reg"].view(T, B), final_state, (lv.squeeze(-1) if squeezed
+                                                               else lv)
         return ctx, out, r["reg"].view(T, B), final_state
 
     def replay_backward(self, ctx, g_out, g_reg):

@@ -424,12 +424,14 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
 def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_add: int, *,
                     min_std: float, std_scale: float, entropy_weight: float,
                     deterministic: bool, extras=None, eps=None, eps2=None, train: bool = False,
-                    want_stats: bool = True):
+                    want_stats: bool = True, value_tail=None):
     """Normaliser -> action trunk -> sampler and value trunk in ONE launch
     (`mi_policy_fwd_bf16`).  `norm` = (mean, m2, counter, eps) | None; `actor` / `critic`
     = (frag images, biases, dims, acts).  Returns a dict: raw, action, log_likelihood,
     reg, mu, sigma, value and — training — mean_and_std, actor_saved, critic_saved
-    (per-layer (x_bf, aux_bf) as `mlp_fwd_bf16`)."""
+    (per-layer (x_bf, aux_bf) as `mlp_fwd_bf16`).  `value_tail` [Mt, K0]: extra rows for
+    the value trunk only (the bootstrap observation); `value` and the critic images then
+    have M + Mt rows and `value_tail_out` is the view of the last Mt."""
     M, K0 = obs.shape
     dev = obs.device
     (a_w, a_b, a_dims, a_acts), (c_w, c_b, c_dims, c_acts) = actor, critic
@@ -446,22 +448,26 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
     ll, reg = mk(M), mk(M)
     mu = mk(M, A) if want_stats else None
     sigma = mk(M, A) if want_stats else None
-    value = mk(M, c_dims[-1])
+    Mt = 0 if value_tail is None else value_tail.shape[0]
+    if value_tail is not None:
+        _need(value_tail.shape == (Mt, K0) and value_tail.is_contiguous(),
+              "policy_fwd_bf16: value_tail must be a contiguous [Mt, K0]")
+    value = mk(M + Mt, c_dims[-1])
     ms = mk(M, A2) if train else None
 
-    def images(L, dims, acts):
+    def images(L, dims, acts, rows):
         if not train:
             return None, None, None
         y, pre = [None] * L, [None] * L
         for l in range(L):
             if l < L - 1 or acts[l] != ACT_NONE:
-                y[l] = _bf_buf(M, dims[l + 1], dev)
+                y[l] = _bf_buf(rows, dims[l + 1], dev)
             if acts[l] == ACT_SWISH:
-                pre[l] = _bf_buf(M, dims[l + 1], dev)
-        return y, pre, _bf_buf(M, K0, dev)
+                pre[l] = _bf_buf(rows, dims[l + 1], dev)
+        return y, pre, _bf_buf(rows, K0, dev)
 
-    a_y, a_pre, a_x = images(La, a_dims, a_acts)
-    c_y, c_pre, c_x = images(Lc, c_dims, c_acts)
+    a_y, a_pre, a_x = images(La, a_dims, a_acts, M)
+    c_y, c_pre, c_x = images(Lc, c_dims, c_acts, M + Mt)
     arr = lambda ts, L: None if ts is None else (ctypes.c_void_p * L)(*[ptr(t) for t in ts])
     i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
     n_mean, n_m2, n_cnt, n_eps = norm if norm is not None else (None, None, None, 0.0)
@@ -485,15 +491,19 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
         ptr(ms, f32), ptr(raw, f32), ptr(action, f32), ptr(ll, f32), ptr(reg, f32),
         ptr(mu, f32), ptr(sigma, f32), ptr(value, f32),
         arr(a_y, La), arr(a_pre, La), ptr(a_x), arr(c_y, Lc), arr(c_pre, Lc), ptr(c_x),
-        stream()), "mi_policy_fwd_bf16")
+        ptr(value_tail, f32), Mt, stream()), "mi_policy_fwd_bf16")
     out = dict(raw=extras if replay else raw, action=action, log_likelihood=ll, reg=reg, mu=mu,
-               sigma=sigma, value=value, mean_and_std=ms)
+               sigma=sigma, value=value[:M], value_tail_out=value[M:] if Mt else None,
+               mean_and_std=ms)
     if train:
         def saved(L, acts, x_bf, y, pre):
             return [((x_bf if l == 0 else y[l - 1]), (pre[l] if acts[l] == ACT_SWISH else y[l]))
                     for l in range(L)]
         out["actor_saved"] = saved(La, a_acts, a_x, a_y, a_pre)
-        out["critic_saved"] = saved(Lc, c_acts, c_x, c_y, c_pre)
+        # the backward and the dW run over the first M rows of the critic images
+        head = lambda t: None if t is None else t[:M]
+        out["critic_saved"] = [(head(xb), head(aux))
+                               for xb, aux in saved(Lc, c_acts, c_x, c_y, c_pre)]
     return out
 
 

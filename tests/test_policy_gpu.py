@@ -119,3 +119,42 @@ def test_replay_and_gradients_bit_identical_to_generic(dev, bf16, T, B, activati
     assert float(ga.abs().sum()) > 0
     scale = float(gb.abs().max())
     assert float((ga - gb).abs().max()) <= 2e-5 * scale
+
+
+def test_bootstrap_rows_ride_along_bit_identically(dev, bf16):
+    """`replay_with_bootstrap`: the value of the bootstrap observation from the value
+    trunk's tail rows == `forward_value`, and everything else == `replay`, bit for bit."""
+    from nnx_ppo_amd.networks.types import PPONetworkOutput, bump_param_epoch
+    from nnx_ppo_amd.optim import Optimizer
+    from nnx_ppo_amd.tree import tree_map
+
+    T, B = 30, 1024
+    net = _net(dev, 5, 1, [64] * 4, [256] * 2, "relu")
+    opt = Optimizer(net, 1e-3, None, None, device=dev)
+    g = torch.Generator().manual_seed(1)
+    x_seq = torch.randn(T, B, 5, generator=g).to(dev)
+    last_obs = torch.randn(B, 5, generator=g).to(dev)
+    done = torch.zeros(T, B, dtype=torch.bool, device=dev)
+    state = net.initialize_state(B)
+    smp = _sampler(net)
+    steps = [net(state, x_seq[t]).rollout_extras for t in range(T)]
+    extras = tree_map(lambda *xs: torch.stack(xs, 0), steps[0], *steps[1:])
+    g_ll = torch.randn(T, B, generator=g).to(dev)
+    g_v = torch.randn(T, B, generator=g).to(dev)
+    res = []
+    for with_boot in (True, False):
+        bump_param_epoch()
+        opt.begin()
+        smp._pending = 3
+        if with_boot:
+            ctx, out, reg, fs, lv = net.replay_with_bootstrap(state, x_seq, done, extras, last_obs)
+        else:
+            ctx, out, reg, fs = net.replay(state, x_seq, done, extras, need_input_grad=False)
+            lv = net.forward_value(state, last_obs)
+        assert ctx[0] == "fused" and lv.shape == (B,)
+        net.replay_backward(ctx, PPONetworkOutput(None, g_ll, g_v), 1.0 / (T * B))
+        torch.cuda.synchronize()
+        res.append((out.loglikelihoods.clone(), out.value_estimates.clone(), reg.clone(),
+                    lv.clone(), opt.grads.clone()))
+    for a, b in zip(*res):
+        assert a.shape == b.shape and torch.equal(a, b)
