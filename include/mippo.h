@@ -399,11 +399,17 @@ int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out, void* wor
  * begin_next_ticket == null: step holds t, already advanced by mi_begin_grad_step_f32.
  * begin_next_ticket != null (16 bytes, ZERO before the first call, left zero): step
  * holds the number of COMPLETED steps; the launch uses t = step + 1, stores it, and
- * zeroes grads after reading them — it is the next step's mi_begin_grad_step_f32. */
+ * zeroes grads after reading them — it is the next step's mi_begin_grad_step_f32.
+ * n_shadows (<= 16) Dense kernels W [K, N] stored at params + shadow_begin[l] also
+ * receive their new values in their bf16 images (layouts of mi_weights_to_bf16_multi;
+ * the images' zero padding is left untouched), so that launch is not needed after an
+ * update. */
 int mi_adam_step_f32(float* params, float* grads, float* m, float* v, int64_t n, float lr,
                      float b1, float b2, float eps, float weight_decay, int64_t* step,
                      const float* grad_norm, float max_norm, void* begin_next_ticket,
-                     mi_stream_t stream);
+                     int64_t n_shadows, const int64_t* shadow_begin, const int64_t* shadow_K,
+                     const int64_t* shadow_N, void* const* w_bf, void* const* wt_bf,
+                     void* const* frag_fwd, void* const* frag_bwd, mi_stream_t stream);
 
 /* ---- a5 / a7: data movement ---------------------------------------------- */
 

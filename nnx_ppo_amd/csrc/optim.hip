@@ -13,7 +13,7 @@
 // arenas, so one launch updates the whole network (28 B/param of HBM traffic).
 // The step counter and the gradient norm are device-resident so the whole
 // update is HIP-graph capturable.
-#include "common.h"
+#include "bf16_common.h"
 
 namespace {
 
@@ -55,11 +55,36 @@ __global__ void norm_finalize_kernel(const double* partials, int G, float* norm_
   *norm_out = (float)sqrt(t);
 }
 
+// bf16 shadows of Dense kernels that live in the arena (networks/dense_chain.py): the
+// update writes the new value into the four bf16 images too, so no separate
+// mi_weights_to_bf16_multi launch sits at the head of the next forward pass.
+struct ShadowLeaf {
+  int64_t begin;  // flat index of W[0][0] in the arena
+  int K, N, ldw, ldwt;
+  mippo_bf16::bf16_t* wb;  // [K][ldw]
+  mippo_bf16::bf16_t* wt;  // [N][ldwt]
+  mippo_bf16::bf16_t* ff;  // forward fragment-major image (gemm_bf16.hip: frag_store)
+  mippo_bf16::bf16_t* fb;  // backward fragment-major image
+};
+constexpr int kMaxShadows = 16;
+struct ShadowTable {
+  ShadowLeaf leaf[kMaxShadows];
+  int n;
+};
+
+// index of (column c, reduce element r) in a fragment-major image with R reduce elements
+__device__ inline int64_t frag_index(int c, int r, int R) {
+  const int KS = (R + 31) / 32;
+  const int lane = (c & 15) + 16 * ((r & 31) >> 3);
+  return (((int64_t)(c >> 4) * KS + (r >> 5)) * 64 + lane) * 8 + (r & 7);
+}
+
 __global__ void __launch_bounds__(kThreads)
 adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
             float weight_decay, int64_t* __restrict__ step,
-            const float* __restrict__ grad_norm, float max_norm, unsigned int* ticket) {
+            const float* __restrict__ grad_norm, float max_norm, unsigned int* ticket,
+            ShadowTable shadows) {
   // ticket != null: this launch also opens the NEXT gradient step — it counts itself
   // (t = step + 1, stored by the last block to finish, after every block has read
   // `step`) and leaves the gradient arena zeroed, so no separate
@@ -87,8 +112,22 @@ adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
     float u = (mi / bc1) / (sqrtf(vi / bc2) + eps);
     const float pi = p[i];
     if (weight_decay != 0.0f) u += weight_decay * pi;
-    p[i] = pi - lr * u;
+    const float pn = pi - lr * u;
+    p[i] = pn;
     if (ticket) g[i] = 0.0f;
+    for (int l = 0; l < shadows.n; ++l) {
+      const ShadowLeaf& lf = shadows.leaf[l];
+      const int64_t q = i - lf.begin;
+      if (q >= 0 && q < (int64_t)lf.K * lf.N) {
+        const int k = (int)(q / lf.N), c = (int)(q % lf.N);
+        const mippo_bf16::bf16_t b = (mippo_bf16::bf16_t)pn;
+        lf.wb[(int64_t)k * lf.ldw + c] = b;
+        lf.wt[(int64_t)c * lf.ldwt + k] = b;
+        if (lf.ff) lf.ff[frag_index(c, k, lf.K)] = b;  // columns = outputs, reduce = K
+        if (lf.fb) lf.fb[frag_index(k, c, lf.N)] = b;  // columns = inputs,  reduce = N
+        break;
+      }
+    }
   }
   if (ticket) {
     if (mippo::last_block_ticket(ticket) && threadIdx.x == 0) {
@@ -138,8 +177,32 @@ extern "C" int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out
 extern "C" int mi_adam_step_f32(float* params, float* grads, float* m, float* v, int64_t n,
                                 float lr, float b1, float b2, float eps, float weight_decay,
                                 int64_t* step, const float* grad_norm, float max_norm,
-                                void* begin_next_ticket, mi_stream_t stream) {
+                                void* begin_next_ticket, int64_t n_shadows,
+                                const int64_t* shadow_begin, const int64_t* shadow_K,
+                                const int64_t* shadow_N, void* const* w_bf, void* const* wt_bf,
+                                void* const* frag_fwd, void* const* frag_bwd,
+                                mi_stream_t stream) {
   MI_REQUIRE(n >= 1 && params && grads && m && v && step, "mi_adam_step_f32: bad arguments");
+  MI_REQUIRE(n_shadows >= 0 && n_shadows <= kMaxShadows, "mi_adam_step_f32: 0 <= n_shadows <= %d",
+             kMaxShadows);
+  ShadowTable tab = {};
+  tab.n = (int)n_shadows;
+  for (int64_t l = 0; l < n_shadows; ++l) {
+    MI_REQUIRE(shadow_begin && shadow_K && shadow_N && w_bf && wt_bf && w_bf[l] && wt_bf[l] &&
+                   shadow_K[l] >= 1 && shadow_N[l] >= 1 && shadow_begin[l] >= 0 &&
+                   shadow_begin[l] + shadow_K[l] * shadow_N[l] <= n,
+               "mi_adam_step_f32: bad shadow %lld", (long long)l);
+    ShadowLeaf& lf = tab.leaf[l];
+    lf.begin = shadow_begin[l];
+    lf.K = (int)shadow_K[l];
+    lf.N = (int)shadow_N[l];
+    lf.ldw = (int)(mippo::ceil_div(shadow_N[l], 8) * 8);
+    lf.ldwt = (int)(mippo::ceil_div(shadow_K[l], 8) * 8);
+    lf.wb = static_cast<mippo_bf16::bf16_t*>(w_bf[l]);
+    lf.wt = static_cast<mippo_bf16::bf16_t*>(wt_bf[l]);
+    lf.ff = frag_fwd ? static_cast<mippo_bf16::bf16_t*>(frag_fwd[l]) : nullptr;
+    lf.fb = frag_bwd ? static_cast<mippo_bf16::bf16_t*>(frag_bwd[l]) : nullptr;
+  }
   // every block takes a ticket when this launch also opens the next step: keep the
   // grid at one block per CU so the tickets do not serialise on the counter's L2 line
   int grid = stream_grid(n);
@@ -147,6 +210,6 @@ extern "C" int mi_adam_step_f32(float* params, float* grads, float* m, float* v,
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0,
                      mippo::as_stream(stream), params, grads, m, v, n, lr, b1, b2, eps,
                      weight_decay, step, grad_norm, max_norm,
-                     static_cast<unsigned int*>(begin_next_ticket));
+                     static_cast<unsigned int*>(begin_next_ticket), tab);
   return mippo::check_launch("mi_adam_step_f32");
 }

@@ -18,6 +18,8 @@ products are bf16 x bf16 with fp32 accumulation, master weights stay fp32.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import ops
@@ -30,6 +32,32 @@ def _stale(layer) -> bool:
             or getattr(layer, "_w_bf", None) is None or layer._w_bf.device != w.device)
 
 
+# layers that own bf16 shadows (weak: a dropped network drops its entries)
+_SHADOWED: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def shadows_in(arena: torch.Tensor) -> list:
+    """(layer, flat offset) of every shadowed layer whose fp32 kernel is a view of
+    `arena` — the optimiser updates those images in its own launch (`mi_adam_step_f32`)."""
+    lo = arena.data_ptr()
+    hi = lo + arena.numel() * arena.element_size()
+    out = []
+    for l in list(_SHADOWED):
+        w = l.kernel.data
+        if getattr(l, "_w_bf", None) is None or l._w_bf.device != w.device:
+            continue
+        p = w.data_ptr()
+        if lo <= p < hi and w.is_contiguous():
+            out.append((l, (p - lo) // arena.element_size()))
+    out.sort(key=lambda t: t[1])
+    return out
+
+
+def mark_fresh(layers) -> None:
+    for l in layers:
+        l._shadow_epoch = param_epoch()
+
+
 def refresh(layers) -> None:
     """Refresh the bf16 shadows of every stale layer of a chain in one launch."""
     stale = [l for l in layers if _stale(l)]
@@ -38,6 +66,7 @@ def refresh(layers) -> None:
     for l in stale:
         w = l.kernel.data
         K, N = w.shape
+        _SHADOWED.add(l)
         if getattr(l, "_w_bf", None) is None or l._w_bf.device != w.device:
             l._w_bf = torch.zeros(K, ops.pad8(N), dtype=torch.bfloat16, device=w.device)
             l._wt_bf = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=w.device)

@@ -627,17 +627,31 @@ def global_norm(grads: torch.Tensor, out: torch.Tensor | None = None) -> torch.T
 
 def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: float = 0.999,
               eps: float = 1e-8, weight_decay: float = 0.0, grad_norm=None,
-              max_norm: float = 0.0, begin_next: bool = False) -> None:
+              max_norm: float = 0.0, begin_next: bool = False, shadows=None) -> None:
     """`begin_next`: `step` counts completed steps; this launch advances it and leaves
-    `grads` zeroed (it doubles as the next step's `begin_grad_step`)."""
+    `grads` zeroed (it doubles as the next step's `begin_grad_step`).  `shadows`: up to
+    16 tuples (begin, K, N, w_bf, wt_bf, frag_fwd, frag_bwd) of Dense kernels stored in
+    `params` whose bf16 images are written by the same launch."""
     n = params.numel()
     for t in (grads, m, v):
         _need(t.numel() == n, "adam_step: arena sizes differ")
     ticket = workspace(params.device, "adam_ticket", 16, zeroed=True) if begin_next else None
+    sh = list(shadows or [])[:16]
+    ns = len(sh)
+    I = ctypes.c_int64 * max(ns, 1)
+    P = ctypes.c_void_p * max(ns, 1)
+    col = lambda j: [t[j] for t in sh]
     check(lib().mi_adam_step_f32(ptr(params, f32), ptr(grads, f32), ptr(m, f32), ptr(v, f32), n,
                                  float(lr), float(b1), float(b2), float(eps),
                                  float(weight_decay), ptr(step, i64), ptr(grad_norm, f32),
-                                 float(max_norm), ptr(ticket), stream()), "mi_adam_step_f32")
+                                 float(max_norm), ptr(ticket), ns,
+                                 I(*col(0)) if ns else None, I(*col(1)) if ns else None,
+                                 I(*col(2)) if ns else None,
+                                 P(*[ptr(t, bf16) for t in col(3)]) if ns else None,
+                                 P(*[ptr(t, bf16) for t in col(4)]) if ns else None,
+                                 P(*[ptr(t, bf16) for t in col(5)]) if ns else None,
+                                 P(*[ptr(t, bf16) for t in col(6)]) if ns else None,
+                                 stream()), "mi_adam_step_f32")
 
 
 # ------------------------------------------------------ a5 / a7: movement

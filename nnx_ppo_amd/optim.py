@@ -85,12 +85,21 @@ class Optimizer:
         gn = None
         if self.gradient_clipping is not None:
             gn = self.grad_norm if have_norm else self.compute_grad_norm()
+        # Dense kernels with bf16 shadows get the new values written into the shadows by
+        # the same launch (up to 16 layers; the rest refresh lazily at their next use)
+        from .networks import dense_chain
+
+        shadowed = dense_chain.shadows_in(self.params)[:16]
+        table = [(off, l.kernel.shape[0], l.kernel.shape[1], l._w_bf, l._wt_bf, l._ff, l._fb)
+                 for l, off in shadowed]
         ops.adam_step(self.params, self.grads, self.m, self.v, self.step,
                       lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
                       weight_decay=self.weight_decay, grad_norm=gn,
-                      max_norm=float(self.gradient_clipping or 0.0), begin_next=True)
+                      max_norm=float(self.gradient_clipping or 0.0), begin_next=True,
+                      shadows=table)
         self._clean = True
         bump_param_epoch()
+        dense_chain.mark_fresh([l for l, _ in shadowed])
 
     # ---- state export (checkpoint callbacks) ----------------------------------------
     def state_dict(self) -> dict:

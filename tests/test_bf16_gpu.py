@@ -339,3 +339,37 @@ def test_fused_mlp_backward_matches_per_layer_path(dev, dims, M, act, need_gin):
         assert torch.allclose(g_in, want, rtol=2e-2, atol=2e-2)
     else:
         assert g_in is None
+
+
+def test_adam_keeps_the_bf16_shadows_fresh(dev):
+    """mi_adam_step_f32 with shadows: after an update every bf16 image of a shadowed Dense
+    kernel equals what mi_weights_to_bf16_multi derives from the new fp32 weights (bit
+    for bit, padding included), so the forward pass needs no refresh launch."""
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.networks import dense_chain, factories
+    from nnx_ppo_amd.networks.types import Rngs, param_epoch
+    from nnx_ppo_amd.optim import Optimizer
+
+    prev = config.compute_dtype()
+    config.set_compute_dtype("bf16")
+    try:
+        net = factories.make_mlp([5, 64, 33, 7], Rngs(4), activation_last_layer=False)
+        net.to(dev)
+        opt = Optimizer(net, 1e-2, device=dev)
+        layers = net.layers
+        dense_chain.refresh(layers)                      # allocates and fills the shadows
+        for step in range(3):
+            opt.begin()
+            opt.grads.normal_()
+            opt.update()
+            assert all(l._shadow_epoch == param_epoch() for l in layers)   # marked fresh
+            got = [(l._w_bf.clone(), l._wt_bf.clone(), l._ff.clone(), l._fb.clone())
+                   for l in layers]
+            for l in layers:                             # recompute from the fp32 masters
+                l._shadow_epoch = -1
+            dense_chain.refresh(layers)
+            for l, g in zip(layers, got):
+                for a, b in zip(g, (l._w_bf, l._wt_bf, l._ff, l._fb)):
+                    assert torch.equal(a, b)
+    finally:
+        config.set_compute_dtype(prev)
