@@ -241,10 +241,16 @@ __device__ inline unsigned xcd_swizzle(unsigned hw, unsigned total) {
 }
 
 template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(kThreads)
-tn_gemm_dw_kernel(DwTable tab) {
+constexpr int dw_lds_bytes() {
+  return 2 * BK * ((WM * TM * 16 + 16) + (WN * TN * 16 + 16)) * (int)sizeof(bf16_t);
+}
+
+// One tile class of a dW launch: workgroup `hw` of `total` of this class.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigned total,
+                                        unsigned char* lds) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  const unsigned logical = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned logical = xcd_swizzle(hw, total);
   const int bx = (int)(logical % (unsigned)tab.gx);
   const int by = (int)((logical / (unsigned)tab.gx) % (unsigned)tab.gy);
   const int bz = (int)(logical / (unsigned)(tab.gx * tab.gy));
@@ -269,8 +275,8 @@ tn_gemm_dw_kernel(DwTable tab) {
   constexpr int B_CH = BK * (BN / 8);
   constexpr int A_PT = (A_CH + kThreads - 1) / kThreads;
   constexpr int B_PT = (B_CH + kThreads - 1) / kThreads;
-  __shared__ __attribute__((aligned(16))) bf16_t As[2][BK][AROW];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BK][BROW];
+  auto As = reinterpret_cast<bf16_t(*)[BK][AROW]>(lds);
+  auto Bs = reinterpret_cast<bf16_t(*)[BK][BROW]>(lds + 2 * BK * AROW * sizeof(bf16_t));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -398,6 +404,27 @@ tn_gemm_dw_kernel(DwTable tab) {
     }
   }
   if (do_bias && tid < BN && j0 + tid < J) slab[I * J + j0 + tid] = bias_sum;
+}
+
+// ALL tile classes of a grouped dW in one launch: the workgroups of the 128x128 class
+// come first, then 128x64, then 128x16 (longest first); narrow classes run beside the
+// wide one instead of after it, and three launches (graph nodes) become one.
+struct DwAll {
+  DwTable cls[3];
+  unsigned begin[4];  // workgroup ranges of the classes
+};
+
+__global__ void __launch_bounds__(kThreads)
+tn_gemm_dw_all_kernel(DwAll all) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw_lds[];
+  const unsigned hw = blockIdx.x;
+  if (hw < all.begin[1]) {
+    dw_body<2, 2, 4, 4>(all.cls[0], hw - all.begin[0], all.begin[1] - all.begin[0], dw_lds);
+  } else if (hw < all.begin[2]) {
+    dw_body<4, 1, 2, 4>(all.cls[1], hw - all.begin[1], all.begin[2] - all.begin[1], dw_lds);
+  } else {
+    dw_body<4, 1, 2, 1>(all.cls[2], hw - all.begin[2], all.begin[3] - all.begin[2], dw_lds);
+  }
 }
 
 // fp32 [M][F] (optionally times act'(aux)) -> bf16 [M][ld], zero padded to ld.
@@ -662,9 +689,13 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
                "mi_dense_bwd_dw_grouped_bf16: bad problem %lld", (long long)l);
     KNv[l] = K[l] * N[l];
   }
-  // one launch per tile class (by output width), problems of a class side by side
+  // one workgroup range per tile class (by output width), problems of a class side by
+  // side; all classes go out in ONE launch
+  DwAll all = {};
+  unsigned next = 0;
+  size_t lds = 0;
   for (int cls = 0; cls < 3; ++cls) {
-    DwTable tab = {};
+    DwTable& tab = all.cls[cls];
     int idx[kMaxDwProblems];
     int64_t tiles = 0, gx = 0, gy = 0;
     for (int64_t l = 0; l < n; ++l) {
@@ -676,6 +707,7 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
       if (tx > gx) gx = tx;
       if (ty > gy) gy = ty;
     }
+    all.begin[cls] = next;
     if (tab.n == 0) continue;
     int64_t rows, S;
     dw_split_plan(M, tiles, &rows, &S);
@@ -698,15 +730,20 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
     }
     tab.gx = (int)gx;
     tab.gy = (int)gy;
-    MI_REQUIRE(gx * gy * tab.n * S <= 0x7fffffffLL, "mi_dense_bwd_dw_grouped_bf16: grid too large");
-    dim3 grid((unsigned)(gx * gy * tab.n * S));
-    if (cls == 0) {
-      hipLaunchKernelGGL((tn_gemm_dw_kernel<2, 2, 4, 4>), grid, dim3(kThreads), 0, st, tab);
-    } else if (cls == 1) {
-      hipLaunchKernelGGL((tn_gemm_dw_kernel<4, 1, 2, 4>), grid, dim3(kThreads), 0, st, tab);
-    } else {
-      hipLaunchKernelGGL((tn_gemm_dw_kernel<4, 1, 2, 1>), grid, dim3(kThreads), 0, st, tab);
-    }
+    const int64_t blocks = gx * gy * tab.n * S;
+    MI_REQUIRE(next + blocks <= 0x7fffffffLL, "mi_dense_bwd_dw_grouped_bf16: grid too large");
+    next += (unsigned)blocks;
+    const size_t need = cls == 0 ? dw_lds_bytes<2, 2, 4, 4>()
+                                 : (cls == 1 ? dw_lds_bytes<4, 1, 2, 4>() : dw_lds_bytes<4, 1, 2, 1>());
+    if (need > lds) lds = need;
+  }
+  all.begin[3] = next;
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&tn_gemm_dw_all_kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2, 2, 4, 4>());
+  MI_REQUIRE(attr == hipSuccess, "mi_dense_bwd_dw_grouped_bf16: cannot raise the LDS limit");
+  hipLaunchKernelGGL(tn_gemm_dw_all_kernel, dim3(next), dim3(kThreads), lds, st, all);
+  {
     int rc = mippo::check_launch("mi_dense_bwd_dw_grouped_bf16");
     if (rc) return rc;
   }
