@@ -211,7 +211,9 @@ def ppo_step(
     reset_key, new_key = keys[0], keys[1]
     total_iterations = n_epochs * n_minibatches
     if minibatch_inds is None:
-        # every epoch's permutation in one launch (they depend on the key only)
+        # every epoch's permutation in one launch (they depend on the key only).  Not
+        # forked onto the second stream: a second branch in the captured graph costs
+        # more than the kernel it would hide (measured: 31.2 M vs 32.5 M env-steps/s).
         all_indices = minibatch_indices(new_key, n_envs, n_epochs, n_minibatches)
     else:
         all_indices = minibatch_inds

@@ -111,25 +111,39 @@ key_permutations_kernel(const int64_t* __restrict__ key, int64_t* __restrict__ o
     hi[i] = i;
   }
   __syncthreads();
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < P; i += kSortThreads) {
-        const int l = i ^ j;
-        if (l > i) {
-          const int64_t a = hk[i], b = hk[l];
-          const int ia = hi[i], ib = hi[l];
-          const bool a_gt_b = a > b || (a == b && ia > ib);
-          const bool up = (i & k) == 0;
-          if (a_gt_b == up) {
-            hk[i] = b;
-            hk[l] = a;
-            hi[i] = ib;
-            hi[l] = ia;
-          }
-        }
+  // P/2 compare-exchanges per stage, one per loop trip of a thread (no idle half): pair
+  // q -> lower element i = insert a zero bit at position log2(j) of q, partner i + j.
+  // For j <= 64 the 64 pairs of a wave's trip stay inside one aligned 128-element chunk
+  // through all remaining stages of the merge, so those stages need no workgroup
+  // barrier (LDS operations of a wave are ordered): 15 barriers instead of 78 at P = 4096.
+  auto stage = [&](int k, int j) {
+    for (int q = threadIdx.x; q < (P >> 1); q += kSortThreads) {
+      const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+      const int l = i + j;
+      const int64_t a = hk[i], b = hk[l];
+      const int ia = hi[i], ib = hi[l];
+      const bool a_gt_b = a > b || (a == b && ia > ib);
+      const bool up = (i & k) == 0;
+      if (a_gt_b == up) {
+        hk[i] = b;
+        hk[l] = a;
+        hi[i] = ib;
+        hi[l] = ia;
       }
+    }
+  };
+  for (int k = 2; k <= P; k <<= 1) {
+    int j = k >> 1;
+    for (; j > 64; j >>= 1) {
+      stage(k, j);
       __syncthreads();
     }
+    for (; j > 0; j >>= 1) {
+      stage(k, j);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
   }
   int64_t* o = out + (int64_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += kSortThreads) o[i] = hi[i];
