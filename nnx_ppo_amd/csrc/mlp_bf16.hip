@@ -65,6 +65,7 @@ struct Chain {
   int64_t M;
   int L;
   int arow;             // LDS row length in bf16: widest (32-rounded) layer + 8
+  int bias_off;         // forward: LDS byte offset of the fp32 bias rows (32-padded, zero filled)
 };
 
 // Fused policy step (mi_policy_fwd_bf16): blockIdx.y picks one of two trunks that
@@ -104,6 +105,38 @@ __device__ inline IStep istep_next(const ChainLayer& ly, IStep s) {
   return s;
 }
 
+// -DMIPPO_TRACE (tools/trace_policy.py): thread 0 of every workgroup stamps the shader
+// clock at each phase boundary; compiled out of the product build.
+#ifdef MIPPO_TRACE
+constexpr int TR_EV = 64, TR_WG = 2048;
+__device__ unsigned long long g_trace[TR_WG * TR_EV];
+// stamps go to LDS and are copied out at the end: a global store per stamp would sit in
+// the wave's vmcnt queue and add a store round trip to every later wait
+#define MI_TR()                                                                      \
+  do {                                                                               \
+    if (tid == 0 && ev_ < TR_EV - 2) tr_s[ev_] = __builtin_amdgcn_s_memtime();       \
+    ++ev_;                                                                           \
+  } while (0)
+#define MI_TR_BEGIN()                                                                \
+  __shared__ unsigned long long tr_s[TR_EV];                                         \
+  int ev_ = 0;                                                                       \
+  const unsigned long long tr_t0_ = wall_clock64();
+#define MI_TR_END()                                                                  \
+  do {                                                                               \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                        \
+    if (tid == 0 && wg_ < TR_WG) {                                                   \
+      for (int i_ = 0; i_ < TR_EV - 2; ++i_)                                         \
+        g_trace[wg_ * TR_EV + i_] = i_ < ev_ ? tr_s[i_] : 0ull;                      \
+      g_trace[wg_ * TR_EV + TR_EV - 2] = tr_t0_;                                     \
+      g_trace[wg_ * TR_EV + TR_EV - 1] = wall_clock64();                             \
+    }                                                                                \
+  } while (0)
+#else
+#define MI_TR() do {} while (0)
+#define MI_TR_BEGIN() do {} while (0)
+#define MI_TR_END() do {} while (0)
+#endif
+
 struct BFrags {
   bf16x8 f[IF_KS][4];  // [k-step][column tile]
 };
@@ -123,25 +156,40 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int64_t i0 = (int64_t)blockIdx.x * ROWS;
-  if (i0 >= c.M) return;  // a launch covers the longer of two trunks (policy step)
+  // kernel-argument scalars the loop needs, read ONCE: left as `c.field` the compiler
+  // re-reads them from the argument segment at every use (an s_load + lgkmcnt(0) wait,
+  // ~90 of them in the loop body)
+  const int64_t cM = c.M;
+  const int cL = c.L;
+  float* const c_out = c.out;
+  const float* const bias_s = reinterpret_cast<const float*>(lds_raw + c.bias_off);
+  if (i0 >= cM) return;  // a launch covers the longer of two trunks (policy step)
   const int K0 = c.layer[0].K;
   const int K0p = (K0 + 31) / 32 * 32;
+  MI_TR_BEGIN();
+  MI_TR();
 
   // column tile b of this wave in pass p starts at column ((p*4 + b)*4 + wave) * 16
-  auto load_frags = [&](const IStep& s, const ChainLayer& ly, BFrags& B) {
-    const int KS = (ly.K + 31) / 32;        // k-steps of this layer
-    const int NT = (ly.N + 15) / 16;        // column tiles of this layer
+  // The 8 loads of a step are UNCONDITIONAL straight-line code (tile / k-step indices
+  // past the layer's range are clamped; those fragments are never multiplied): with a
+  // branch around each load the compiler cannot count the loads in flight and waits
+  // for vmcnt(0) in front of every MFMA group — i.e. for the fragments it has just
+  // requested, which turns the prefetch into one exposed memory round trip per step
+  // (tools/trace_policy.py: 2 000-2 800 cycles per step whatever the step computes).
+  auto load_frags = [&](const IStep& s, const bf16_t* w, int K, int N, BFrags& B) {
+    const int KS = (K + 31) / 32;        // k-steps of this layer
+    const int NT = (N + 15) / 16;        // column tiles of this layer
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int ct = (s.p * 4 + b) * 4 + wave;
+      int ct = (s.p * 4 + b) * 4 + wave;
+      ct = ct < NT ? ct : NT - 1;
 #pragma unroll
       for (int ks = 0; ks < IF_KS; ++ks) {
-        const int kg = s.kc / 32 + ks;
-        u32x4 r = u32x4{0u, 0u, 0u, 0u};
-        // one contiguous 1 KiB per wave-instruction (the image is zero padded)
-        if (ct < NT && kg < KS)
-          r = *reinterpret_cast<const u32x4*>(ly.w + (int64_t)(ct * KS + kg) * 512 + lane * 8);
-        B.f[ks][b] = __builtin_bit_cast(bf16x8, r);
+        int kg = s.kc / 32 + ks;
+        kg = kg < KS ? kg : KS - 1;
+        // one contiguous 1 KiB per wave-instruction
+        B.f[ks][b] = __builtin_bit_cast(
+            bf16x8, *reinterpret_cast<const u32x4*>(w + (int64_t)(ct * KS + kg) * 512 + lane * 8));
       }
     }
   };
@@ -152,12 +200,21 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     int sh = 0;
     while ((1 << sh) < nch) ++sh;             // scalar
     const int cc = tid & ((1 << sh) - 1);
+    const int rstep = kThreads >> sh;
     if (cc < nch) {
-      for (int row = tid >> sh; row < ROWS; row += kThreads >> sh) {
-        const int64_t gi = i0 + row;
-        if (gi < c.M)
-          *reinterpret_cast<u32x4*>(dst + gi * ld + cc * 8) =
-              *reinterpret_cast<const u32x4*>(buf + row * arow + cc * 8);
+      for (int row = tid >> sh; row < ROWS; row += 4 * rstep) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // clamped: in-bounds LDS reads, stores predicated below
+          const int ru = row + u * rstep < ROWS ? row + u * rstep : ROWS - 1;
+          v[u] = *reinterpret_cast<const u32x4*>(buf + ru * arow + cc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ru = row + u * rstep;
+          const int64_t gi = i0 + ru;
+          if (ru < ROWS && gi < cM) *reinterpret_cast<u32x4*>(dst + gi * ld + cc * 8) = v[u];
+        }
       }
     }
   };
@@ -168,11 +225,64 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   // descriptors are kept in registers instead and rolled forward at layer changes,
   // so the load for layer l+2 is issued a whole layer before it is needed.
   ChainLayer Lc = c.layer[0];
-  ChainLayer Ln = c.layer[c.L > 1 ? 1 : 0];
+  ChainLayer Ln = c.layer[cL > 1 ? 1 : 0];
   IStep s = {0, 0, 0};
   BFrags B, Bn;
-  load_frags(s, Lc, B);
+  load_frags(s, Lc.w, Lc.K, Lc.N, B);
+  MI_TR();
 
+  // Every XCD's L2 starts a kernel cold and the workgroups of a launch walk the layers
+  // in lock-step, so each layer's first fetch would be an L2 miss for all of them at
+  // once.  Workgroups 8l .. 8l+7 (one per XCD: consecutive workgroups go to consecutive
+  // XCDs) touch one dword per 128-byte line of layer l's image at kernel start; the
+  // values are folded into `warm` after the input stage and never used.
+  unsigned warm = 0;
+  if (blockIdx.x < 8 * (unsigned)cL) {
+    const ChainLayer& wl = c.layer[blockIdx.x >> 3];
+    const int64_t bytes = (int64_t)((wl.N + 15) / 16) * ((wl.K + 31) / 32) * 1024;
+    unsigned t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t off = (int64_t)(tid + u * kThreads) * 128;
+      t[u] = off < bytes ? *reinterpret_cast<const unsigned*>(
+                               reinterpret_cast<const char*>(wl.w) + off)
+                         : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) warm ^= t[u];
+  }
+  MI_TR();
+  // bias rows -> LDS (each padded to a multiple of 32 columns with zeros): the epilogue
+  // then has no global load of its own.  Every layer's values are requested here and
+  // stored after the input tile below, so both share one memory round trip.
+  float bv[CH_MAXL][2];
+  if constexpr (!BWD) {
+#pragma unroll
+    for (int l = 0; l < CH_MAXL; ++l) {
+      bv[l][0] = bv[l][1] = 0.0f;
+      if (l < cL) {
+        const float* bl = c.layer[l].bias;
+        const int Nl = c.layer[l].N;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (bl && tid + u * kThreads < Nl) bv[l][u] = bl[tid + u * kThreads];
+      }
+    }
+  }
+
+  // the sampler's own inputs (counter, replayed actions) are first needed after the last
+  // layer: request their lines now so that the tail does not start with a cold miss
+  unsigned tw0 = 0, tw1 = 0, tw2 = 0;
+  if constexpr (POLICY && !BWD) {
+    const mippo_sampler::FwdParams& sp = px->samp;
+    if (sp.A > 0 && blockIdx.y == 0 && tid < ROWS && i0 + tid < cM) {
+      const int64_t e = (i0 + tid) * sp.A;
+      if (sp.noise.rng) tw0 = (unsigned)sp.noise.rng[1];
+      if (sp.extras) tw1 = __float_as_uint(sp.extras[e]);
+      if (sp.noise.eps2) tw2 = __float_as_uint(sp.noise.eps2[e]);
+    }
+  }
+  MI_TR();
   // stage 0: fp32 input tile (x act'(aux0) in the backward) -> bf16, zero padded
   bool from_sampler = false;
   if constexpr (POLICY && BWD) from_sampler = px->sbwd.A > 0 && blockIdx.y == 0;
@@ -182,7 +292,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
       // gradient columns (K0 == 2A); the others clear the pad columns
       for (int row = tid; row < ROWS; row += kThreads) {
         bf16_t* dst = act0 + row * arow;
-        if (i0 + row < c.M) {
+        if (i0 + row < cM) {
           mippo_sampler::bwd_row(i0 + row, px->sbwd, [dst](int j, float v) { dst[j] = (bf16_t)v; });
         } else {
           for (int k = 0; k < K0; ++k) dst[k] = (bf16_t)0.0f;
@@ -192,27 +302,99 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         act0[(i / (K0p - K0)) * arow + K0 + i % (K0p - K0)] = (bf16_t)0.0f;
     }
   }
-  for (int row = tid >> 5; row < (from_sampler ? 0 : ROWS); row += kThreads >> 5)
-  for (int k = tid & 31; k < K0p; k += 32) {
-    const int64_t gi = i0 + row;
-    float v = 0.0f;
-    if (gi < c.M && k < K0)
-      v = gi < c.M_head ? c.x[gi * K0 + k] : c.x_tail[(gi - c.M_head) * K0 + k];
-    if constexpr (POLICY && !BWD) {
-      // normalizer.py:76-81,92-96 — the same fp32 expression as normalize_fwd_kernel
-      if (px->norm_mean && gi < c.M && k < K0) {
-        const float cnt = *px->norm_count;
-        const float sd = cnt > 0.0f ? sqrtf(fmaxf(px->norm_m2[k] / cnt, px->norm_eps)) : 10.0f;
-        v = (v - px->norm_mean[k]) / sd;
+  if (!from_sampler) {
+    // The tile's ROWS x K0 real elements are one contiguous run of the input: thread t
+    // takes elements t, t + 256, ... and ALL loads of a batch of 4 are issued before the
+    // first is used (one memory round trip for the tile instead of one per row group).
+    const int nel = ROWS * K0;
+    for (int e0 = 0; e0 < nel; e0 += 4 * kThreads) {
+      float xv[4], av[4], mean[4], m2[4];
+      int rw[4], kk[4];
+      bool ok[4];
+      float cnt = 0.0f;
+      bool norm = false;
+      if constexpr (POLICY && !BWD) {
+        norm = px->norm_mean != nullptr;
+        if (norm) cnt = *px->norm_count;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * kThreads + tid;
+        rw[u] = e / K0;
+        kk[u] = e - rw[u] * K0;
+        const int64_t gi = i0 + rw[u];
+        ok[u] = e < nel && gi < cM;
+        xv[u] = 0.0f;
+        av[u] = 0.0f;
+        mean[u] = 0.0f;
+        m2[u] = 1.0f;
+        if (ok[u]) {
+          xv[u] = gi < c.M_head ? c.x[gi * K0 + kk[u]] : c.x_tail[(gi - c.M_head) * K0 + kk[u]];
+          if constexpr (POLICY && !BWD) {
+            if (norm) {
+              mean[u] = px->norm_mean[kk[u]];
+              m2[u] = px->norm_m2[kk[u]];
+            }
+          }
+          if constexpr (BWD) {
+            if (c.aux0) av[u] = (float)c.aux0[gi * c.ldaux0 + kk[u]];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v = xv[u];
+        if constexpr (POLICY && !BWD) {
+          // normalizer.py:76-81,92-96 — the same fp32 expression as normalize_fwd_kernel
+          if (norm && ok[u]) {
+            const float sd = cnt > 0.0f ? sqrtf(fmaxf(m2[u] / cnt, px->norm_eps)) : 10.0f;
+            v = (v - mean[u]) / sd;
+          }
+        }
+        if constexpr (BWD) {
+          if (c.aux0 && ok[u]) v *= act_grad(av[u], c.act0);
+        }
+        if (e0 + u * kThreads + tid < nel) act0[rw[u] * arow + kk[u]] = (bf16_t)v;
       }
     }
-    if (BWD && c.aux0 && gi < c.M && k < K0)
-      v *= act_grad((float)c.aux0[gi * c.ldaux0 + k], c.act0);
-    act0[row * arow + k] = (bf16_t)v;
+    const int padw = K0p - K0;  // zero the pad columns the first layer reduces over
+    for (int i = tid; i < ROWS * padw; i += kThreads)
+      act0[(i / padw) * arow + K0 + i % padw] = (bf16_t)0.0f;
   }
+  warm ^= tw0 ^ tw1 ^ tw2;
+  if constexpr (!BWD) {
+    float* const bias_w = reinterpret_cast<float*>(lds_raw + c.bias_off);
+    int boff = 0;
+#pragma unroll
+    for (int l = 0; l < CH_MAXL; ++l) {
+      if (l < cL) {
+        const int Np32 = (c.layer[l].N + 31) / 32 * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (tid + u * kThreads < Np32) bias_w[boff + tid + u * kThreads] = bv[l][u];
+        boff += Np32;
+      }
+    }
+  }
+  MI_TR();
   __syncthreads();
-  if (c.x_bf) flush(act0, c.x_bf, c.ldx);
+  MI_TR();
+  // Copies to global are deferred by one layer: the bf16 image of layer l's output is
+  // written out while layer l+1's MFMAs run (its LDS buffer stays intact until layer
+  // l+2's epilogue), so the stores have a whole layer to be acknowledged before any
+  // later wait of this wave has to pass them (vmcnt counts loads and stores in order).
+  const bf16_t* pf_buf = act0;
+  bf16_t* pf_dst = c.x_bf;
+  int64_t pf_ld = c.ldx;
+  MI_TR();
 
+  bool samp_here = false;     // this workgroup's trunk ends in the sampler
+  float* ms_base = nullptr;
+  if constexpr (POLICY && !BWD) {
+    samp_here = px->samp.A > 0 && blockIdx.y == 0;
+    ms_base = reinterpret_cast<float*>(lds_raw + px->ms_off);
+  }
+  int boff_c = 0;     // offset of the current layer's bias row in the LDS bias area
   f32x4 acc[RT][4];   // acc[r][b][e]: row r*16 + li, column tile b, column 4*lq + e
   s16x4 auxr[RT][4];  // backward: the act' operands of the same elements
   // Unrolled epilogue of one column pass.  TRANS selects, at compile time, the
@@ -224,15 +406,15 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   auto epilogue = [&](const IStep& st, const ChainLayer& ly, auto trans_tag) {
     constexpr bool TRANS = decltype(trans_tag)::value;
     bf16_t* const nbuf = (st.l & 1) ? act0 : act1;
-    const bool last = st.l == c.L - 1;
+    const bool last = st.l == cL - 1;
     const bool keep = !last || ly.out_bf;
-    const bool to_out = last && c.out;
+    const bool to_out = last && c_out;
     // action trunk of a policy step: the sampler reads the fp32 output row from LDS
     bool to_ms = false;
     float* ms_s = nullptr;
     if constexpr (POLICY && !BWD) {
-      to_ms = last && px->samp.A > 0 && blockIdx.y == 0;
-      ms_s = reinterpret_cast<float*>(lds_raw + px->ms_off);
+      to_ms = last && samp_here;
+      ms_s = ms_base;
     }
     const bool store_pre = !BWD && TRANS && ly.pre_bf;
     const bool use_aux = BWD && ly.aux && ly.act != MI_ACT_NONE;
@@ -245,14 +427,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
       const int j0 = ct * 16 + 4 * lq;
       const bool full = ct * 16 + 16 <= ly.N;    // no pad column in this tile
       f32x4 bj = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!BWD && ly.bias) {
-        if (full) {
-          bj = *reinterpret_cast<const f32x4*>(ly.bias + j0);  // arena rows are 256-B aligned
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bj[e] = j0 + e < ly.N ? ly.bias[j0 + e] : 0.0f;
-        }
-      }
+      if constexpr (!BWD)  // staged at kernel start (zeros where the layer has no bias)
+        bj = *reinterpret_cast<const f32x4*>(bias_s + boff_c + j0);
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         const int row = r * 16 + li;
@@ -295,7 +471,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         if (keep) *reinterpret_cast<bf16x4*>(nbuf + row * arow + j0) = vo;
         if constexpr (!BWD && TRANS) {
           const int64_t gi = i0 + row;
-          if (store_pre && gi < c.M && j0 < ly.ldo)
+          if (store_pre && gi < cM && j0 < ly.ldo)
             *reinterpret_cast<bf16x4*>(ly.pre_bf + gi * ly.ldo + j0) = zo;
         }
         // fp32 results of the chain's last layer (a handful of columns): kept out
@@ -304,7 +480,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
           const int64_t gi = i0 + row;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (gi < c.M && j0 + e < ly.N) c.out[gi * ly.N + j0 + e] = v4[e];
+            if (gi < cM && j0 + e < ly.N) c_out[gi * ly.N + j0 + e] = v4[e];
         }
         if constexpr (POLICY && !BWD) {
           if (to_ms) {
@@ -317,17 +493,53 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     }
   };
 
-  while (s.l < c.L) {
+  // Hidden relu layer whose width is a multiple of 32 — the common case: no pad columns,
+  // no fp32 / sampler / pre-activation outputs, so none of the per-(tile, row) uniform
+  // tests of the general epilogue (each a compare + taken branch) is needed.  The trunk
+  // kernels are bound by instruction issue; this is ~12 instead of ~30 instructions per
+  // (tile, row).  Same fp32 expressions as the general path.
+  auto epilogue_hidden_relu = [&](const IStep& st, const ChainLayer& ly) {
+    bf16_t* const wbase = ((st.l & 1) ? act0 : act1) + li * arow + 4 * lq;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ct = (st.p * 4 + b) * 4 + wave;
+      if (ct * 16 >= ly.N) continue;
+      f32x4 bj = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!BWD) bj = *reinterpret_cast<const f32x4*>(bias_s + boff_c + ct * 16 + 4 * lq);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        f32x4 v4 = acc[r][b];
+        bf16x4 vo;
+        if constexpr (BWD) {
+          const bf16x4 a4 = __builtin_bit_cast(bf16x4, auxr[r][b]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] *= ((float)a4[e] > 0.0f ? 1.0f : 0.0f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = fmaxf(v4[e] + bj[e], 0.0f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)v4[e];
+        *reinterpret_cast<bf16x4*>(wbase + r * 16 * arow + ct * 16) = vo;
+      }
+    }
+  };
+
+  while (s.l < cL) {
     const IStep st = s;
     const ChainLayer& ly = Lc;
     const int Kp = (ly.K + 31) / 32 * 32;
     const bf16_t* const cbuf = (st.l & 1) ? act1 : act0;
     const bool pass_done = st.kc + IF_KC >= Kp;  // this step completes the wave's columns
     const IStep sn = istep_next(ly, st);
-    if (sn.l < c.L) {
-      if (sn.l == st.l) load_frags(sn, Lc, Bn);
-      else load_frags(sn, Ln, Bn);
+    {
+      // next step's fragments; the last step re-reads its own (never used) so that the
+      // loads of a step stay unconditional
+      const bool same = sn.l == st.l || sn.l >= cL;
+      const IStep sl = sn.l < cL ? sn : st;
+      load_frags(sl, same ? Lc.w : Ln.w, same ? Lc.K : Ln.K, same ? Lc.N : Ln.N, Bn);
     }
+    MI_TR();
     if constexpr (BWD) {
       if (pass_done && ly.aux && ly.act != MI_ACT_NONE) {
         // act' operands of this pass: 8 bytes per (row, column tile), in flight
@@ -339,7 +551,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
           for (int r = 0; r < RT; ++r) {
             const int64_t gi = i0 + r * 16 + li;
             s16x4 a = s16x4{0, 0, 0, 0};
-            if (gi < c.M && j0 < ly.ldo)
+            if (gi < cM && j0 < ly.ldo)
               a = *reinterpret_cast<const s16x4*>(ly.aux + gi * ly.ldo + j0);
             auxr[r][b] = a;
           }
@@ -371,16 +583,30 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         }
       }
     }
+    MI_TR();
+    if (pf_dst) {  // the previous layer's image, while this step's MFMAs run
+      flush(pf_buf, pf_dst, pf_ld);
+      pf_dst = nullptr;
+    }
+    MI_TR();
     if (pass_done) {
       const bool trans = BWD ? ly.act == MI_ACT_SWISH : ly.act >= MI_ACT_TANH;
-      if (trans) {
+      const bool hidden_relu = st.l != cL - 1 && (ly.N & 31) == 0 && ly.act == MI_ACT_RELU &&
+                               (!BWD || ly.aux);
+      if (hidden_relu) {
+        epilogue_hidden_relu(st, ly);
+      } else if (trans) {
         epilogue(st, ly, std::true_type{});
       } else {
         epilogue(st, ly, std::false_type{});
       }
-      if (sn.l != st.l) {  // layer finished: publish, copy out
+      MI_TR();
+      if (sn.l != st.l) {  // layer finished: publish; the copy out rides on the next step
         __syncthreads();
-        if (ly.out_bf) flush((st.l & 1) ? act0 : act1, ly.out_bf, ly.ldo);
+        MI_TR();
+        pf_buf = (st.l & 1) ? act0 : act1;
+        pf_dst = ly.out_bf;
+        pf_ld = ly.ldo;
       }
     }
     // hand the prefetched fragments to the next step (register moves)
@@ -389,20 +615,25 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
 #pragma unroll
       for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
     if (sn.l != st.l) {  // roll the descriptors: the load for layer l+2 starts now
+      boff_c += (Lc.N + 31) / 32 * 32;
       Lc = Ln;
-      if (sn.l + 1 < c.L) Ln = c.layer[sn.l + 1];
+      if (sn.l + 1 < cL) Ln = c.layer[sn.l + 1];
     }
     s = sn;
   }
+  if (pf_dst) flush(pf_buf, pf_dst, pf_ld);
+  if (warm == 0x9e3779b9u && cM < 0) act0[tid] = (bf16_t)0.0f;  // keeps the warm-up loads
   if constexpr (POLICY && !BWD) {
     // sampling_layers.py:82-147 on this workgroup's rows (the last layer's barrier
     // has published ms_s); one thread per row, as in sampler_fwd_kernel
-    if (px->samp.A > 0 && blockIdx.y == 0) {
-      const float* ms_s = reinterpret_cast<const float*>(lds_raw + px->ms_off);
+    if (samp_here) {
+      const float* ms_s = ms_base;
       for (int row = tid; row < ROWS; row += kThreads)
-        if (i0 + row < c.M) mippo_sampler::fwd_row(ms_s + row * 2 * px->samp.A, i0 + row, px->samp);
+        if (i0 + row < cM) mippo_sampler::fwd_row(ms_s + row * 2 * px->samp.A, i0 + row, px->samp);
     }
   }
+  MI_TR();
+  MI_TR_END();
 }
 
 template <int RT, bool BWD>
@@ -423,14 +654,32 @@ policy_bwd_kernel(PolicyArgs a) {
   chain_body<RT, true, true>(a.c[blockIdx.y], &a.px);
 }
 
+// fp32 words of the LDS bias area of a forward chain (one 32-padded row per layer)
+int bias_words(const Chain& c) {
+  int n = 0;
+  for (int l = 0; l < c.L; ++l) n += (c.layer[l].N + 31) / 32 * 32;
+  return n;
+}
+
+#ifdef MIPPO_TRACE
+constexpr int kLdsMax = 160 * 1024 - 512;  // room for the static stamp buffer
+#else
+constexpr int kLdsMax = 160 * 1024;
+#endif
+
 template <int RT, bool BWD>
-int launch_rt(const Chain& c, hipStream_t st) {
-  const size_t lds = (size_t)2 * 16 * RT * c.arow * sizeof(bf16_t);
+int launch_rt(Chain& c, hipStream_t st) {
+  const int act_bytes = 2 * 16 * RT * c.arow * (int)sizeof(bf16_t);
+  c.bias_off = act_bytes;
+  const size_t lds = (size_t)act_bytes + (BWD ? 0 : (size_t)bias_words(c) * sizeof(float));
+  constexpr int kWant = 2 * 16 * RT * (512 + 8) * (int)sizeof(bf16_t) + CH_MAXL * 512 * 4;
+  constexpr int kCap = kWant < kLdsMax ? kWant : kLdsMax;
   static const hipError_t attr = hipFuncSetAttribute(
       reinterpret_cast<const void*>(&mlp_chain_kernel<RT, BWD>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * RT * (512 + 8) * (int)sizeof(bf16_t));
+      hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
   MI_REQUIRE(attr == hipSuccess, "mlp_chain: cannot raise the dynamic LDS limit: %s",
              hipGetErrorString(attr));
+  MI_REQUIRE(lds <= (size_t)kCap, "mlp_chain: %zu bytes of LDS needed, %d available", lds, kCap);
   hipLaunchKernelGGL((mlp_chain_kernel<RT, BWD>), dim3((unsigned)mippo::ceil_div(c.M, 16 * RT)),
                      dim3(kThreads), lds, st, c);
   return mippo::check_launch(BWD ? "mi_mlp_bwd_dx_bf16" : "mi_mlp_fwd_bf16");
@@ -502,9 +751,13 @@ int launch_policy(PolicyArgs& a, int maxw, hipStream_t st) {
   constexpr int ROWS = 16 * RT;
   const int act_bytes = 2 * ROWS * (maxw + 8) * (int)sizeof(bf16_t);
   a.px.ms_off = act_bytes;
-  const size_t lds = (size_t)act_bytes + (size_t)ROWS * 2 * a.px.samp.A * sizeof(float);
-  constexpr int kWant = 2 * ROWS * (512 + 8) * (int)sizeof(bf16_t) + ROWS * 128 * (int)sizeof(float);
-  constexpr int kCap = kWant < 160 * 1024 ? kWant : 160 * 1024;
+  const int ms_bytes = (ROWS * 2 * a.px.samp.A * (int)sizeof(float) + 15) / 16 * 16;
+  a.c[0].bias_off = a.c[1].bias_off = act_bytes + ms_bytes;
+  const int bw0 = bias_words(a.c[0]), bw1 = bias_words(a.c[1]);
+  const size_t lds = (size_t)act_bytes + ms_bytes + (size_t)(bw0 > bw1 ? bw0 : bw1) * sizeof(float);
+  constexpr int kWant = 2 * ROWS * (512 + 8) * (int)sizeof(bf16_t) +
+                        ROWS * 128 * (int)sizeof(float) + CH_MAXL * 512 * 4;
+  constexpr int kCap = kWant < kLdsMax ? kWant : kLdsMax;
   static const hipError_t attr = hipFuncSetAttribute(
       reinterpret_cast<const void*>(&policy_kernel<RT>),
       hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
@@ -715,3 +968,14 @@ extern "C" int mi_policy_bwd_bf16(
                           "(use mi_mlp_bwd_dx_bf16 per trunk)");
   return launch_policy_bwd<4>(a, maxw, st);
 }
+
+#ifdef MIPPO_TRACE
+extern "C" int mi_debug_trace(unsigned long long* host_out, int64_t n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), (size_t)n * 8);
+}
+extern "C" int mi_debug_trace_clear() {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace));
+  return e != hipSuccess ? (int)e : (int)hipMemset(p, 0, sizeof(g_trace));
+}
+#endif

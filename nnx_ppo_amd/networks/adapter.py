@@ -5,6 +5,8 @@ ports see the same input; the action port's output is a tree of sampler dicts
 squeezed (`adapter.py:55-58,98`)."""
 from __future__ import annotations
 
+import os
+
 from typing import Any
 
 import torch
@@ -64,7 +66,7 @@ class _Fork:
 
 
 _SIDE_STREAMS: dict = {}
-OVERLAP_PORTS = True
+OVERLAP_PORTS = os.environ.get("MIPPO_OVERLAP_PORTS", "1") != "0"
 
 
 def _can_fork(x) -> bool:
