@@ -632,12 +632,20 @@ extern "C" int mi_dense_bwd_dx_bf16(const void* dz_bf, int64_t lddz, const void*
 
 // rows per split / number of splits shared by every problem of a launch (they
 // share M): enough workgroups to cover the chip about twice, >= 128 rows each.
-static void dw_split_plan(int64_t M, int64_t total_tiles, int64_t* rows, int64_t* S) {
-  // MIPPO_DW_BLOCKS overrides the target workgroup count (tuning aid)
-  static const int64_t target = [] {
+// `classes`: tile classes that share the launch.  The launch as a whole aims at ~2.25
+// workgroups per CU: every split adds a K x N fp32 slab that is written and read again
+// (at C2 and 512 workgroups per class the slabs moved as many bytes as the operands);
+// measured on bench.py with MIPPO_DW_BLOCKS = 64 .. 768 per class, best at 160-192.
+static void dw_split_plan(int64_t M, int64_t total_tiles, int classes, int64_t* rows,
+                          int64_t* S) {
+  // MIPPO_DW_BLOCKS overrides the per-class target workgroup count (tuning aid)
+  static const int64_t override_target = [] {
     const char* e = getenv("MIPPO_DW_BLOCKS");
-    return e ? (int64_t)atoi(e) : (int64_t)2 * mippo::kNumCU;
+    return e ? (int64_t)atoi(e) : (int64_t)0;
   }();
+  const int64_t target = override_target > 0
+                             ? override_target
+                             : (int64_t)9 * mippo::kNumCU / 4 / (classes < 1 ? 1 : classes);
   int64_t s = mippo::ceil_div(target, total_tiles < 1 ? 1 : total_tiles);
   const int64_t max_s = mippo::ceil_div(M, 128);
   if (s > max_s) s = max_s;
@@ -664,7 +672,7 @@ extern "C" int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const
   int64_t total = 0;
   for (int64_t l = 0; l < n; ++l) {
     int64_t rows, S;
-    dw_split_plan(M, dw_tiles(K[l], N[l]), &rows, &S);
+    dw_split_plan(M, dw_tiles(K[l], N[l]), 1, &rows, &S);
     total += S * (K[l] * N[l] + N[l]);
   }
   return total * (int64_t)sizeof(float);
@@ -693,6 +701,12 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
   // side; all classes go out in ONE launch
   DwAll all = {};
   unsigned next = 0;
+  int n_classes = 0;
+  {
+    bool has[3] = {false, false, false};
+    for (int64_t l = 0; l < n; ++l) has[N[l] > 64 ? 0 : (N[l] > 16 ? 1 : 2)] = true;
+    n_classes = (int)has[0] + (int)has[1] + (int)has[2];
+  }
   size_t lds = 0;
   for (int cls = 0; cls < 3; ++cls) {
     DwTable& tab = all.cls[cls];
@@ -710,7 +724,7 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
     all.begin[cls] = next;
     if (tab.n == 0) continue;
     int64_t rows, S;
-    dw_split_plan(M, tiles, &rows, &S);
+    dw_split_plan(M, tiles, n_classes, &rows, &S);
     tab.M = M;
     tab.rows_per_split = rows;
     for (int q = 0; q < tab.n; ++q) {

@@ -90,14 +90,13 @@ struct IStep {
   int l, p, kc;  // layer, column pass (256 columns per pass), k-chunk
 };
 
-// `ly` = descriptor of layer s.l
-__device__ inline IStep istep_next(const ChainLayer& ly, IStep s) {
-  const int Kp = (ly.K + 31) / 32 * 32;
+// Kp: the layer's reduce width rounded up to 32, N: its output width
+__device__ inline IStep istep_next(int Kp, int N, IStep s) {
   s.kc += IF_KC;
   if (s.kc >= Kp) {
     s.kc = 0;
     s.p += 1;
-    if (s.p * 256 >= ly.N) {
+    if (s.p * 256 >= N) {
       s.p = 0;
       s.l += 1;
     }
@@ -176,21 +175,26 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   // for vmcnt(0) in front of every MFMA group — i.e. for the fragments it has just
   // requested, which turns the prefetch into one exposed memory round trip per step
   // (tools/trace_policy.py: 2 000-2 800 cycles per step whatever the step computes).
-  auto load_frags = [&](const IStep& s, const bf16_t* w, int K, int N, BFrags& B) {
-    const int KS = (K + 31) / 32;        // k-steps of this layer
-    const int NT = (N + 15) / 16;        // column tiles of this layer
+  // KS / NT (k-steps and column tiles of the layer) are kept per layer, and the block
+  // index is 32-bit unsigned: the step's address arithmetic is a few scalar instructions
+  // per load (it was ~130 dependent scalar instructions per step, ~1 000 cycles).
+  auto load_frags = [&](const IStep& s, const bf16_t* w, unsigned KS, unsigned NT, BFrags& B) {
+    const char* const wb = reinterpret_cast<const char*>(w) + lane * 16;
+    unsigned kg[IF_KS];
+#pragma unroll
+    for (int ks = 0; ks < IF_KS; ++ks) {
+      kg[ks] = ((unsigned)s.kc >> 5) + ks;
+      kg[ks] = kg[ks] < KS ? kg[ks] : KS - 1;
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      int ct = (s.p * 4 + b) * 4 + wave;
+      unsigned ct = ((unsigned)s.p * 4 + b) * 4 + wave;
       ct = ct < NT ? ct : NT - 1;
+      const unsigned base = ct * KS;
 #pragma unroll
-      for (int ks = 0; ks < IF_KS; ++ks) {
-        int kg = s.kc / 32 + ks;
-        kg = kg < KS ? kg : KS - 1;
-        // one contiguous 1 KiB per wave-instruction
+      for (int ks = 0; ks < IF_KS; ++ks)  // one contiguous 1 KiB per wave-instruction
         B.f[ks][b] = __builtin_bit_cast(
-            bf16x8, *reinterpret_cast<const u32x4*>(w + (int64_t)(ct * KS + kg) * 512 + lane * 8));
-      }
+            bf16x8, *reinterpret_cast<const u32x4*>(wb + ((size_t)(base + kg[ks]) << 10)));
     }
   };
   // coalesced copy of a published LDS buffer (rows x ld columns) to global
@@ -228,7 +232,9 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   ChainLayer Ln = c.layer[cL > 1 ? 1 : 0];
   IStep s = {0, 0, 0};
   BFrags B, Bn;
-  load_frags(s, Lc.w, Lc.K, Lc.N, B);
+  unsigned KSc = (unsigned)(Lc.K + 31) >> 5, NTc = (unsigned)(Lc.N + 15) >> 4;
+  unsigned KSn = (unsigned)(Ln.K + 31) >> 5, NTn = (unsigned)(Ln.N + 15) >> 4;
+  load_frags(s, Lc.w, KSc, NTc, B);
   MI_TR();
 
   // Every XCD's L2 starts a kernel cold and the workgroups of a launch walk the layers
@@ -528,16 +534,16 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   while (s.l < cL) {
     const IStep st = s;
     const ChainLayer& ly = Lc;
-    const int Kp = (ly.K + 31) / 32 * 32;
+    const int Kp = (int)KSc * 32;
     const bf16_t* const cbuf = (st.l & 1) ? act1 : act0;
     const bool pass_done = st.kc + IF_KC >= Kp;  // this step completes the wave's columns
-    const IStep sn = istep_next(ly, st);
+    const IStep sn = istep_next(Kp, ly.N, st);
     {
       // next step's fragments; the last step re-reads its own (never used) so that the
       // loads of a step stay unconditional
       const bool same = sn.l == st.l || sn.l >= cL;
       const IStep sl = sn.l < cL ? sn : st;
-      load_frags(sl, same ? Lc.w : Ln.w, same ? Lc.K : Ln.K, same ? Lc.N : Ln.N, Bn);
+      load_frags(sl, same ? Lc.w : Ln.w, same ? KSc : KSn, same ? NTc : NTn, Bn);
     }
     MI_TR();
     if constexpr (BWD) {
@@ -617,7 +623,13 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     if (sn.l != st.l) {  // roll the descriptors: the load for layer l+2 starts now
       boff_c += (Lc.N + 31) / 32 * 32;
       Lc = Ln;
-      if (sn.l + 1 < cL) Ln = c.layer[sn.l + 1];
+      KSc = KSn;
+      NTc = NTn;
+      if (sn.l + 1 < cL) {
+        Ln = c.layer[sn.l + 1];
+        KSn = (unsigned)(Ln.K + 31) >> 5;
+        NTn = (unsigned)(Ln.N + 15) >> 4;
+      }
     }
     s = sn;
   }

@@ -101,8 +101,10 @@ adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
     clip = !(gn < max_norm);
   }
   (void)gscale;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * kThreads) {
+  for (int64_t pass_begin = (int64_t)blockIdx.x * kThreads; pass_begin < n;
+       pass_begin += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = pass_begin + threadIdx.x;
+    if (i >= n) break;
     float gi = g[i];
     if (clip) gi = gi / gn * max_norm;
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -115,17 +117,23 @@ adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
     const float pn = pi - lr * u;
     p[i] = pn;
     if (ticket) g[i] = 0.0f;
+    // The 256 elements of this pass are one contiguous arena range, so the leaves that
+    // overlap it are found with wave-uniform (scalar) tests; inside a leaf the index
+    // arithmetic is 32-bit.  (A per-element search over the table with 64-bit divisions
+    // made this tiny kernel 14 us long.)
     for (int l = 0; l < shadows.n; ++l) {
       const ShadowLeaf& lf = shadows.leaf[l];
-      const int64_t q = i - lf.begin;
-      if (q >= 0 && q < (int64_t)lf.K * lf.N) {
-        const int k = (int)(q / lf.N), c = (int)(q % lf.N);
+      const unsigned KN = (unsigned)lf.K * (unsigned)lf.N;
+      if (lf.begin >= pass_begin + kThreads || lf.begin + (int64_t)KN <= pass_begin) continue;
+      const int64_t q64 = i - lf.begin;
+      if (q64 >= 0 && q64 < (int64_t)KN) {
+        const unsigned q = (unsigned)q64, N = (unsigned)lf.N;
+        const unsigned k = q / N, c = q - k * N;
         const mippo_bf16::bf16_t b = (mippo_bf16::bf16_t)pn;
-        lf.wb[(int64_t)k * lf.ldw + c] = b;
-        lf.wt[(int64_t)c * lf.ldwt + k] = b;
-        if (lf.ff) lf.ff[frag_index(c, k, lf.K)] = b;  // columns = outputs, reduce = K
-        if (lf.fb) lf.fb[frag_index(k, c, lf.N)] = b;  // columns = inputs,  reduce = N
-        break;
+        lf.wb[(size_t)k * lf.ldw + c] = b;
+        lf.wt[(size_t)c * lf.ldwt + k] = b;
+        if (lf.ff) lf.ff[frag_index((int)c, (int)k, lf.K)] = b;  // columns = outputs, reduce = K
+        if (lf.fb) lf.fb[frag_index((int)k, (int)c, lf.N)] = b;  // columns = inputs,  reduce = N
       }
     }
   }
