@@ -90,9 +90,10 @@ struct IStep {
   int l, p, kc;  // layer, column pass (256 columns per pass), k-chunk
 };
 
-// Kp: the layer's reduce width rounded up to 32, N: its output width
-__device__ inline IStep istep_next(int Kp, int N, IStep s) {
-  s.kc += IF_KC;
+// Kp: the layer's reduce width rounded up to 32, N: its output width, kstep: reduce
+// elements per step
+__device__ inline IStep istep_next(int Kp, int N, int kstep, IStep s) {
+  s.kc += kstep;
   if (s.kc >= Kp) {
     s.kc = 0;
     s.p += 1;
@@ -178,23 +179,24 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   // KS / NT (k-steps and column tiles of the layer) are kept per layer, and the block
   // index is 32-bit unsigned: the step's address arithmetic is a few scalar instructions
   // per load (it was ~130 dependent scalar instructions per step, ~1 000 cycles).
+  // A layer with ONE column tile (N <= 16: value heads, the backward's first layer) runs
+  // "deep": the 8 fragment slots of a step hold 8 consecutive k-steps of that tile, so
+  // K = 256 is one step instead of four (same accumulation order, same sums).
   auto load_frags = [&](const IStep& s, const bf16_t* w, unsigned KS, unsigned NT, BFrags& B) {
     const char* const wb = reinterpret_cast<const char*>(w) + lane * 16;
-    unsigned kg[IF_KS];
-#pragma unroll
-    for (int ks = 0; ks < IF_KS; ++ks) {
-      kg[ks] = ((unsigned)s.kc >> 5) + ks;
-      kg[ks] = kg[ks] < KS ? kg[ks] : KS - 1;
-    }
+    const unsigned bstride = (!BWD && NT == 1) ? IF_KS : 0;  // deep: slot (ks, b) = k-step b*IF_KS + ks
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       unsigned ct = ((unsigned)s.p * 4 + b) * 4 + wave;
       ct = ct < NT ? ct : NT - 1;
       const unsigned base = ct * KS;
 #pragma unroll
-      for (int ks = 0; ks < IF_KS; ++ks)  // one contiguous 1 KiB per wave-instruction
+      for (int ks = 0; ks < IF_KS; ++ks) {  // one contiguous 1 KiB per wave-instruction
+        unsigned kg = ((unsigned)s.kc >> 5) + b * bstride + ks;
+        kg = kg < KS ? kg : KS - 1;
         B.f[ks][b] = __builtin_bit_cast(
-            bf16x8, *reinterpret_cast<const u32x4*>(wb + ((size_t)(base + kg[ks]) << 10)));
+            bf16x8, *reinterpret_cast<const u32x4*>(wb + ((size_t)(base + kg) << 10)));
+      }
     }
   };
   // coalesced copy of a published LDS buffer (rows x ld columns) to global
@@ -262,16 +264,23 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   // then has no global load of its own.  Every layer's values are requested here and
   // stored after the input tile below, so both share one memory round trip.
   float bv[CH_MAXL][2];
+  int bN[CH_MAXL];
   if constexpr (!BWD) {
+    // all CH_MAXL descriptors are read unconditionally (unused ones are zero filled), so
+    // the scalar loads of the argument segment go out as one batch with one wait — a
+    // branch on `l < L` in front of each serialised them (~500 cycles apiece)
+    const float* bl[CH_MAXL];
 #pragma unroll
     for (int l = 0; l < CH_MAXL; ++l) {
-      bv[l][0] = bv[l][1] = 0.0f;
-      if (l < cL) {
-        const float* bl = c.layer[l].bias;
-        const int Nl = c.layer[l].N;
+      bl[l] = c.layer[l].bias;
+      bN[l] = c.layer[l].N;
+    }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (bl && tid + u * kThreads < Nl) bv[l][u] = bl[tid + u * kThreads];
+    for (int l = 0; l < CH_MAXL; ++l) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bv[l][u] = 0.0f;
+        if (bl[l] && tid + u * kThreads < bN[l]) bv[l][u] = bl[l][tid + u * kThreads];
       }
     }
   }
@@ -373,13 +382,11 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     int boff = 0;
 #pragma unroll
     for (int l = 0; l < CH_MAXL; ++l) {
-      if (l < cL) {
-        const int Np32 = (c.layer[l].N + 31) / 32 * 32;
+      const int Np32 = (bN[l] + 31) / 32 * 32;  // 0 for the unused descriptors
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (tid + u * kThreads < Np32) bias_w[boff + tid + u * kThreads] = bv[l][u];
-        boff += Np32;
-      }
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * kThreads < Np32) bias_w[boff + tid + u * kThreads] = bv[l][u];
+      boff += Np32;
     }
   }
   MI_TR();
@@ -536,8 +543,10 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     const ChainLayer& ly = Lc;
     const int Kp = (int)KSc * 32;
     const bf16_t* const cbuf = (st.l & 1) ? act1 : act0;
-    const bool pass_done = st.kc + IF_KC >= Kp;  // this step completes the wave's columns
-    const IStep sn = istep_next(Kp, ly.N, st);
+    const bool deep = !BWD && NTc == 1;  // (the backward's single-tile layers have K <= 64)
+    const int kstep = deep ? 4 * IF_KC : IF_KC;
+    const bool pass_done = st.kc + kstep >= Kp;  // this step completes the wave's columns
+    const IStep sn = istep_next(Kp, ly.N, kstep, st);
     {
       // next step's fragments; the last step re-reads its own (never used) so that the
       // loads of a step stay unconditional
@@ -570,21 +579,43 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (deep) {
+      if (wave == 0) {  // the layer's only column tile
 #pragma unroll
-    for (int ks = 0; ks < IF_KS; ++ks) {
-      if (st.kc + ks * 32 < Kp) {
-        bf16x8 af[RT];
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
-          af[r] = *reinterpret_cast<const bf16x8*>(cbuf + (r * 16 + li) * arow + st.kc +
-                                                   ks * 32 + 8 * lq);
+          for (int ks = 0; ks < IF_KS; ++ks) {
+            const int ko = st.kc + (b * IF_KS + ks) * 32;
+            if (ko < Kp) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (((st.p * 4 + b) * 4 + wave) * 16 < ly.N) {
+              for (int r = 0; r < RT; ++r) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(cbuf + (r * 16 + li) * arow +
+                                                                  ko + 8 * lq);
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][b], a, acc[r][0],
+                                                                    0, 0, 0);
+              }
+            }
+            // keep the scheduler from hoisting all 8 x RT operand reads (128 VGPRs at RT = 4)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+    } else {
 #pragma unroll
-            for (int r = 0; r < RT; ++r)  // transposed tile: weights are the A operand
-              acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][b], af[r], acc[r][b],
-                                                                  0, 0, 0);
+      for (int ks = 0; ks < IF_KS; ++ks) {
+        if (st.kc + ks * 32 < Kp) {
+          bf16x8 af[RT];
+#pragma unroll
+          for (int r = 0; r < RT; ++r)
+            af[r] = *reinterpret_cast<const bf16x8*>(cbuf + (r * 16 + li) * arow + st.kc +
+                                                     ks * 32 + 8 * lq);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (((st.p * 4 + b) * 4 + wave) * 16 < ly.N) {
+#pragma unroll
+              for (int r = 0; r < RT; ++r)  // transposed tile: weights are the A operand
+                acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][b], af[r],
+                                                                    acc[r][b], 0, 0, 0);
+            }
           }
         }
       }
@@ -649,19 +680,20 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
 }
 
 template <int RT, bool BWD>
-__global__ void __launch_bounds__(kThreads)
+// (kThreads, 2): at least two waves per SIMD, i.e. at most 256 VGPRs
+__global__ void __launch_bounds__(kThreads, 2)
 mlp_chain_kernel(Chain c) {
   chain_body<RT, BWD, false>(c, nullptr);
 }
 
 template <int RT>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 2)
 policy_kernel(PolicyArgs a) {
   chain_body<RT, false, true>(a.c[blockIdx.y], &a.px);
 }
 
 template <int RT>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 2)
 policy_bwd_kernel(PolicyArgs a) {
   chain_body<RT, true, true>(a.c[blockIdx.y], &a.px);
 }
