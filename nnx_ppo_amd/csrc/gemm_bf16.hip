@@ -293,39 +293,51 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[A_PT], rb[B_PT];
-  auto load_tile = [&](int64_t r0) {
+  // Two register stages (tiles i+1 and i+2 in flight while tile i is multiplied): with
+  // one stage the loads of a tile were in flight for a single 64-row iteration, less than
+  // the memory latency under load, and every iteration ended waiting for them.  Loads are
+  // unconditional (clamped addresses, invalid chunks zeroed by a select) so that the
+  // compiler can count them and wait for the OLDER stage only.
+  struct Stage {
+    u32x4 a[A_PT], b[B_PT];
+  };
+  Stage st0, st1;
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+  const int64_t r_last = r_end - 1;  // r_end > r_begin for every launched split
+  auto load_tile = [&](int64_t r0, Stage& sg) {
 #pragma unroll
     for (int p = 0; p < A_PT; ++p) {
       const int c = tid + p * kThreads;
       const int r = c / (BM / 8), ic = c % (BM / 8);
       const int64_t gr = r0 + r, gi = i0 + ic * 8;
-      ra[p] = u32x4{0u, 0u, 0u, 0u};
-      if (c < A_CH && gr < r_end && gi < lda)
-        ra[p] = *reinterpret_cast<const u32x4*>(A + gr * lda + gi);
+      sg.a[p] = *reinterpret_cast<const u32x4*>(A + (gr < r_end ? gr : r_last) * lda +
+                                                (gi < lda ? gi : 0));
     }
 #pragma unroll
     for (int p = 0; p < B_PT; ++p) {
       const int c = tid + p * kThreads;
       const int r = c / (BN / 8), jc = c % (BN / 8);
       const int64_t gr = r0 + r, gj = j0 + jc * 8;
-      rb[p] = u32x4{0u, 0u, 0u, 0u};
-      if (c < B_CH && gr < r_end && gj < ldb)
-        rb[p] = *reinterpret_cast<const u32x4*>(B + gr * ldb + gj);
+      sg.b[p] = *reinterpret_cast<const u32x4*>(B + (gr < r_end ? gr : r_last) * ldb +
+                                                (gj < ldb ? gj : 0));
     }
   };
-  auto store_tile = [&](int buf) {
+  // (the zeroing select happens here, when the values are consumed, so that only the raw
+  // loaded registers stay live across an iteration)
+  auto store_tile = [&](int buf, const Stage& sg, int64_t r0) {
 #pragma unroll
     for (int p = 0; p < A_PT; ++p) {
       const int c = tid + p * kThreads;
-      if (c < A_CH)
-        *reinterpret_cast<u32x4*>(&As[buf][c / (BM / 8)][(c % (BM / 8)) * 8]) = ra[p];
+      const int r = c / (BM / 8), ic = c % (BM / 8);
+      const bool ok = r0 + r < r_end && i0 + ic * 8 < lda;
+      if (c < A_CH) *reinterpret_cast<u32x4*>(&As[buf][r][ic * 8]) = ok ? sg.a[p] : zero4;
     }
 #pragma unroll
     for (int p = 0; p < B_PT; ++p) {
       const int c = tid + p * kThreads;
-      if (c < B_CH)
-        *reinterpret_cast<u32x4*>(&Bs[buf][c / (BN / 8)][(c % (BN / 8)) * 8]) = rb[p];
+      const int r = c / (BN / 8), jc = c % (BN / 8);
+      const bool ok = r0 + r < r_end && j0 + jc * 8 < ldb;
+      if (c < B_CH) *reinterpret_cast<u32x4*>(&Bs[buf][r][jc * 8]) = ok ? sg.b[p] : zero4;
     }
   };
 
@@ -344,20 +356,19 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
     return __builtin_bit_cast(bf16x8, v);
   };
 
-  float bias_sum = 0.0f;
-  const bool do_bias = bx == 0;
+  // Bias gradient db[j] = sum_r dZ[r][j] rides on the matrix cores: the dZ fragments
+  // against an all-ones operand (wave row 0 of the first row-tile column only).  Summing
+  // the column out of LDS element by element cost ~200 instructions per iteration on the
+  // waves that did it — more than their MFMA work.
+  const bool do_bias = bx == 0 && wm == 0;
+  f32x4 accb[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) accb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short ones_s16x8;
+  const bf16x8 ones = __builtin_bit_cast(
+      bf16x8, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
-  load_tile(r_begin);
-  store_tile(0);
-  __syncthreads();
-  int buf = 0;
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
-    const bool more = r0 + BK < r_end;
-    if (more) load_tile(r0 + BK);
-    if (do_bias && tid < BN) {
-#pragma unroll 8
-      for (int r = 0; r < BK; ++r) bias_sum += (float)Bs[buf][r][tid];
-    }
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 af[TM], bfr[TN];
@@ -375,10 +386,35 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
           // transposed tile (dZ fragment as the A operand): a lane then holds 4
           // CONSECUTIVE output columns of one row — 16-byte slab stores below
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], ones, accb[b], 0, 0, 0);
+      }
     }
-    if (more) store_tile(buf ^ 1);
+  };
+
+  load_tile(r_begin, st0);
+  store_tile(0, st0, r_begin);
+  __syncthreads();
+  load_tile(r_begin + BK, st0);      // tile 1
+  // tile 2 strictly after tile 1: the in-loop waits count on "stage X older than stage Y"
+  __builtin_amdgcn_sched_barrier(0);
+  load_tile(r_begin + 2 * BK, st1);  // tile 2
+  __builtin_amdgcn_sched_barrier(0);
+  // Both halves always run (no early exit: a straight-line body keeps the accumulators in
+  // place); a split with an odd number of tiles multiplies one tile of zeros at the end.
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * BK) {
+    // LDS buffer 0 holds tile r0; st0 = tile r0 + BK, st1 = tile r0 + 2 BK
+    multiply(0);
+    store_tile(1, st0, r0 + BK);
+    load_tile(r0 + 3 * BK, st0);
     __syncthreads();
-    buf ^= 1;
+    // LDS buffer 1 holds tile r0 + BK; st1 = tile r0 + 2 BK, st0 = tile r0 + 3 BK
+    multiply(1);
+    store_tile(0, st1, r0 + 2 * BK);
+    load_tile(r0 + 4 * BK, st1);
+    __syncthreads();
   }
 
   float* slab = slabs + (int64_t)zsplit * (I * J + J);
@@ -403,7 +439,15 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
       }
     }
   }
-  if (do_bias && tid < BN && j0 + tid < J) slab[I * J + j0 + tid] = bias_sum;
+  if (do_bias && (lane & 15) == 0) {  // every row of the ones-tile holds the same sums
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int j = (int)j0 + (wn * TN + b) * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j + e < Jn) slab[(int64_t)In * Jn + j + e] = accb[b][e];
+    }
+  }
 }
 
 // ALL tile classes of a grouped dW in one launch: the workgroups of the 128x128 class
@@ -414,7 +458,7 @@ struct DwAll {
   unsigned begin[4];  // workgroup ranges of the classes
 };
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 2)  // two workgroups per CU: <= 256 VGPRs
 tn_gemm_dw_all_kernel(DwAll all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dw_lds[];
   const unsigned hw = blockIdx.x;
