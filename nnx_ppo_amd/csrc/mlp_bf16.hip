@@ -313,29 +313,34 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
           for (int k = 0; k < K0; ++k) dst[k] = (bf16_t)0.0f;
         }
       }
-      for (int i = tid; i < ROWS * (K0p - K0); i += kThreads)
-        act0[(i / (K0p - K0)) * arow + K0 + i % (K0p - K0)] = (bf16_t)0.0f;
+      for (int row = tid >> 5; row < ROWS; row += kThreads >> 5)
+        for (int k = K0 + (tid & 31); k < K0p; k += 32) act0[row * arow + k] = (bf16_t)0.0f;
     }
   }
   if (!from_sampler) {
     // The tile's ROWS x K0 real elements are one contiguous run of the input: thread t
-    // takes elements t, t + 256, ... and ALL loads of a batch of 4 are issued before the
-    // first is used (one memory round trip for the tile instead of one per row group).
+    // takes elements t, t + 256, ... and ALL loads of a batch are issued before the first
+    // is used (one memory round trip for the tile instead of one per row group).  The
+    // row of an element comes from a float reciprocal (exact: e < 2^15, and (e + 1/2) / K0
+    // stays 1/(2 K0) away from an integer) — an integer division here is ~40 instructions
+    // per element on a kernel that is bound by instruction issue.
+    constexpr int SB = 2;  // elements per thread and batch
     const int nel = ROWS * K0;
-    for (int e0 = 0; e0 < nel; e0 += 4 * kThreads) {
-      float xv[4], av[4], mean[4], m2[4];
-      int rw[4], kk[4];
-      bool ok[4];
-      float cnt = 0.0f;
-      bool norm = false;
-      if constexpr (POLICY && !BWD) {
-        norm = px->norm_mean != nullptr;
-        if (norm) cnt = *px->norm_count;
-      }
+    const float rcpK0 = 1.0f / (float)K0;
+    float cnt = 0.0f;
+    bool norm = false;
+    if constexpr (POLICY && !BWD) {
+      norm = px->norm_mean != nullptr;
+      if (norm) cnt = *px->norm_count;
+    }
+    for (int e0 = 0; e0 < nel; e0 += SB * kThreads) {
+      float xv[SB], av[SB], mean[SB], m2[SB];
+      int rw[SB], kk[SB];
+      bool ok[SB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SB; ++u) {
         const int e = e0 + u * kThreads + tid;
-        rw[u] = e / K0;
+        rw[u] = (int)(((float)e + 0.5f) * rcpK0);
         kk[u] = e - rw[u] * K0;
         const int64_t gi = i0 + rw[u];
         ok[u] = e < nel && gi < cM;
@@ -357,7 +362,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SB; ++u) {
         float v = xv[u];
         if constexpr (POLICY && !BWD) {
           // normalizer.py:76-81,92-96 — the same fp32 expression as normalize_fwd_kernel
@@ -372,9 +377,10 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         if (e0 + u * kThreads + tid < nel) act0[rw[u] * arow + kk[u]] = (bf16_t)v;
       }
     }
-    const int padw = K0p - K0;  // zero the pad columns the first layer reduces over
-    for (int i = tid; i < ROWS * padw; i += kThreads)
-      act0[(i / padw) * arow + K0 + i % padw] = (bf16_t)0.0f;
+    // zero the pad columns the first layer reduces over (no division: 8 rows x 32 columns
+    // of threads sweep the tile)
+    for (int row = tid >> 5; row < ROWS; row += kThreads >> 5)
+      for (int k = K0 + (tid & 31); k < K0p; k += 32) act0[row * arow + k] = (bf16_t)0.0f;
   }
   warm ^= tw0 ^ tw1 ^ tw2;
   if constexpr (!BWD) {
