@@ -1,6 +1,7 @@
 """Configuration dataclasses for train_ppo — every field and default of the
 reference's `nnx_ppo/algorithms/config.py` (PPOConfig 11-30, EvalConfig 33-42,
-VideoConfig 45-57, TrainConfig 60-68, VideoData 98-105, TrainResult 108-116)."""
+VideoConfig 45-57, TrainConfig 60-68, DistillationConfig 71-84, DistillationTrainConfig
+87-95, VideoData 98-105, TrainResult 108-116, DistillationTrainResult 119-127)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -8,7 +9,7 @@ from typing import Any, Optional
 
 import numpy as np
 
-from .types import LoggingLevel, TrainingState
+from .types import DistillationState, LoggingLevel, TrainingState
 
 
 @dataclass
@@ -71,6 +72,38 @@ class VideoData:
 @dataclass
 class TrainResult:
     training_state: TrainingState
+    final_metrics: dict[str, Any]
+    eval_history: list[dict[str, Any]]
+    total_steps: int
+    total_iterations: int
+
+
+@dataclass
+class DistillationConfig:
+    n_envs: int = 256
+    rollout_length: int = 20
+    total_steps: int = 512_000
+    learning_rate: float = 1e-4
+    n_epochs: int = 4
+    n_minibatches: int = 4
+    gradient_clipping: Optional[float] = None
+    weight_decay: Optional[float] = None
+    logging_level: LoggingLevel = LoggingLevel.LOSSES
+    logging_percentiles: Optional[tuple[int, ...]] = None
+
+
+@dataclass
+class DistillationTrainConfig:
+    distillation: DistillationConfig = field(default_factory=DistillationConfig)
+    eval: EvalConfig = field(default_factory=EvalConfig)
+    video: VideoConfig = field(default_factory=VideoConfig)
+    seed: int = 17
+    checkpoint_every_steps: int = 500_000
+
+
+@dataclass
+class DistillationTrainResult:
+    training_state: DistillationState
     final_metrics: dict[str, Any]
     eval_history: list[dict[str, Any]]
     total_steps: int

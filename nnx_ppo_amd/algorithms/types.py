@@ -88,6 +88,37 @@ class Transition(TreeDataclass):
     rollout_extras: Any = None
 
 
+@dataclasses.dataclass(frozen=True)
+class DistillationTransition(TreeDataclass):
+    """types.py:85-106 — one distillation rollout: the student's outputs drive the env,
+    the teacher's `rollout_extras` (teacher in eval mode: its action mean at the sampler
+    positions) are the target."""
+
+    obs: Any
+    student_output: PPONetworkOutput
+    rewards: Any
+    done: torch.Tensor
+    truncated: torch.Tensor
+    next_obs: Any
+    metrics: dict
+    student_rollout_extras: Any = None
+    teacher_rollout_extras: Any = None
+
+
+@dataclasses.dataclass(frozen=True)
+class DistillationState(TreeDataclass):
+    """types.py:111-125.  The teacher is an external argument (like the env); only its
+    per-env carry is tracked here."""
+
+    student: Any
+    student_states: Any
+    teacher_states: Any
+    env_states: Any
+    optimizer: Any
+    rng_key: torch.Tensor
+    steps_taken: torch.Tensor
+
+
 class LoggingLevel(enum.Flag):
     """types.py:128-150."""
 
