@@ -278,6 +278,13 @@ reduce_slabs_grouped_kernel(RedTable tab, int accumulate) {
        i += (int64_t)gridDim.x * kThreads) {
     float v = 0.0f;
     int64_t s = 0;
+    for (; s + 16 <= pr.S; s += 16) {  // 16 loads in flight: S = 32..64 is 2..4 round trips
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = pr.slabs[(s + u) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += t[u];
+    }
     for (; s + 8 <= pr.S; s += 8) {
       float t[8];
 #pragma unroll

@@ -66,6 +66,10 @@ struct Chain {
   int L;
   int arow;             // LDS row length in bf16: widest (32-rounded) layer + 8
   int bias_off;         // forward: LDS byte offset of the fp32 bias rows (32-padded, zero filled)
+  // copies of layer[l].bias / layer[l].N side by side: the bias staging reads all of them
+  // at kernel start, and 8 descriptors 64 bytes apart are 8 scalar-cache lines
+  const float* bias_all[CH_MAXL];
+  int n_all[CH_MAXL];
 };
 
 // Fused policy step (mi_policy_fwd_bf16): blockIdx.y picks one of two trunks that
@@ -272,8 +276,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     const float* bl[CH_MAXL];
 #pragma unroll
     for (int l = 0; l < CH_MAXL; ++l) {
-      bl[l] = c.layer[l].bias;
-      bN[l] = c.layer[l].N;
+      bl[l] = c.bias_all[l];
+      bN[l] = c.n_all[l];
     }
 #pragma unroll
     for (int l = 0; l < CH_MAXL; ++l) {
@@ -634,7 +638,9 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     MI_TR();
     if (pass_done) {
       const bool trans = BWD ? ly.act == MI_ACT_SWISH : ly.act >= MI_ACT_TANH;
-      const bool hidden_relu = st.l != cL - 1 && (ly.N & 31) == 0 && ly.act == MI_ACT_RELU &&
+      // (also the backward's last layer: it only keeps its bf16 image for the dW launch)
+      const bool plain_out = st.l != cL - 1 || (BWD && !c_out && ly.out_bf);
+      const bool hidden_relu = plain_out && (ly.N & 31) == 0 && ly.act == MI_ACT_RELU &&
                                (!BWD || ly.aux);
       if (hidden_relu) {
         epilogue_hidden_relu(st, ly);
@@ -782,6 +788,8 @@ int fill_fwd_chain(Chain& c, const char* who, const float* x, int64_t M, int64_t
     ChainLayer& ly = c.layer[l];
     ly.w = static_cast<const bf16_t*>(wt_bf[l]);
     ly.bias = bias ? bias[l] : nullptr;
+    c.bias_all[l] = ly.bias;
+    c.n_all[l] = (int)N;
     ly.K = (int)K;
     ly.N = (int)N;
     ly.act = (int)acts[l];

@@ -100,3 +100,31 @@ def test_mock_env_is_reproducible_and_pytree_obs():
     assert set(c.obs) == {"position", "velocity"} and c.obs["velocity"].shape == (16, 9)
     d = DummyCounterEnv().reset(k)
     assert int(d.data["reset_step"].min()) >= 3 and int(d.data["reset_step"].max()) <= 9
+
+
+def test_trunk_input_row_index_by_reciprocal_is_exact():
+    """`csrc/mlp_bf16.hip` (input stage) maps flat element e of a [rows x K0] tile to its
+    row with `(int)((e + 0.5f) * (1.0f / K0))` instead of an integer division.  Host
+    restatement in IEEE fp32: exact for every K0 the kernels accept (1..512) and every
+    element of the largest tile (64 rows)."""
+    import numpy as np
+
+    for K0 in range(1, 513):
+        e = np.arange(64 * K0, dtype=np.int64)
+        rcp = np.float32(1.0) / np.float32(K0)
+        row = ((e.astype(np.float32) + np.float32(0.5)) * rcp).astype(np.int32)
+        assert np.array_equal(row, (e // K0).astype(np.int32)), K0
+
+
+def test_distillation_config_defaults_match_the_reference():
+    """config.py:71-95 of the reference: every field and default."""
+    from nnx_ppo_amd.algorithms.config import DistillationConfig, DistillationTrainConfig
+    from nnx_ppo_amd.algorithms.types import LoggingLevel
+
+    d = DistillationConfig()
+    assert (d.n_envs, d.rollout_length, d.total_steps, d.learning_rate, d.n_epochs,
+            d.n_minibatches, d.gradient_clipping, d.weight_decay, d.logging_level,
+            d.logging_percentiles) == (256, 20, 512_000, 1e-4, 4, 4, None, None,
+                                       LoggingLevel.LOSSES, None)
+    t = DistillationTrainConfig()
+    assert t.seed == 17 and t.checkpoint_every_steps == 500_000 and t.eval.enabled
