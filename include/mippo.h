@@ -479,6 +479,23 @@ int mi_episode_step(const int64_t* counter, const void* inner_done, int done_is_
                     uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out, int64_t n,
                     mi_stream_t stream);
 
+/* EpisodeWrapper.step (`nnx_ppo/wrappers/episode_wrapper.py:12-22`) AND the rollout's
+ * reset-on-done select of the env state (`rollout.py:41-44`, `tree_where` 270-279) in one
+ * launch.  The first nine arguments are `mi_episode_step`'s; mask[b] = done flag of row b.
+ * The three leaves the wrapper itself produces are selected against their reset values
+ * (`*_sel[b] = mask[b] ? reset_*[b] : *_out[b]`), every other leaf l < n_leaves (<= 16) as
+ * `mi_select_rows_multi` does.  B rows. */
+int mi_episode_step_select(const int64_t* counter, const void* inner_done, int done_is_float,
+                           const uint8_t* inner_truncated, int64_t max_len,
+                           int64_t* counter_out, uint8_t* truncated_out, float* done_out,
+                           uint8_t* done_flag_out, const int64_t* reset_counter,
+                           const uint8_t* reset_truncated, const float* reset_done,
+                           int64_t* counter_sel, uint8_t* truncated_sel, float* done_sel,
+                           const void* const* on_true, const int64_t* true_row_stride_bytes,
+                           const void* const* on_false, void* const* out,
+                           const int64_t* row_bytes, int64_t n_leaves, int64_t B,
+                           mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,15 +15,19 @@ from ..tree import tree_all, tree_map
 from .types import Transition
 
 
-def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
-    """rollout.py:270-279 — per leaf `where(cond[:, None...], x, y)`; leaves whose
-    leading dim is not the batch are taken from `on_true` unchanged (the
-    reference's shared-field rule, 272-275).  One byte-exact select kernel per
-    leaf (`mi_select_rows`)."""
-    B = cond.shape[0]
+def collect_pairs(B: int, on_true: Any, on_false: Any, special=None):
+    """The leaf walk of `tree_where`: returns (pairs, skeleton).  `pairs[i]` = the
+    contiguous (on_true, on_false) tensors of a leaf that is selected per row; the
+    skeleton holds `_Slot(i)` there, the `on_true` leaf where the reference's shared-field
+    rule applies (rollout.py:272-275), and — `special(x, y)` returning not-None — whatever
+    that callback returns (leaves a fused kernel produces itself)."""
     pairs: list = []
 
     def collect(x, y):
+        if special is not None:
+            s = special(x, y)
+            if s is not None:
+                return s
         if not isinstance(x, torch.Tensor) or x.dim() == 0 or x.shape[0] != B:
             return x
         if not isinstance(y, torch.Tensor):
@@ -36,9 +40,27 @@ def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
         pairs.append((x.contiguous(), y.contiguous()))
         return _Slot(len(pairs) - 1)
 
-    skeleton = tree_map(collect, on_true, on_false)
-    outs = ops.select_rows_multi(cond, pairs)
-    return tree_map(lambda v: outs[v.i] if isinstance(v, _Slot) else v, skeleton)
+    return pairs, tree_map(collect, on_true, on_false)
+
+
+def fill_slots(skeleton: Any, outs: list, special=None) -> Any:
+    def put(v):
+        if isinstance(v, _Slot):
+            return outs[v.i]
+        if special is not None:
+            return special(v)
+        return v
+
+    return tree_map(put, skeleton)
+
+
+def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
+    """rollout.py:270-279 — per leaf `where(cond[:, None...], x, y)`; leaves whose
+    leading dim is not the batch are taken from `on_true` unchanged (the
+    reference's shared-field rule, 272-275).  One byte-exact select launch for all
+    leaves (`mi_select_rows_multi`)."""
+    pairs, skeleton = collect_pairs(cond.shape[0], on_true, on_false)
+    return fill_slots(skeleton, ops.select_rows_multi(cond, pairs))
 
 
 class _Slot:
@@ -61,7 +83,15 @@ def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_res
     out = networks(network_state, env_state.obs)
     next_network_state = out.next_state
     ppo_output = out.output
-    next_env_state = env.step(env_state, ppo_output.actions)
+    # an env that can step AND apply the reset-on-done select in one launch
+    # (wrappers/episode_wrapper.py) hands back both states
+    reset_env_state = None
+    step_and_reset = getattr(env, "step_and_reset", None) if reset_states is not None else None
+    if step_and_reset is not None:
+        next_env_state, reset_env_state = step_and_reset(env_state, ppo_output.actions,
+                                                         reset_states)
+    else:
+        next_env_state = env.step(env_state, ppo_output.actions)
     done = _as_bool(next_env_state.done)
     trunc = next_env_state.info.get("truncated", None)
     trunc = torch.zeros_like(done) if trunc is None else _as_bool(trunc)
@@ -75,9 +105,12 @@ def single_transition(env, networks: StatefulModule, carry, rng_keys_for_env_res
         metrics={"env": next_env_state.metrics, "net": out.metrics},
         rollout_extras=out.rollout_extras,
     )
-    if reset_states is None:
-        reset_states = env.reset(rng_keys_for_env_reset)
-    next_env_state = tree_where(done, reset_states, next_env_state)
+    if reset_env_state is not None:
+        next_env_state = reset_env_state
+    else:
+        if reset_states is None:
+            reset_states = env.reset(rng_keys_for_env_reset)
+        next_env_state = tree_where(done, reset_states, next_env_state)
     reset_network_states = networks.reset_state(next_network_state)
     next_network_state = tree_where(done, reset_network_states, next_network_state)
     return (next_network_state, next_env_state), transition

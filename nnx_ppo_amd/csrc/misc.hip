@@ -75,6 +75,75 @@ select_rows_multi_kernel(const uint8_t* __restrict__ mask, SelectTable tab, int6
   }
 }
 
+// EpisodeWrapper.step + the reset-on-done select of every env-state leaf in ONE launch
+// (a rollout step is five launches of 2-10 us; this removes one of them).  The done flag
+// of a row is recomputed from the wrapper's three inputs wherever it is needed, so no
+// block waits for another.  blockIdx.y == n_leaves: the wrapper's own outputs and the
+// three leaves it produces; blockIdx.y < n_leaves: one generic leaf each.
+struct EpisodeArgs {
+  const int64_t* counter;
+  const void* inner_done;
+  const uint8_t* inner_trunc;
+  int64_t max_len;
+  int done_is_float;
+  int64_t* counter_out;
+  uint8_t* trunc_out;
+  float* done_out;
+  uint8_t* flag_out;
+  const int64_t* reset_counter;
+  const uint8_t* reset_trunc;
+  const float* reset_done;
+  int64_t* counter_sel;
+  uint8_t* trunc_sel;
+  float* done_sel;
+};
+
+__device__ inline void episode_row(const EpisodeArgs& e, int64_t b, int64_t& c, bool& t, bool& m) {
+  c = e.counter[b] + 1;
+  const bool d = e.done_is_float ? static_cast<const float*>(e.inner_done)[b] != 0.0f
+                                 : static_cast<const uint8_t*>(e.inner_done)[b] != 0;
+  t = (e.inner_trunc ? e.inner_trunc[b] != 0 : false) || c >= e.max_len;
+  m = d || t;
+}
+
+__global__ void __launch_bounds__(kThreads)
+episode_select_kernel(EpisodeArgs e, SelectTable tab, int n_leaves, int64_t B) {
+  if ((int)blockIdx.y == n_leaves) {
+    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B;
+         b += (int64_t)gridDim.x * kThreads) {
+      int64_t c;
+      bool t, m;
+      episode_row(e, b, c, t, m);
+      e.counter_out[b] = c;
+      e.trunc_out[b] = t ? 1 : 0;
+      e.done_out[b] = m ? 1.0f : 0.0f;
+      if (e.flag_out) e.flag_out[b] = m ? 1 : 0;
+      e.counter_sel[b] = m ? e.reset_counter[b] : c;
+      e.trunc_sel[b] = m ? e.reset_trunc[b] : (uint8_t)(t ? 1 : 0);
+      e.done_sel[b] = m ? e.reset_done[b] : 0.0f;
+    }
+    return;
+  }
+  const SelectLeaf lf = tab.leaf[blockIdx.y];
+  const int64_t total = B * lf.words;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t b = i / lf.words, w = i % lf.words;
+    int64_t c;
+    bool t, m;
+    episode_row(e, b, c, t, m);
+    if (lf.word_bytes == 4) {
+      const uint32_t* tt = static_cast<const uint32_t*>(lf.on_true);
+      const uint32_t* ff = static_cast<const uint32_t*>(lf.on_false);
+      static_cast<uint32_t*>(lf.out)[i] = m ? tt[b * lf.true_stride + w] : ff[i];
+    } else {
+      const uint8_t* tt = static_cast<const uint8_t*>(lf.on_true);
+      const uint8_t* ff = static_cast<const uint8_t*>(lf.on_false);
+      static_cast<uint8_t*>(lf.out)[i] = m ? tt[b * lf.true_stride + w] : ff[i];
+    }
+  }
+}
+
 // Several contiguous buffers copied in one launch (blockIdx.y = buffer): the state
 // hand-over at the end of a captured iteration is ~10 small tensors, and one
 // launch per tensor costs more than the bytes do.
@@ -266,4 +335,48 @@ extern "C" int mi_copy_multi(const void* const* src, void* const* dst, const int
   dim3 grid((unsigned)stream_grid(max_words), (unsigned)n_leaves);
   hipLaunchKernelGGL(copy_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream), tab);
   return mippo::check_launch("mi_copy_multi");
+}
+
+extern "C" int mi_episode_step_select(
+    const int64_t* counter, const void* inner_done, int done_is_float,
+    const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
+    uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out,
+    const int64_t* reset_counter, const uint8_t* reset_truncated, const float* reset_done,
+    int64_t* counter_sel, uint8_t* truncated_sel, float* done_sel, const void* const* on_true,
+    const int64_t* true_row_stride_bytes, const void* const* on_false, void* const* out,
+    const int64_t* row_bytes, int64_t n_leaves, int64_t B, mi_stream_t stream) {
+  MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves && B >= 0,
+             "mi_episode_step_select: 0 <= n_leaves <= %d", kMaxSelectLeaves);
+  if (B == 0) return 0;
+  MI_REQUIRE(counter && inner_done && counter_out && truncated_out && done_out &&
+                 reset_counter && reset_truncated && reset_done && counter_sel &&
+                 truncated_sel && done_sel,
+             "mi_episode_step_select: null pointer");
+  MI_REQUIRE(n_leaves == 0 || (on_true && on_false && out && row_bytes && true_row_stride_bytes),
+             "mi_episode_step_select: null leaf table");
+  EpisodeArgs e = {counter,       inner_done,    inner_truncated, max_len,       done_is_float,
+                   counter_out,   truncated_out, done_out,        done_flag_out, reset_counter,
+                   reset_truncated, reset_done,  counter_sel,     truncated_sel, done_sel};
+  SelectTable tab = {};
+  int64_t max_words = 1;
+  for (int64_t l = 0; l < n_leaves; ++l) {
+    MI_REQUIRE(on_true[l] && on_false[l] && out[l] && row_bytes[l] >= 1,
+               "mi_episode_step_select: bad leaf %lld", (long long)l);
+    MI_REQUIRE(true_row_stride_bytes[l] == 0 || true_row_stride_bytes[l] == row_bytes[l],
+               "mi_episode_step_select: on_true stride must be 0 or row_bytes");
+    const bool w4 = row_bytes[l] % 4 == 0 && aligned4(on_true[l]) && aligned4(on_false[l]) &&
+                    aligned4(out[l]);
+    SelectLeaf& lf = tab.leaf[l];
+    lf.on_true = on_true[l];
+    lf.on_false = on_false[l];
+    lf.out = out[l];
+    lf.word_bytes = w4 ? 4 : 1;
+    lf.words = row_bytes[l] / lf.word_bytes;
+    lf.true_stride = true_row_stride_bytes[l] / lf.word_bytes;
+    if (lf.words > max_words) max_words = lf.words;
+  }
+  dim3 grid((unsigned)stream_grid(B * max_words), (unsigned)n_leaves + 1);
+  hipLaunchKernelGGL(episode_select_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream), e,
+                     tab, (int)n_leaves, B);
+  return mippo::check_launch("mi_episode_step_select");
 }

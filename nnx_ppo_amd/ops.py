@@ -861,6 +861,61 @@ def episode_step(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc, m
     return c_out, t_out, d_out, f_out
 
 
+def episode_step_select(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc,
+                        max_len: int, reset_counter: torch.Tensor, reset_trunc: torch.Tensor,
+                        reset_done: torch.Tensor, pairs: list):
+    """`episode_step` and the reset-on-done select of every (on_true, on_false) leaf of
+    `pairs` (<= 16) in ONE launch (`mi_episode_step_select`).  Returns
+    (counter', truncated, done, done flag, selected counter / truncated / done, outs)."""
+    B = counter.numel()
+    _need(counter.dtype == i64 and counter.dim() == 1 and inner_done.numel() == B,
+          "episode_step_select: shapes")
+    _need(reset_counter.dtype == i64 and reset_trunc.dtype == torch.bool
+          and reset_done.dtype == f32 and reset_counter.shape == counter.shape
+          and reset_trunc.shape == counter.shape and reset_done.shape == counter.shape,
+          "episode_step_select: reset leaves must be int64 / bool / float32 [B]")
+    _need(len(pairs) <= 16, "episode_step_select: at most 16 leaves")
+    is_float = inner_done.dtype == f32
+    d_in = inner_done if is_float else _as_u8(inner_done)
+    t_in = None if inner_trunc is None else _as_u8(inner_trunc)
+    dev = counter.device
+    mk = lambda dt: torch.empty(counter.shape, dtype=dt, device=dev)
+    c_out, c_sel = mk(i64), mk(i64)
+    t_out, t_sel, f_out = mk(torch.bool), mk(torch.bool), mk(torch.bool)
+    d_out, d_sel = mk(f32), mk(f32)
+    v = lambda t: t.view(torch.uint8) if t.dtype == torch.bool else t
+    outs, tab = [], []
+    for on_true, on_false in pairs:
+        _need(on_false.shape[0] == B and on_true.dtype == on_false.dtype
+              and on_true.is_contiguous() and on_false.is_contiguous(),
+              "episode_step_select: leaf layout")
+        row_bytes = on_false.element_size()
+        for dd in on_false.shape[1:]:
+            row_bytes *= dd
+        if on_true.shape == on_false.shape:
+            stride = row_bytes
+        elif on_true.shape == on_false.shape[1:]:
+            stride = 0
+        else:
+            raise MippoError("episode_step_select: on_true must match on_false or be one row")
+        out = torch.empty_like(on_false)
+        outs.append(out)
+        if row_bytes:
+            tab.append((ptr(v(on_true)), stride, ptr(v(on_false)), ptr(v(out)), row_bytes))
+    n = len(tab)
+    P = ctypes.c_void_p * max(n, 1)
+    L = ctypes.c_int64 * max(n, 1)
+    col = lambda k: [r[k] for r in tab] or [None if k in (0, 2, 3) else 0]
+    check(lib().mi_episode_step_select(
+        ptr(counter, i64), ptr(d_in), int(is_float), ptr(t_in), int(max_len), ptr(c_out, i64),
+        ptr(t_out.view(torch.uint8)), ptr(d_out, f32), ptr(f_out.view(torch.uint8)),
+        ptr(reset_counter, i64), ptr(reset_trunc.view(torch.uint8)), ptr(reset_done, f32),
+        ptr(c_sel, i64), ptr(t_sel.view(torch.uint8)), ptr(d_sel, f32),
+        P(*col(0)), L(*col(1)), P(*col(2)), P(*col(3)), L(*col(4)), n, B, stream()),
+        "mi_episode_step_select")
+    return c_out, t_out, d_out, f_out, c_sel, t_sel, d_sel, outs
+
+
 # ------------------------------------------------------------- a20: GRU
 def gru_mfma_ok(H: int) -> bool:
     """Hidden sizes the matrix-core GRU kernels take (csrc/gru_mfma.hip)."""

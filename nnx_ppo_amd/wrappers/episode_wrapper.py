@@ -10,6 +10,19 @@ from .. import random as rnd
 from ..envs.constants import cast_constant, constant, is_constant
 
 
+class _Produced:
+    """Marks a state leaf that `step` itself produces (fused step + reset select)."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __repr__(self):
+        return f"<{self.name}>"
+
+
+_COUNTER, _TRUNC, _DONE = _Produced("step_counter"), _Produced("truncated"), _Produced("done")
+
+
 class EpisodeWrapper:
     def __init__(self, env, max_len: int):
         self.env = env
@@ -36,6 +49,58 @@ class EpisodeWrapper:
         next_state.info["truncated"] = truncated
         done = torch.logical_or(next_state.done.to(torch.bool), truncated)
         return next_state.replace(done=done.to(torch.float32))
+
+    def step_and_reset(self, state, action, reset_states):
+        """`step` followed by the rollout's `tree_where(done, reset_states, stepped)`
+        (rollout.py:41-44) — on the GPU both in ONE launch (`mi_episode_step_select`).
+        Returns (stepped state, state after the reset select); the second is None when
+        the fused launch does not apply and the caller selects itself."""
+        counter = state.info["step_counter"]
+        r_info = getattr(reset_states, "info", None) or {}
+        rc, rt, rd = r_info.get("step_counter"), r_info.get("truncated"), reset_states.done
+        ok = (counter.is_cuda and counter.dim() == 1
+              and all(isinstance(x, torch.Tensor) and x.shape == counter.shape
+                      and x.is_contiguous() for x in (rc, rt, rd))
+              and rc.dtype == torch.int64 and rt.dtype == torch.bool
+              and rd.dtype == torch.float32)
+        if not ok:
+            return self.step(state, action), None
+        from .. import ops
+        from ..algorithms.rollout import collect_pairs, fill_slots
+
+        inner = self.env.step(state, action)
+        prev = inner.info.get("truncated", None)
+        prev = prev if isinstance(prev, torch.Tensor) else None
+        marked_info = dict(inner.info)
+        marked_info["step_counter"] = _COUNTER
+        marked_info["truncated"] = _TRUNC
+        marked = inner.replace(done=_DONE, info=marked_info)
+        pairs, skeleton = collect_pairs(
+            counter.shape[0], reset_states, marked,
+            special=lambda x, y: y if isinstance(y, _Produced) else None)
+        if len(pairs) > 16:
+            return self._finish_step(inner, state, prev), None
+        c, t, d, flag, c_sel, t_sel, d_sel, outs = ops.episode_step_select(
+            counter, inner.done, prev, self.max_len, rc, rt, rd, pairs)
+        d.done_flag = flag
+        info = dict(inner.info)
+        info["step_counter"] = c
+        info["truncated"] = t
+        stepped = inner.replace(done=d, info=info)
+        sel = {_COUNTER: c_sel, _TRUNC: t_sel, _DONE: d_sel}
+        after = fill_slots(skeleton, outs,
+                           special=lambda v: sel[v] if isinstance(v, _Produced) else v)
+        return stepped, after
+
+    def _finish_step(self, next_state, state, prev):
+        from .. import ops
+
+        c, t, d, flag = ops.episode_step(state.info["step_counter"], next_state.done, prev,
+                                         self.max_len)
+        d.done_flag = flag
+        next_state.info["step_counter"] = c
+        next_state.info["truncated"] = t
+        return next_state.replace(done=d)
 
     def reset(self, rng: torch.Tensor):
         base_rng, step_counter_rng = rnd.split2(rng)

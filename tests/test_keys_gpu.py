@@ -162,3 +162,34 @@ def test_key_permutations_match_the_host_scheme(dev, n):
     for e in range(4):
         assert torch.equal(want[e], rnd.permutation(rnd.fold_in(k, e), n))
         assert torch.equal(torch.sort(got[e].cpu()).values, torch.arange(n))
+
+
+@pytest.mark.parametrize("B", [1, 257, 4096])
+def test_episode_step_select_equals_step_then_select(dev, B):
+    """`mi_episode_step_select` == `mi_episode_step` followed by `mi_select_rows_multi` on
+    the done flag, bit for bit: the wrapper's own leaves and generic leaves of 1-, 4- and
+    20-byte rows (episode_wrapper.py:12-22, rollout.py:41-44)."""
+    from nnx_ppo_amd import ops
+
+    g = torch.Generator().manual_seed(B)
+    counter = torch.randint(0, 12, (B,), generator=g).to(dev)
+    inner_done = (torch.rand(B, generator=g) < 0.2).to(dev)
+    inner_trunc = (torch.rand(B, generator=g) < 0.1).to(dev)
+    rc = torch.randint(0, 5, (B,), generator=g).to(dev)
+    rt = torch.zeros(B, dtype=torch.bool, device=dev)
+    rd = torch.zeros(B, dtype=torch.float32, device=dev)
+    leaves = [(torch.randn(B, 5, generator=g).to(dev), torch.randn(B, 5, generator=g).to(dev)),
+              (torch.randn(B, generator=g).to(dev), torch.randn(B, generator=g).to(dev)),
+              ((torch.rand(B, generator=g) < 0.5).to(dev), (torch.rand(B, generator=g) < 0.5).to(dev)),
+              (torch.randint(0, 99, (B,), generator=g).to(dev),
+               torch.randint(0, 99, (B,), generator=g).to(dev))]
+    for trunc in (inner_trunc, None):
+        for done_in in (inner_done, inner_done.float()):
+            c0, t0, d0, f0 = ops.episode_step(counter, done_in, trunc, 10)
+            want = ops.select_rows_multi(f0, leaves + [(rc, c0), (rt, t0), (rd, d0)])
+            c, t, d, f, cs, ts, ds, outs = ops.episode_step_select(counter, done_in, trunc, 10,
+                                                                   rc, rt, rd, leaves)
+            for a, b in zip((c, t, d, f), (c0, t0, d0, f0)):
+                assert a.dtype == b.dtype and torch.equal(a, b)
+            for a, b in zip(outs + [cs, ts, ds], want):
+                assert a.dtype == b.dtype and torch.equal(a, b)
