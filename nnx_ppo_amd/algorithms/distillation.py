@@ -41,7 +41,13 @@ def distillation_single_transition(env, teacher: StatefulModule, student: Statef
     student_out = student(student_state, env_state.obs)
     teacher_out = teacher(teacher_state, env_state.obs)
     student_output = student_out.output
-    next_env_state = env.step(env_state, student_output.actions)
+    reset_env_state = None
+    step_and_reset = getattr(env, "step_and_reset", None) if reset_states is not None else None
+    if step_and_reset is not None:  # step + reset-on-done select in one launch
+        next_env_state, reset_env_state = step_and_reset(env_state, student_output.actions,
+                                                         reset_states)
+    else:
+        next_env_state = env.step(env_state, student_output.actions)
     done = _as_bool(next_env_state.done)
     trunc = next_env_state.info.get("truncated", None)
     trunc = torch.zeros_like(done) if trunc is None else _as_bool(trunc)
@@ -56,9 +62,12 @@ def distillation_single_transition(env, teacher: StatefulModule, student: Statef
         student_rollout_extras=student_out.rollout_extras,
         teacher_rollout_extras=teacher_out.rollout_extras,
     )
-    if reset_states is None:
-        reset_states = env.reset(rng_keys_for_env_reset)
-    next_env_state = tree_where(done, reset_states, next_env_state)
+    if reset_env_state is not None:
+        next_env_state = reset_env_state
+    else:
+        if reset_states is None:
+            reset_states = env.reset(rng_keys_for_env_reset)
+        next_env_state = tree_where(done, reset_states, next_env_state)
     next_student_state = tree_where(done, student.reset_state(student_out.next_state),
                                     student_out.next_state)
     next_teacher_state = tree_where(done, teacher.reset_state(teacher_out.next_state),

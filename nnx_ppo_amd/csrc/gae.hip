@@ -141,9 +141,18 @@ extern "C" int mi_gae_stats_f32(const float* rewards, const float* values,
   const int block = 64;
   const int64_t grid = mippo::ceil_div(N, block);
   MI_REQUIRE(grid <= 0x7fffffffLL, "mi_gae_stats_f32: N=%lld too large", (long long)N);
-  hipLaunchKernelGGL((gae_kernel<8, true>), dim3((unsigned)grid), dim3(block), 0,
-                     mippo::as_stream(stream), rewards, values, last_value, done,
-                     truncated, advantages, targets, T, N, gamma, lambda, adv_stats,
-                     workspace);
+  if (N <= 16384 && T <= 32) {
+    // latency-bound size (a minibatch: 16 workgroups): request every row of the scan up
+    // front — one memory round trip instead of T/8 — at 32 rows of registers per thread
+    hipLaunchKernelGGL((gae_kernel<32, true>), dim3((unsigned)grid), dim3(block), 0,
+                       mippo::as_stream(stream), rewards, values, last_value, done,
+                       truncated, advantages, targets, T, N, gamma, lambda, adv_stats,
+                       workspace);
+  } else {
+    hipLaunchKernelGGL((gae_kernel<8, true>), dim3((unsigned)grid), dim3(block), 0,
+                       mippo::as_stream(stream), rewards, values, last_value, done,
+                       truncated, advantages, targets, T, N, gamma, lambda, adv_stats,
+                       workspace);
+  }
   return mippo::check_launch("mi_gae_stats_f32");
 }

@@ -100,7 +100,6 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
                 float clip, float critic_weight, float* __restrict__ g_ll,
                 float* __restrict__ g_v, void* __restrict__ ws,
                 float* __restrict__ loss_out, int64_t n) {
-  __shared__ double scratch[kThreads / 64];
   unsigned int* counter = static_cast<unsigned int*>(ws);
   double* partials = reinterpret_cast<double*>(static_cast<char*>(ws) + kTicketBytes);
   float mean = 0.0f, denom = 1.0f;
@@ -139,10 +138,27 @@ ppo_loss_kernel(const float* __restrict__ ll_new, const float* __restrict__ ll_o
     }
     if (reg) s_reg += (double)reg[i];
   }
-  const double t0 = block_sum(s_act, scratch);
-  const double t1 = block_sum(s_crit, scratch);
-  const double t2 = block_sum(s_reg, scratch);
-  const double t3 = block_sum(s_clip, scratch);
+  // the four sums share one pair of barriers (same wave order as `block_sum`)
+  __shared__ double scratch4[4][kThreads / 64];
+  double q[4] = {s_act, s_crit, s_reg, s_clip};
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] += __shfl_down(q[k], off, 64);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) scratch4[k][threadIdx.x >> 6] = q[k];
+  }
+  __syncthreads();
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < kThreads / 64; ++w) {
+      t0 += scratch4[0][w];
+      t1 += scratch4[1][w];
+      t2 += scratch4[2][w];
+      t3 += scratch4[3][w];
+    }
+  }
   if (threadIdx.x == 0) {
     double* p = partials + 4 * blockIdx.x;
     p[0] = t0;
