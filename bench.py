@@ -166,7 +166,7 @@ def roofline_of_dominant_kernel(env, ts):
                 add(f"{kern}<{1 if M <= 8192 else 4}>", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
-                add("dW group (tn_gemm_dw_kernel x tile classes + reduce_slabs_grouped)",
+                add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",
                     t_ms, work)
         if name in GEMM_SYMBOLS:
             if GEMM_SYMBOLS[name] is None:

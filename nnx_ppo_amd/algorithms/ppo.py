@@ -347,7 +347,8 @@ def ppo_loss(
                                                rollout_data.rollout_extras, last_obs)
     if fused is not None:
         ctx, out, reg_seq, final_state, last_values = fused
-    elif stateless and _can_fork(last_obs):
+    elif stateless and _can_fork(last_obs, any(getattr(m, "_wide", False)
+                                               for m in networks.modules())):
         # no carry: the bootstrap forward does not depend on the replay's final
         # state, so it runs beside the replay on the second stream (it is a 1/T-size
         # launch that would otherwise sit alone on the critical path)

@@ -222,7 +222,7 @@ class MLPActorCritic(Sequential):
         g_ms = sampler.replay_backward(s_ctx, {"action": None,
                                                "log_likelihood": g_out.loglikelihoods}, g_reg)
         g_ms = g_ms.reshape(M, g_ms.shape[-1])
-        if _can_fork(g_v):
+        if _can_fork(g_v, getattr(self.layers[-1], "_wide", True)):
             fork = _Fork(g_v)
             with fork:
                 dense_chain.backward(c_layers, v_ctx, g_v)
