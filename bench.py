@@ -161,9 +161,14 @@ def roofline_of_dominant_kernel(env, ts):
                 add(f"mlp_chain_kernel<{1 if M <= 8192 else 4}, {bwd}>", t_ms, work)
         if name in ("mi_policy_fwd_bf16", "mi_policy_bwd_bf16"):
             kern = "policy_kernel" if name == "mi_policy_fwd_bf16" else "policy_bwd_kernel"
+            # the instantiation csrc/mlp_bf16.hip picks: <RT, NB> of the action trunk, then of
+            # the value trunk — 16 rows x 4 column tiles per wave at rollout sizes; at training
+            # sizes 64 x 4, and 256 x 1 for a trunk no wider than 64
+            narrow = max(ACTOR_H) <= 64 and os.environ.get("MIPPO_NARROW_TRUNK", "1")[:1] != "0"
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 M = ints[0] if name == "mi_policy_fwd_bf16" else ints[1]  # (offset_add, M, ..)
-                add(f"{kern}<{1 if M <= 8192 else 4}>", t_ms, work)
+                shape = "1, 4, 1, 4" if M <= 8192 else ("16, 1, 4, 4" if narrow else "4, 4, 4, 4")
+                add(f"{kern}<{shape}>", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",

@@ -95,13 +95,13 @@ struct IStep {
 };
 
 // Kp: the layer's reduce width rounded up to 32, N: its output width, kstep: reduce
-// elements per step
-__device__ inline IStep istep_next(int Kp, int N, int kstep, IStep s) {
+// elements per step, pass_cols: output columns of a column pass (64 per fragment slot)
+__device__ inline IStep istep_next(int Kp, int N, int kstep, int pass_cols, IStep s) {
   s.kc += kstep;
   if (s.kc >= Kp) {
     s.kc = 0;
     s.p += 1;
-    if (s.p * 256 >= N) {
+    if (s.p * pass_cols >= N) {
       s.p = 0;
       s.l += 1;
     }
@@ -141,11 +141,17 @@ __device__ unsigned long long g_trace[TR_WG * TR_EV];
 #define MI_TR_END() do {} while (0)
 #endif
 
+template <int NB>
 struct BFrags {
-  bf16x8 f[IF_KS][4];  // [k-step][column tile]
+  bf16x8 f[IF_KS][NB];  // [k-step][column tile]
 };
 
-template <int RT, bool BWD, bool POLICY>
+// NB = column tiles (fragment slots) per wave and pass.  NB = 4: a pass covers 256 columns
+// (the general form).  NB = 1 with RT = 16: a pass covers 64 columns and the workgroup owns
+// 256 rows — for trunks no wider than 64, where a wave has ONE column tile anyway and
+// three of four slots idled: the same accumulator and operand registers hold 4x the rows,
+// so a quarter of the workgroups pay the per-workgroup latency chain.
+template <int RT, bool BWD, bool POLICY, int NB = 4>
 __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px) {
   constexpr int ROWS = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -186,12 +192,14 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   // A layer with ONE column tile (N <= 16: value heads, the backward's first layer) runs
   // "deep": the 8 fragment slots of a step hold 8 consecutive k-steps of that tile, so
   // K = 256 is one step instead of four (same accumulation order, same sums).
-  auto load_frags = [&](const IStep& s, const bf16_t* w, unsigned KS, unsigned NT, BFrags& B) {
+  auto load_frags = [&](const IStep& s, const bf16_t* w, unsigned KS, unsigned NT,
+                        BFrags<NB>& B) {
     const char* const wb = reinterpret_cast<const char*>(w) + lane * 16;
-    const unsigned bstride = (!BWD && NT == 1) ? IF_KS : 0;  // deep: slot (ks, b) = k-step b*IF_KS + ks
+    // deep: slot (ks, b) = k-step b*IF_KS + ks
+    const unsigned bstride = (!BWD && NB == 4 && NT == 1) ? IF_KS : 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      unsigned ct = ((unsigned)s.p * 4 + b) * 4 + wave;
+    for (int b = 0; b < NB; ++b) {
+      unsigned ct = ((unsigned)s.p * NB + b) * 4 + wave;
       ct = ct < NT ? ct : NT - 1;
       const unsigned base = ct * KS;
 #pragma unroll
@@ -237,7 +245,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   ChainLayer Lc = c.layer[0];
   ChainLayer Ln = c.layer[cL > 1 ? 1 : 0];
   IStep s = {0, 0, 0};
-  BFrags B, Bn;
+  BFrags<NB> B, Bn;
   unsigned KSc = (unsigned)(Lc.K + 31) >> 5, NTc = (unsigned)(Lc.N + 15) >> 4;
   unsigned KSn = (unsigned)(Ln.K + 31) >> 5, NTn = (unsigned)(Ln.N + 15) >> 4;
   load_frags(s, Lc.w, KSc, NTc, B);
@@ -418,8 +426,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     ms_base = reinterpret_cast<float*>(lds_raw + px->ms_off);
   }
   int boff_c = 0;     // offset of the current layer's bias row in the LDS bias area
-  f32x4 acc[RT][4];   // acc[r][b][e]: row r*16 + li, column tile b, column 4*lq + e
-  s16x4 auxr[RT][4];  // backward: the act' operands of the same elements
+  f32x4 acc[RT][NB];  // acc[r][b][e]: row r*16 + li, column tile b, column 4*lq + e
+  s16x4 auxr[RT][NB]; // backward: the act' operands of the same elements
   // Unrolled epilogue of one column pass.  TRANS selects, at compile time, the
   // variant with transcendentals (tanh / swish) so that the common relu / none
   // variant stays a handful of VALU ops per element; the kernel keeps exactly ONE
@@ -444,8 +452,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     const int Np = (ly.N + 31) / 32 * 32;  // the next layer reduces over Np columns
     const int relu = ly.act == MI_ACT_RELU;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int ct = (st.p * 4 + b) * 4 + wave;  // scalar: the tests on it are uniform
+    for (int b = 0; b < NB; ++b) {
+      const int ct = (st.p * NB + b) * 4 + wave;  // scalar: the tests on it are uniform
       if (ct * 16 >= Np) continue;
       const int j0 = ct * 16 + 4 * lq;
       const bool full = ct * 16 + 16 <= ly.N;    // no pad column in this tile
@@ -524,8 +532,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
   auto epilogue_hidden_relu = [&](const IStep& st, const ChainLayer& ly) {
     bf16_t* const wbase = ((st.l & 1) ? act0 : act1) + li * arow + 4 * lq;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int ct = (st.p * 4 + b) * 4 + wave;
+    for (int b = 0; b < NB; ++b) {
+      const int ct = (st.p * NB + b) * 4 + wave;
       if (ct * 16 >= ly.N) continue;
       f32x4 bj = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (!BWD) bj = *reinterpret_cast<const f32x4*>(bias_s + boff_c + ct * 16 + 4 * lq);
@@ -553,10 +561,10 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     const ChainLayer& ly = Lc;
     const int Kp = (int)KSc * 32;
     const bf16_t* const cbuf = (st.l & 1) ? act1 : act0;
-    const bool deep = !BWD && NTc == 1;  // (the backward's single-tile layers have K <= 64)
+    const bool deep = !BWD && NB == 4 && NTc == 1;  // (the backward's single-tile layers have K <= 64)
     const int kstep = deep ? 4 * IF_KC : IF_KC;
     const bool pass_done = st.kc + kstep >= Kp;  // this step completes the wave's columns
-    const IStep sn = istep_next(Kp, ly.N, kstep, st);
+    const IStep sn = istep_next(Kp, ly.N, kstep, NB * 64, st);
     {
       // next step's fragments; the last step re-reads its own (never used) so that the
       // loads of a step stay unconditional
@@ -570,8 +578,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
         // act' operands of this pass: 8 bytes per (row, column tile), in flight
         // during the MFMAs below
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int j0 = ((st.p * 4 + b) * 4 + wave) * 16 + 4 * lq;
+        for (int b = 0; b < NB; ++b) {
+          const int j0 = ((st.p * NB + b) * 4 + wave) * 16 + 4 * lq;
 #pragma unroll
           for (int r = 0; r < RT; ++r) {
             const int64_t gi = i0 + r * 16 + li;
@@ -587,12 +595,12 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (deep) {
       if (wave == 0) {  // the layer's only column tile
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int ks = 0; ks < IF_KS; ++ks) {
             const int ko = st.kc + (b * IF_KS + ks) * 32;
@@ -619,8 +627,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
             af[r] = *reinterpret_cast<const bf16x8*>(cbuf + (r * 16 + li) * arow + st.kc +
                                                      ks * 32 + 8 * lq);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            if (((st.p * 4 + b) * 4 + wave) * 16 < ly.N) {
+          for (int b = 0; b < NB; ++b) {
+            if (((st.p * NB + b) * 4 + wave) * 16 < ly.N) {
 #pragma unroll
               for (int r = 0; r < RT; ++r)  // transposed tile: weights are the A operand
                 acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B.f[ks][b], af[r],
@@ -662,7 +670,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
 #pragma unroll
     for (int ks = 0; ks < IF_KS; ++ks)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) B.f[ks][b] = Bn.f[ks][b];
+      for (int b = 0; b < NB; ++b) B.f[ks][b] = Bn.f[ks][b];
     if (sn.l != st.l) {  // roll the descriptors: the load for layer l+2 starts now
       boff_c += (Lc.N + 31) / 32 * 32;
       Lc = Ln;
@@ -698,16 +706,39 @@ mlp_chain_kernel(Chain c) {
   chain_body<RT, BWD, false>(c, nullptr);
 }
 
-template <int RT>
-__global__ void __launch_bounds__(kThreads, 2)
-policy_kernel(PolicyArgs a) {
-  chain_body<RT, false, true>(a.c[blockIdx.y], &a.px);
+// blockIdx.y = 0: action trunk with (RT_A, NB_A), 1: value trunk with (RT_V, NB_V).  Equal
+// shapes share ONE instance of the body (instruction cache).
+template <bool BWD, int RT_A, int NB_A, int RT_V, int NB_V>
+__device__ __forceinline__ void policy_trunk(const PolicyArgs& a) {
+  if constexpr (RT_A == RT_V && NB_A == NB_V) {
+    chain_body<RT_A, BWD, true, NB_A>(a.c[blockIdx.y], &a.px);
+  } else if (blockIdx.y == 0) {
+    chain_body<RT_A, BWD, true, NB_A>(a.c[0], &a.px);
+  } else {
+    chain_body<RT_V, BWD, true, NB_V>(a.c[1], &a.px);
+  }
 }
 
-template <int RT>
+template <int RT_A, int NB_A, int RT_V, int NB_V>
+__global__ void __launch_bounds__(kThreads, 2)
+policy_kernel(PolicyArgs a) {
+  policy_trunk<false, RT_A, NB_A, RT_V, NB_V>(a);
+}
+
+template <int RT_A, int NB_A, int RT_V, int NB_V>
 __global__ void __launch_bounds__(kThreads, 2)
 policy_bwd_kernel(PolicyArgs a) {
-  chain_body<RT, true, true>(a.c[blockIdx.y], &a.px);
+  policy_trunk<true, RT_A, NB_A, RT_V, NB_V>(a);
+}
+
+// A trunk no wider than 64 has one column tile per wave: at training sizes it runs with
+// 256 rows per workgroup (RT = 16, NB = 1).  MIPPO_NARROW_TRUNK=0 disables (tuning aid).
+bool narrow_trunk_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MIPPO_NARROW_TRUNK");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 // fp32 words of the LDS bias area of a forward chain (one 32-padded row per layer)
@@ -718,7 +749,7 @@ int bias_words(const Chain& c) {
 }
 
 #ifdef MIPPO_TRACE
-constexpr int kLdsMax = 160 * 1024 - 512;  // room for the static stamp buffer
+constexpr int kLdsMax = 160 * 1024 - 2048;  // room for the static stamp buffers
 #else
 constexpr int kLdsMax = 160 * 1024;
 #endif
@@ -804,27 +835,31 @@ int fill_fwd_chain(Chain& c, const char* who, const float* x, int64_t M, int64_t
   return 0;
 }
 
-template <int RT>
-int launch_policy(PolicyArgs& a, int maxw, hipStream_t st) {
-  constexpr int ROWS = 16 * RT;
-  const int act_bytes = 2 * ROWS * (maxw + 8) * (int)sizeof(bf16_t);
-  a.px.ms_off = act_bytes;
-  const int ms_bytes = (ROWS * 2 * a.px.samp.A * (int)sizeof(float) + 15) / 16 * 16;
-  a.c[0].bias_off = a.c[1].bias_off = act_bytes + ms_bytes;
-  const int bw0 = bias_words(a.c[0]), bw1 = bias_words(a.c[1]);
-  const size_t lds = (size_t)act_bytes + ms_bytes + (size_t)(bw0 > bw1 ? bw0 : bw1) * sizeof(float);
-  constexpr int kWant = 2 * ROWS * (512 + 8) * (int)sizeof(bf16_t) +
-                        ROWS * 128 * (int)sizeof(float) + CH_MAXL * 512 * 4;
+template <int RT_A, int NB_A, int RT_V, int NB_V>
+int launch_policy(PolicyArgs& a, int wa, int wc, hipStream_t st) {
+  constexpr int ROWS_A = 16 * RT_A, ROWS_V = 16 * RT_V;
+  const int act_a = 2 * ROWS_A * (wa + 8) * (int)sizeof(bf16_t);
+  const int act_v = 2 * ROWS_V * (wc + 8) * (int)sizeof(bf16_t);
+  a.px.ms_off = act_a;  // only the action trunk has the sampler's fp32 rows
+  const int ms_bytes = (ROWS_A * 2 * a.px.samp.A * (int)sizeof(float) + 15) / 16 * 16;
+  a.c[0].bias_off = act_a + ms_bytes;
+  a.c[1].bias_off = act_v;
+  const size_t lds_a = (size_t)act_a + ms_bytes + (size_t)bias_words(a.c[0]) * sizeof(float);
+  const size_t lds_v = (size_t)act_v + (size_t)bias_words(a.c[1]) * sizeof(float);
+  const size_t lds = lds_a > lds_v ? lds_a : lds_v;
+  constexpr int kRowsMax = ROWS_A > ROWS_V ? ROWS_A : ROWS_V;
+  constexpr int kWant = 2 * kRowsMax * (512 + 8) * (int)sizeof(bf16_t) +
+                        kRowsMax * 128 * (int)sizeof(float) + CH_MAXL * 512 * 4;
   constexpr int kCap = kWant < kLdsMax ? kWant : kLdsMax;
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&policy_kernel<RT>),
+      reinterpret_cast<const void*>(&policy_kernel<RT_A, NB_A, RT_V, NB_V>),
       hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
   MI_REQUIRE(attr == hipSuccess, "policy_kernel: cannot raise the dynamic LDS limit: %s",
              hipGetErrorString(attr));
   MI_REQUIRE(lds <= (size_t)kCap, "policy_kernel: %zu bytes of LDS needed, %d available", lds, kCap);
-  const int64_t m_max = a.c[0].M > a.c[1].M ? a.c[0].M : a.c[1].M;
-  hipLaunchKernelGGL((policy_kernel<RT>), dim3((unsigned)mippo::ceil_div(m_max, ROWS), 2),
-                     dim3(kThreads), lds, st, a);
+  const int64_t ga = mippo::ceil_div(a.c[0].M, ROWS_A), gv = mippo::ceil_div(a.c[1].M, ROWS_V);
+  hipLaunchKernelGGL((policy_kernel<RT_A, NB_A, RT_V, NB_V>),
+                     dim3((unsigned)(ga > gv ? ga : gv), 2), dim3(kThreads), lds, st, a);
   return mippo::check_launch("mi_policy_fwd_bf16");
 }
 
@@ -888,10 +923,11 @@ extern "C" int mi_policy_fwd_bf16(
                loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
   const int maxw = wa > wc ? wa : wc;
   hipStream_t st = mippo::as_stream(stream);
-  if (M + M_tail <= 8192) return launch_policy<1>(a, maxw, st);
+  if (M + M_tail <= 8192) return launch_policy<1, 4, 1, 4>(a, wa, wc, st);
   MI_REQUIRE(maxw <= 256, "mi_policy_fwd_bf16: trunks wider than 256 take at most 8192 rows "
                           "(use mi_mlp_fwd_bf16 per trunk)");
-  return launch_policy<4>(a, maxw, st);
+  if (wa <= 64 && narrow_trunk_enabled()) return launch_policy<16, 1, 4, 4>(a, wa, wc, st);
+  return launch_policy<4, 4, 4, 4>(a, wa, wc, st);
 }
 
 namespace {
@@ -953,17 +989,25 @@ int fill_bwd_chain(Chain& c, const char* who, const float* g_out, const void* au
   return 0;
 }
 
-template <int RT>
-int launch_policy_bwd(PolicyArgs& a, int maxw, hipStream_t st) {
-  constexpr int ROWS = 16 * RT;
-  const size_t lds = (size_t)2 * ROWS * (maxw + 8) * sizeof(bf16_t);
+template <int RT_A, int NB_A, int RT_V, int NB_V>
+int launch_policy_bwd(PolicyArgs& a, int wa, int wc, hipStream_t st) {
+  constexpr int ROWS_A = 16 * RT_A, ROWS_V = 16 * RT_V;
+  const size_t lds_a = (size_t)2 * ROWS_A * (wa + 8) * sizeof(bf16_t);
+  const size_t lds_v = (size_t)2 * ROWS_V * (wc + 8) * sizeof(bf16_t);
+  const size_t lds = lds_a > lds_v ? lds_a : lds_v;
+  constexpr int kRowsMax = ROWS_A > ROWS_V ? ROWS_A : ROWS_V;
+  constexpr int kWant = 2 * kRowsMax * (512 + 8) * (int)sizeof(bf16_t);
+  constexpr int kCap = kWant < kLdsMax ? kWant : kLdsMax;
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&policy_bwd_kernel<RT>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROWS * (512 + 8) * (int)sizeof(bf16_t));
+      reinterpret_cast<const void*>(&policy_bwd_kernel<RT_A, NB_A, RT_V, NB_V>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
   MI_REQUIRE(attr == hipSuccess, "policy_bwd_kernel: cannot raise the dynamic LDS limit: %s",
              hipGetErrorString(attr));
-  hipLaunchKernelGGL((policy_bwd_kernel<RT>), dim3((unsigned)mippo::ceil_div(a.c[0].M, ROWS), 2),
-                     dim3(kThreads), lds, st, a);
+  MI_REQUIRE(lds <= (size_t)kCap, "policy_bwd_kernel: %zu bytes of LDS needed, %d available", lds,
+             kCap);
+  const int64_t ga = mippo::ceil_div(a.c[0].M, ROWS_A), gv = mippo::ceil_div(a.c[1].M, ROWS_V);
+  hipLaunchKernelGGL((policy_bwd_kernel<RT_A, NB_A, RT_V, NB_V>),
+                     dim3((unsigned)(ga > gv ? ga : gv), 2), dim3(kThreads), lds, st, a);
   return mippo::check_launch("mi_policy_bwd_bf16");
 }
 
@@ -1021,10 +1065,11 @@ extern "C" int mi_policy_bwd_bf16(
                (int)(A2 / 2), min_std, std_scale, entropy_weight};
   const int maxw = wa > wc ? wa : wc;
   hipStream_t st = mippo::as_stream(stream);
-  if (M <= 8192) return launch_policy_bwd<1>(a, maxw, st);
+  if (M <= 8192) return launch_policy_bwd<1, 4, 1, 4>(a, wa, wc, st);
   MI_REQUIRE(maxw <= 256, "mi_policy_bwd_bf16: trunks wider than 256 take at most 8192 rows "
                           "(use mi_mlp_bwd_dx_bf16 per trunk)");
-  return launch_policy_bwd<4>(a, maxw, st);
+  if (wa <= 64 && narrow_trunk_enabled()) return launch_policy_bwd<16, 1, 4, 4>(a, wa, wc, st);
+  return launch_policy_bwd<4, 4, 4, 4>(a, wa, wc, st);
 }
 
 #ifdef MIPPO_TRACE
