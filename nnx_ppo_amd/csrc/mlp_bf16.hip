@@ -336,7 +336,8 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     // row of an element comes from a float reciprocal (exact: e < 2^15, and (e + 1/2) / K0
     // stays 1/(2 K0) away from an integer) — an integer division here is ~40 instructions
     // per element on a kernel that is bound by instruction issue.
-    constexpr int SB = 2;  // elements per thread and batch
+    // elements per thread and batch: one batch covers the tile for K0 <= 8
+    constexpr int SB = ROWS > 64 ? 8 : 2;
     const int nel = ROWS * K0;
     const float rcpK0 = 1.0f / (float)K0;
     float cnt = 0.0f;
@@ -556,6 +557,33 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     }
   };
 
+  // Linear head of a forward chain (no activation, no bf16 image): its fp32 columns go to
+  // the chain output and / or the sampler's LDS rows and nothing else — the general
+  // epilogue's per-element predicates and pad handling cost ~800 cycles per row tile here.
+  auto epilogue_head = [&](const IStep& st, const ChainLayer& ly, bool to_ms) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int ct = (st.p * NB + b) * 4 + wave;
+      if (ct * 16 >= ly.N) continue;
+      const int j0 = ct * 16 + 4 * lq;
+      const f32x4 bj = *reinterpret_cast<const f32x4*>(bias_s + boff_c + j0);
+      if (j0 >= ly.N) continue;  // per lane: none of its 4 columns exists
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int row = r * 16 + li;
+        const int64_t gi = i0 + row;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[r][b][e] + bj[e];
+          if (j0 + e < ly.N) {
+            if (to_ms) ms_base[row * ly.N + j0 + e] = v;
+            if (c_out && gi < cM) c_out[gi * ly.N + j0 + e] = v;
+          }
+        }
+      }
+    }
+  };
+
   while (s.l < cL) {
     const IStep st = s;
     const ChainLayer& ly = Lc;
@@ -650,8 +678,13 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
       const bool plain_out = st.l != cL - 1 || (BWD && !c_out && ly.out_bf);
       const bool hidden_relu = plain_out && (ly.N & 31) == 0 && ly.act == MI_ACT_RELU &&
                                (!BWD || ly.aux);
+      bool head = false;
+      if constexpr (!BWD)
+        head = st.l == cL - 1 && ly.act == MI_ACT_NONE && !ly.out_bf && !ly.pre_bf;
       if (hidden_relu) {
         epilogue_hidden_relu(st, ly);
+      } else if (head) {
+        epilogue_head(st, ly, samp_here);
       } else if (trans) {
         epilogue(st, ly, std::true_type{});
       } else {
