@@ -19,9 +19,15 @@
 //     pre-activation store) instead of 2-byte scalars;
 //   * RT row tiles per workgroup reuse every weight fragment RT times: RT = 1
 //     fills the chip at rollout sizes (M = 1k..8k rows), RT = 4 at training sizes
-//     (M = T * minibatch = 30 720) — measured in tools/microbench_trunk.py.
+//     (M = T * minibatch = 30 720) — measured in tools/microbench_trunk.py; a trunk
+//     no wider than 64 runs RT = 16 with ONE column tile per wave (NB = 1) there.
+//   * the kernel is bound by instruction issue and dependent latency, not by MFMA or
+//     HBM (tools/trace_policy.py: per-workgroup phase timeline): loads of a step are
+//     unconditional and counted, biases and the input tile share one memory round trip,
+//     kernel-argument scalars are read once, copies out ride one layer behind.
 // Forward:  v = act(acc + bias); training also copies each layer's output (and the
-//           bf16 input) out of LDS in coalesced 16-byte rows for the backward.
+//           bf16 input) out of LDS in coalesced 16-byte rows for the backward, while
+//           the NEXT layer's MFMAs run.
 // Backward: the same walk over the transposed problem: dz_{l-1} = (dz_l . W_l^T)
 //           (.) act'_{l-1}(y_{l-1}); the y_{l-1} values a lane needs are loaded
 //           global -> VGPR before the layer's last MFMAs; every dz_l is copied out
