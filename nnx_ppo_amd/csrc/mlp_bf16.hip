@@ -608,9 +608,10 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
     }
     MI_TR();
     if constexpr (BWD) {
-      if (pass_done && ly.aux && ly.act != MI_ACT_NONE) {
-        // act' operands of this pass: 8 bytes per (row, column tile), in flight
-        // during the MFMAs below
+      if (st.kc == 0 && ly.aux && ly.act != MI_ACT_NONE) {
+        // act' operands of this pass: 8 bytes per (row, column tile), requested at the
+        // pass's FIRST step — in flight during all its MFMAs (they were requested at the
+        // last step and the epilogue of a 4-step layer then waited ~3 000 cycles)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const int j0 = ((st.p * NB + b) * 4 + wave) * 16 + 4 * lq;
