@@ -313,12 +313,13 @@ def train_distillation(
     if log_fn is not None and metrics:
         log_fn(metrics, steps)
 
-    while int(distillation_state.steps_taken) < dc.total_steps:
+    steps_per_iteration = dc.rollout_length * dc.n_envs  # host mirror of `steps_taken`
+    while steps < dc.total_steps:
         distillation_state, metrics = distillation_step(
             env, teacher, distillation_state, dc.n_envs, dc.rollout_length, dc.n_epochs,
             dc.n_minibatches, dc.logging_level, dc.logging_percentiles)
         n_iterations += 1
-        steps = int(distillation_state.steps_taken)
+        steps += steps_per_iteration
         if config.eval.enabled and _should_run(steps, last_eval_step, config.eval.every_steps):
             eval_metrics = run_eval(steps)
             metrics.update(eval_metrics)

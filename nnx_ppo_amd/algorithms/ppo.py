@@ -122,7 +122,11 @@ def train_ppo(
     if log_fn is not None and metrics:
         log_fn(metrics, steps)
 
-    while int(training_state.steps_taken) < config.ppo.total_steps:
+    # `steps_taken` advances by the same constant every iteration (ppo.py:338), so the loop
+    # counts it on the host: reading the device scalar each iteration (ppo.py:209) would
+    # drain the GPU queue once per iteration for a number the host already knows
+    steps_per_iteration = config.ppo.rollout_length * config.ppo.n_envs * parallel.world_size()
+    while steps < config.ppo.total_steps:
         t0 = time.perf_counter() if measure_throughput else None
         training_state, metrics = ppo_step(
             env, training_state, config.ppo.n_envs, config.ppo.rollout_length,
@@ -131,8 +135,10 @@ def train_ppo(
             config.ppo.n_epochs, config.ppo.n_minibatches, config.ppo.critic_loss_weight,
             config.ppo.logging_level, config.ppo.logging_percentiles)
         n_iterations += 1
-        steps = int(training_state.steps_taken)  # the one host sync per iteration
+        steps += steps_per_iteration
         if measure_throughput:
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
             elapsed = time.perf_counter() - t0
             metrics["throughput/train_sps"] = (
                 config.ppo.n_envs * config.ppo.rollout_length / elapsed)
@@ -153,11 +159,13 @@ def train_ppo(
         if log_fn is not None:
             log_fn(metrics, steps)
 
+    device_steps = int(training_state.steps_taken)  # the one host read of the run
+    assert device_steps == steps, (device_steps, steps)
     return TrainResult(
         training_state=training_state,
         final_metrics=metrics,
         eval_history=eval_history,
-        total_steps=int(training_state.steps_taken),
+        total_steps=device_steps,
         total_iterations=n_iterations,
     )
 
