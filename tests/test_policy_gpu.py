@@ -47,7 +47,10 @@ def _leaves(x):
 
 @pytest.mark.parametrize("M", [1, 100, 4096, 9000])
 @pytest.mark.parametrize("activation", ["relu", "tanh", "swish"])
-@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [256] * 2, [128])])
+# third shape: a NARROW action trunk (<= 64 wide: 256 rows per workgroup above 8192 rows)
+# whose widths are not multiples of 32 (pad tiles, general epilogue) with a 6-column head
+@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [256] * 2, [128]),
+                                   (7, 3, [48, 40], [96])])
 def test_rollout_call_is_bit_identical_to_generic(dev, bf16, M, activation, shape):
     from nnx_ppo_amd.networks.containers import Sequential
     from nnx_ppo_amd.networks.policy import MLPActorCritic
@@ -72,17 +75,21 @@ def test_rollout_call_is_bit_identical_to_generic(dev, bf16, M, activation, shap
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("T,B", [(3, 7), (30, 1024)])
+@pytest.mark.parametrize("T,B,shape", [(3, 7, (5, 2, [64, 64], [256, 256])),
+                                       (30, 1024, (5, 2, [64, 64], [256, 256])),
+                                       # narrow trunk, ragged last workgroup, odd widths
+                                       (9, 1000, (7, 3, [48, 40], [96]))])
 @pytest.mark.parametrize("activation", ["relu", "swish"])
-def test_replay_and_gradients_bit_identical_to_generic(dev, bf16, T, B, activation):
+def test_replay_and_gradients_bit_identical_to_generic(dev, bf16, T, B, shape, activation):
     from nnx_ppo_amd.networks.containers import Sequential
     from nnx_ppo_amd.networks.types import PPONetworkOutput, bump_param_epoch
     from nnx_ppo_amd.optim import Optimizer
 
-    net = _net(dev, 5, 2, [64, 64], [256, 256], activation)
+    obs_dim = shape[0]
+    net = _net(dev, *shape, activation)
     opt = Optimizer(net, 1e-3, None, None, device=dev)
     g = torch.Generator().manual_seed(T * B)
-    x_seq = torch.randn(T, B, 5, generator=g).to(dev)
+    x_seq = torch.randn(T, B, obs_dim, generator=g).to(dev)
     done = torch.zeros(T, B, dtype=torch.bool, device=dev)
     state = net.initialize_state(B)
     smp = _sampler(net)
