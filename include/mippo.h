@@ -479,6 +479,12 @@ int mi_episode_step(const int64_t* counter, const void* inner_done, int done_is_
                     uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out, int64_t n,
                     mi_stream_t stream);
 
+/* The scan's output stacking (`rollout.py:61-66`: every Transition leaf of T steps becomes
+ * one `[T, ...]` array) for n_leaves leaves in one launch: dst[l] + t * nbytes[l] <-
+ * src[l * T + t][0 .. nbytes[l]).  n_leaves <= 16 and n_leaves * T <= 448. */
+int mi_stack_multi(const void* const* src, void* const* dst, const int64_t* nbytes,
+                   int64_t n_leaves, int64_t T, mi_stream_t stream);
+
 /* EpisodeWrapper.step (`nnx_ppo/wrappers/episode_wrapper.py:12-22`) AND the rollout's
  * reset-on-done select of the env state (`rollout.py:41-44`, `tree_where` 270-279) in one
  * launch.  The first nine arguments are `mi_episode_step`'s; mask[b] = done flag of row b.

@@ -98,7 +98,7 @@ def distillation_unroll_env(env, env_state, teacher: StatefulModule, student: St
         carry, tr = distillation_single_transition(env, teacher, student, carry, keys[t],
                                                    reset_states=at_step(t))
         steps.append(tr)
-    rollout_data = tree_map(lambda *xs: torch.stack(xs, dim=0), steps[0], *steps[1:])
+    rollout_data = rollout.stack_steps(steps)
     return carry[0], carry[1], carry[2], rollout_data
 
 

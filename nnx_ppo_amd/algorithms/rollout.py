@@ -63,6 +63,24 @@ def tree_where(cond: torch.Tensor, on_true: Any, on_false: Any) -> Any:
     return fill_slots(skeleton, ops.select_rows_multi(cond, pairs))
 
 
+def stack_steps(steps: list) -> Any:
+    """`tree_map(lambda *xs: stack(xs, 0), *steps)` — what the reference's scan does with
+    its per-step outputs (rollout.py:61-66) — with every GPU leaf in ONE launch
+    (`mi_stack_multi`) instead of one `torch.cat` launch per leaf."""
+    groups: list = []
+
+    def collect(*xs):
+        x0 = xs[0]
+        if (isinstance(x0, torch.Tensor) and x0.is_cuda
+                and all(x.shape == x0.shape and x.dtype == x0.dtype for x in xs)):
+            groups.append([x if x.is_contiguous() else x.contiguous() for x in xs])
+            return _Slot(len(groups) - 1)
+        return torch.stack(xs, dim=0)
+
+    skeleton = tree_map(collect, steps[0], *steps[1:])
+    return fill_slots(skeleton, ops.stack_multi(groups))
+
+
 class _Slot:
     def __init__(self, i: int):
         self.i = i
@@ -140,7 +158,7 @@ def unroll_env(env, env_state, networks: StatefulModule, network_state, unroll_l
     for t in range(unroll_length):
         carry, tr = single_transition(env, networks, carry, keys[t], reset_states=at_step(t))
         steps.append(tr)
-    rollout = tree_map(lambda *xs: torch.stack(xs, dim=0), steps[0], *steps[1:])
+    rollout = stack_steps(steps)
     shapes_match = tree_map(lambda v, r: v.shape == r.shape,
                             rollout.network_output.value_estimates, rollout.rewards)
     assert tree_all(shapes_match), "value_estimates leaves must match rewards leaves"

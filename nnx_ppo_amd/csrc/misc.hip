@@ -169,6 +169,33 @@ copy_multi_kernel(CopyTable tab) {
   }
 }
 
+// T per-step tensors of each of n leaves -> n stacked [T, ...] buffers in one launch
+// (blockIdx.y = leaf * T + step): a rollout ends with ~12 such stacks, one torch.cat
+// launch each.
+constexpr int kMaxStackSegments = 448;  // the table must fit the 4 KiB argument segment
+struct StackTable {
+  const void* src[kMaxStackSegments];
+  void* dst[kMaxSelectLeaves];
+  int64_t words[kMaxSelectLeaves];
+  int word_bytes[kMaxSelectLeaves];
+  int T;
+};
+
+__global__ void __launch_bounds__(kThreads)
+stack_multi_kernel(StackTable tab) {
+  const int seg = blockIdx.y, l = seg / tab.T, t = seg % tab.T;
+  const int64_t words = tab.words[l];
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < words;
+       i += (int64_t)gridDim.x * kThreads) {
+    if (tab.word_bytes[l] == 4)
+      static_cast<uint32_t*>(tab.dst[l])[t * words + i] =
+          static_cast<const uint32_t*>(tab.src[seg])[i];
+    else
+      static_cast<uint8_t*>(tab.dst[l])[t * words + i] =
+          static_cast<const uint8_t*>(tab.src[seg])[i];
+  }
+}
+
 struct GatherLeaf {
   const void* src;
   void* dst;
@@ -379,4 +406,34 @@ extern "C" int mi_episode_step_select(
   hipLaunchKernelGGL(episode_select_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream), e,
                      tab, (int)n_leaves, B);
   return mippo::check_launch("mi_episode_step_select");
+}
+
+extern "C" int mi_stack_multi(const void* const* src, void* const* dst, const int64_t* nbytes,
+                              int64_t n_leaves, int64_t T, mi_stream_t stream) {
+  MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves && T >= 0 &&
+                 n_leaves * T <= kMaxStackSegments,
+             "mi_stack_multi: n_leaves <= %d and n_leaves * T <= %d", kMaxSelectLeaves,
+             kMaxStackSegments);
+  if (n_leaves == 0 || T == 0) return 0;
+  MI_REQUIRE(src && dst && nbytes, "mi_stack_multi: null pointer");
+  StackTable tab = {};
+  tab.T = (int)T;
+  int64_t max_words = 0;
+  for (int64_t l = 0; l < n_leaves; ++l) {
+    MI_REQUIRE(dst[l] && nbytes[l] >= 0, "mi_stack_multi: bad leaf %lld", (long long)l);
+    bool w4 = nbytes[l] % 4 == 0 && aligned4(dst[l]);
+    for (int64_t t = 0; t < T; ++t) {
+      MI_REQUIRE(src[l * T + t] || nbytes[l] == 0, "mi_stack_multi: null source");
+      w4 = w4 && aligned4(src[l * T + t]);
+      tab.src[l * T + t] = src[l * T + t];
+    }
+    tab.dst[l] = dst[l];
+    tab.word_bytes[l] = w4 ? 4 : 1;
+    tab.words[l] = nbytes[l] / tab.word_bytes[l];
+    if (tab.words[l] > max_words) max_words = tab.words[l];
+  }
+  if (max_words == 0) return 0;
+  dim3 grid((unsigned)stream_grid(max_words), (unsigned)(n_leaves * T));
+  hipLaunchKernelGGL(stack_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream), tab);
+  return mippo::check_launch("mi_stack_multi");
 }

@@ -803,6 +803,34 @@ def copy_multi(pairs: list) -> None:
               "mi_copy_multi")
 
 
+def stack_multi(groups: list) -> list:
+    """`torch.stack(group, 0)` for every group of a list of equal-length groups of
+    same-shape contiguous tensors — one launch per 16 leaves / 448 segments
+    (`mi_stack_multi`) instead of one per group."""
+    if not groups:
+        return []
+    T = len(groups[0])
+    outs = []
+    per = max(1, min(16, 448 // max(T, 1)))
+    for g in groups:
+        _need(len(g) == T, "stack_multi: groups must have one length")
+        x0 = g[0]
+        _need(all(x.shape == x0.shape and x.dtype == x0.dtype and x.is_contiguous() for x in g),
+              "stack_multi: a group's tensors must share shape / dtype and be contiguous")
+        outs.append(torch.empty((T, *x0.shape), dtype=x0.dtype, device=x0.device))
+    if T == 0 or T > 448:
+        return [torch.stack(g, 0) if g else o for g, o in zip(groups, outs)]
+    for i in range(0, len(groups), per):
+        grp, dst = groups[i:i + per], outs[i:i + per]
+        n = len(grp)
+        P = ctypes.c_void_p * (n * T)
+        check(lib().mi_stack_multi(
+            P(*[ptr(x) for g in grp for x in g]), (ctypes.c_void_p * n)(*[ptr(d) for d in dst]),
+            (ctypes.c_int64 * n)(*[g[0].numel() * g[0].element_size() for g in grp]), n, T,
+            stream()), "mi_stack_multi")
+    return outs
+
+
 def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: int = 0,
                child_major: bool = False, fold: Optional[torch.Tensor] = None):
     """keys (int64, any shape) -> `[*keys.shape, m]` children / bits / integers / floats

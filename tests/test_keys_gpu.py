@@ -193,3 +193,23 @@ def test_episode_step_select_equals_step_then_select(dev, B):
                 assert a.dtype == b.dtype and torch.equal(a, b)
             for a, b in zip(outs + [cs, ts, ds], want):
                 assert a.dtype == b.dtype and torch.equal(a, b)
+
+
+def test_stack_multi_equals_torch_stack(dev):
+    """`mi_stack_multi` == `torch.stack(group, 0)` per group, bit for bit: 4-byte and 1-byte
+    rows, a shared (repeated) source, more groups than one launch takes."""
+    from nnx_ppo_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    T = 30
+    shared = torch.randn(64, generator=g).to(dev)
+    groups = [[torch.randn(64, 5, generator=g).to(dev) for _ in range(T)],
+              [(torch.rand(64, generator=g) < 0.5).to(dev) for _ in range(T)],
+              [torch.randint(0, 9, (64,), generator=g).to(dev) for _ in range(T)],
+              [shared] * T,
+              [torch.randn(3, generator=g).to(dev) for _ in range(T)]] * 4
+    got = ops.stack_multi(groups)
+    for a, grp in zip(got, groups):
+        want = torch.stack(grp, 0)
+        assert a.dtype == want.dtype and a.shape == want.shape and torch.equal(a, want)
+    assert ops.stack_multi([]) == []
