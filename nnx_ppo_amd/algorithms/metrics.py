@@ -24,9 +24,10 @@ def _log_metric(metrics: dict, name: str, x: Any,
     if x.dtype == torch.bool:
         metrics[name] = x.float().mean()
     elif percentile_levels is None or len(percentile_levels) == 0:
-        xf = x.float()
-        metrics[f"{name}/mean"] = xf.mean()
-        metrics[f"{name}/std"] = xf.std(unbiased=False)
+        # one Welford launch for both (population std, as `jp.std`)
+        sd, mu = torch.std_mean(x.float(), correction=0)
+        metrics[f"{name}/mean"] = mu
+        metrics[f"{name}/std"] = sd
     else:
         q = torch.tensor(percentile_levels, dtype=torch.float32, device=x.device) / 100.0
         pct = torch.quantile(x.float().reshape(-1), q)
