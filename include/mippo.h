@@ -439,10 +439,12 @@ int mi_copy_multi(const void* const* src, void* const* dst, const int64_t* nbyte
                   int64_t n_leaves, mi_stream_t stream);
 
 /* The minibatch gather for several leaves in one launch (n_leaves <= 16); leaf l
- * is time-major [T[l], N, row_bytes[l]]. */
+ * is time-major [T[l], N, row_bytes[l]].  The L indices are L / group_len consecutive
+ * groups (minibatches, `ppo.py:284-300`): dst[l] is [L / group_len][T[l]][group_len][row],
+ * so every group is a contiguous time-major block; group_len = L is one group. */
 int mi_gather_cols_multi(const void* const* src, void* const* dst, const int64_t* T,
                          const int64_t* row_bytes, int64_t n_leaves, const int64_t* idx,
-                         int64_t N, int64_t L, mi_stream_t stream);
+                         int64_t N, int64_t L, int64_t group_len, mi_stream_t stream);
 
 /* ---- a4 / a18: integer keys and episode bookkeeping ----------------------- */
 

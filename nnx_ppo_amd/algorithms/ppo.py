@@ -250,12 +250,26 @@ def ppo_step(
         grad_norms = torch.zeros(total_iterations, dtype=torch.float32, device=device)
 
     critic_extra: dict = {}
+    # minibatch gather x[:, inds] (ppo.py:297-300).  The indices of every gradient step are
+    # known before the first one, and the gathered leaves (rollout data, pre-rollout
+    # carry) do not change during the update: ONE launch gathers all n_epochs *
+    # n_minibatches minibatches, each a contiguous time-major block, instead of one launch
+    # per gradient step.  (Memory: n_epochs x the loss's share of the rollout; above
+    # 1 GiB the gather goes back to one launch per step.)
+    mb_leaves = tree_leaves(loss_view)
+    st_leaves = tree_leaves(training_state.network_states)
+    gather_src = mb_leaves + [x.unsqueeze(0) for x in st_leaves]
+    mb_size = all_indices.shape[1]
+    per_step_bytes = sum(x[:, :1].numel() * x.element_size() for x in gather_src) * mb_size
+    gather_all = per_step_bytes * total_iterations <= (1 << 30)
+    if gather_all:
+        all_gathered = ops.gather_cols_multi(gather_src, all_indices.reshape(-1).contiguous(),
+                                             groups=total_iterations)
     for i in range(total_iterations):
-        inds = all_indices[i].contiguous()
-        # minibatch gather x[:, inds] (ppo.py:297-300): every leaf in one launch
-        mb_leaves = tree_leaves(loss_view)
-        st_leaves = tree_leaves(training_state.network_states)
-        gathered = ops.gather_cols_multi(mb_leaves + [x.unsqueeze(0) for x in st_leaves], inds)
+        if gather_all:
+            gathered = [g[i] for g in all_gathered]
+        else:
+            gathered = ops.gather_cols_multi(gather_src, all_indices[i].contiguous())
         it = iter(gathered)
         minibatch = tree_map(lambda x: next(it), loss_view)
         net_state_subset = tree_map(lambda x: next(it).squeeze(0),

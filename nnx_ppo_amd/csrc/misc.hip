@@ -208,7 +208,8 @@ struct GatherTable {
 };
 
 __global__ void __launch_bounds__(kThreads)
-gather_cols_multi_kernel(GatherTable tab, const int64_t* __restrict__ idx, int64_t N, int64_t L) {
+gather_cols_multi_kernel(GatherTable tab, const int64_t* __restrict__ idx, int64_t N, int64_t L,
+                         int64_t GL) {
   const GatherLeaf lf = tab.leaf[blockIdx.y];
   const int64_t total = lf.T * L * lf.words;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
@@ -217,10 +218,13 @@ gather_cols_multi_kernel(GatherTable tab, const int64_t* __restrict__ idx, int64
     const int64_t j = (i / lf.words) % L;
     const int64_t t = i / (lf.words * L);
     const int64_t s = (t * N + idx[j]) * lf.words + w;
+    // group g = j / GL is a contiguous [T][GL][row] block of the output
+    const int64_t g = j / GL, jj = j - g * GL;
+    const int64_t d = ((g * lf.T + t) * GL + jj) * lf.words + w;
     if (lf.word_bytes == 4)
-      static_cast<uint32_t*>(lf.dst)[i] = static_cast<const uint32_t*>(lf.src)[s];
+      static_cast<uint32_t*>(lf.dst)[d] = static_cast<const uint32_t*>(lf.src)[s];
     else
-      static_cast<uint8_t*>(lf.dst)[i] = static_cast<const uint8_t*>(lf.src)[s];
+      static_cast<uint8_t*>(lf.dst)[d] = static_cast<const uint8_t*>(lf.src)[s];
   }
 }
 
@@ -313,10 +317,13 @@ extern "C" int mi_select_rows_multi(const uint8_t* mask, const void* const* on_t
 extern "C" int mi_gather_cols_multi(const void* const* src, void* const* dst, const int64_t* T,
                                     const int64_t* row_bytes, int64_t n_leaves,
                                     const int64_t* idx, int64_t N, int64_t L,
-                                    mi_stream_t stream) {
+                                    int64_t group_len, mi_stream_t stream) {
   MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves && N >= 1 && L >= 0,
              "mi_gather_cols_multi: 0 <= n_leaves <= %d", kMaxSelectLeaves);
   if (n_leaves == 0 || L == 0) return 0;
+  MI_REQUIRE(group_len >= 1 && L % group_len == 0,
+             "mi_gather_cols_multi: group_len must divide L (L=%lld, group_len=%lld)",
+             (long long)L, (long long)group_len);
   MI_REQUIRE(src && dst && T && row_bytes && idx, "mi_gather_cols_multi: null pointer");
   GatherTable tab = {};
   int64_t max_total = 0;
@@ -335,7 +342,7 @@ extern "C" int mi_gather_cols_multi(const void* const* src, void* const* dst, co
   }
   dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_leaves);
   hipLaunchKernelGGL(gather_cols_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream),
-                     tab, idx, N, L);
+                     tab, idx, N, L, group_len);
   return mippo::check_launch("mi_gather_cols_multi");
 }
 

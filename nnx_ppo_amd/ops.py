@@ -674,11 +674,15 @@ def gather_cols(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def gather_cols_multi(leaves: list, idx: torch.Tensor) -> list:
+def gather_cols_multi(leaves: list, idx: torch.Tensor, groups: int = 1) -> list:
     """`gather_cols` for several time-major `[T_l, N, ...]` leaves with ONE launch per
-    16 leaves (all leaves share N and the index vector)."""
+    16 leaves (all leaves share N and the index vector).  `groups` > 1: `idx` is that
+    many consecutive index groups (minibatches) and every output is
+    `[groups, T_l, L / groups, ...]` — each group a contiguous time-major block."""
     _need(idx.dim() == 1 and idx.dtype == i64, "gather_cols_multi: idx must be int64 [L]")
     L = idx.numel()
+    _need(groups >= 1 and L % groups == 0, "gather_cols_multi: groups must divide len(idx)")
+    GL = L // groups if L else 1
     outs: list = [None] * len(leaves)
     batch: list = []
     N = None
@@ -691,7 +695,8 @@ def gather_cols_multi(leaves: list, idx: torch.Tensor) -> list:
         I = ctypes.c_int64 * n
         check(lib().mi_gather_cols_multi(P(*[b[0] for b in batch]), P(*[b[1] for b in batch]),
                                          I(*[b[2] for b in batch]), I(*[b[3] for b in batch]), n,
-                                         ptr(idx, i64), N, L, stream()), "mi_gather_cols_multi")
+                                         ptr(idx, i64), N, L, GL, stream()),
+              "mi_gather_cols_multi")
         batch.clear()
 
     for k, src in enumerate(leaves):
@@ -702,7 +707,9 @@ def gather_cols_multi(leaves: list, idx: torch.Tensor) -> list:
         row_bytes = src.element_size()
         for d in src.shape[2:]:
             row_bytes *= d
-        dst = torch.empty((src.shape[0], L, *src.shape[2:]), dtype=src.dtype, device=src.device)
+        shape = ((src.shape[0], L, *src.shape[2:]) if groups == 1
+                 else (groups, src.shape[0], GL, *src.shape[2:]))
+        dst = torch.empty(shape, dtype=src.dtype, device=src.device)
         outs[k] = dst
         if row_bytes == 0 or L == 0 or src.shape[0] == 0:
             continue

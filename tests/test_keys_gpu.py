@@ -213,3 +213,22 @@ def test_stack_multi_equals_torch_stack(dev):
         want = torch.stack(grp, 0)
         assert a.dtype == want.dtype and a.shape == want.shape and torch.equal(a, want)
     assert ops.stack_multi([]) == []
+
+
+def test_gather_cols_multi_groups(dev):
+    """`groups` > 1: group g of every output == the single-group gather of that group's
+    indices (each minibatch a contiguous time-major block, ppo.py:284-300)."""
+    from nnx_ppo_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    T, N, G, mb = 7, 96, 6, 32
+    leaves = [torch.randn(T, N, 5, generator=g).to(dev), torch.randn(T, N, generator=g).to(dev),
+              (torch.rand(T, N, generator=g) < 0.5).to(dev),
+              torch.randint(0, 9, (1, N), generator=g).to(dev)]
+    idx = torch.stack([torch.randperm(N, generator=g)[:mb] for _ in range(G)]).to(dev)
+    got = ops.gather_cols_multi(leaves, idx.reshape(-1).contiguous(), groups=G)
+    for k in range(G):
+        want = ops.gather_cols_multi(leaves, idx[k].contiguous())
+        for a, b, src in zip(got, want, leaves):
+            assert a.shape == (G, src.shape[0], mb, *src.shape[2:]) and a[k].is_contiguous()
+            assert torch.equal(a[k], b) and torch.equal(b, src[:, idx[k]])
