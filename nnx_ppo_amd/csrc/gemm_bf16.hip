@@ -245,6 +245,16 @@ constexpr int dw_lds_bytes() {
   return 2 * BK * ((WM * TM * 16 + 16) + (WN * TN * 16 + 16)) * (int)sizeof(bf16_t);
 }
 
+// -DMIPPO_TRACE (tools/trace_policy.py): per-workgroup phase stamps of the dW kernel
+// (start, first tile in LDS, loop done, end; wall clock start / end; class; iterations).
+#ifdef MIPPO_TRACE
+constexpr int TRD_EV = 12, TRD_WG = 2048;
+__device__ unsigned long long g_trace_dw[TRD_WG * TRD_EV];
+#define MI_TRD(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MI_TRD(var) do {} while (0)
+#endif
+
 // One tile class of a dW launch: workgroup `hw` of `total` of this class.
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigned total,
@@ -394,9 +404,14 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
     }
   };
 
+#ifdef MIPPO_TRACE
+  const unsigned long long trd_w0 = wall_clock64();
+#endif
+  MI_TRD(trd_t0);
   load_tile(r_begin, st0);
   store_tile(0, st0, r_begin);
   __syncthreads();
+  MI_TRD(trd_t1);
   load_tile(r_begin + BK, st0);      // tile 1
   // tile 2 strictly after tile 1: the in-loop waits count on "stage X older than stage Y"
   __builtin_amdgcn_sched_barrier(0);
@@ -404,12 +419,27 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
   __builtin_amdgcn_sched_barrier(0);
   // Both halves always run (no early exit: a straight-line body keeps the accumulators in
   // place); a split with an odd number of tiles multiplies one tile of zeros at the end.
+#ifdef MIPPO_TRACE
+  unsigned long long trd_acc[4] = {0, 0, 0, 0};  // multiply / store (+ its wait) / load issue / barrier
+#define MI_TRD_ACC(k, a, b) trd_acc[k] += (b) - (a)
+#else
+#define MI_TRD_ACC(k, a, b) do {} while (0)
+#endif
   for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * BK) {
     // LDS buffer 0 holds tile r0; st0 = tile r0 + BK, st1 = tile r0 + 2 BK
+    MI_TRD(q0);
     multiply(0);
+    MI_TRD(q1);
     store_tile(1, st0, r0 + BK);
+    MI_TRD(q2);
     load_tile(r0 + 3 * BK, st0);
+    MI_TRD(q3);
     __syncthreads();
+    MI_TRD(q4);
+    MI_TRD_ACC(0, q0, q1);
+    MI_TRD_ACC(1, q1, q2);
+    MI_TRD_ACC(2, q2, q3);
+    MI_TRD_ACC(3, q3, q4);
     // LDS buffer 1 holds tile r0 + BK; st1 = tile r0 + 2 BK, st0 = tile r0 + 3 BK
     multiply(1);
     store_tile(0, st1, r0 + 2 * BK);
@@ -417,6 +447,7 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
     __syncthreads();
   }
 
+  MI_TRD(trd_t2);
   float* slab = slabs + (int64_t)zsplit * (I * J + J);
   const int In = (int)I, Jn = (int)J;  // <= 512: 32-bit index arithmetic
   // rows of the slab are 16-byte aligned
@@ -448,6 +479,20 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
         if (j + e < Jn) slab[(int64_t)In * Jn + j + e] = accb[b][e];
     }
   }
+#ifdef MIPPO_TRACE
+  if (tid == 0 && blockIdx.x < TRD_WG) {
+    unsigned long long* o = g_trace_dw + (size_t)blockIdx.x * TRD_EV;
+    o[0] = trd_t0;
+    o[1] = trd_t1;
+    o[2] = trd_t2;
+    o[3] = __builtin_amdgcn_s_memtime();
+    o[4] = trd_w0;
+    o[5] = wall_clock64();
+    o[6] = (unsigned long long)(WM * 100 + TN);  // tile class tag
+    o[7] = (unsigned long long)((r_end - r_begin + BK - 1) / BK);
+    for (int k = 0; k < 4; ++k) o[8 + k] = trd_acc[k];  // sums over the EVEN tiles
+  }
+#endif
 }
 
 // ALL tile classes of a grouped dW in one launch: the workgroups of the 128x128 class
@@ -855,3 +900,14 @@ extern "C" int mi_weights_to_bf16_multi(int64_t n_layers, const float* const* w,
                      mippo::as_stream(stream), tab);
   return mippo::check_launch("mi_weights_to_bf16_multi");
 }
+
+#ifdef MIPPO_TRACE
+extern "C" int mi_debug_trace_dw(unsigned long long* host_out, int64_t n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace_dw), (size_t)n * 8);
+}
+extern "C" int mi_debug_trace_dw_clear() {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace_dw));
+  return e != hipSuccess ? (int)e : (int)hipMemset(p, 0, sizeof(g_trace_dw));
+}
+#endif

@@ -100,3 +100,34 @@ g = PPONetworkOutput(None, torch.randn(T, B, device=dev), torch.randn(T, B, devi
 opt.begin()
 net.replay_backward(ctx, g, 1.0 / (T * B))
 dump("policy_bwd_kernel<4> (M = %d)" % (T * B), 64, T * B)
+
+# ---- dW kernel of the same backward (gemm_bf16.hip, -DMIPPO_TRACE) ---------------------
+cd.mi_debug_trace_dw.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+cd.mi_debug_trace_dw_clear()
+torch.cuda.synchronize()
+opt.begin()
+net.replay_backward(ctx, g, 1.0 / (T * B))
+torch.cuda.synchronize()
+buf = np.zeros(2048 * 12, dtype=np.uint64)
+assert cd.mi_debug_trace_dw(buf.ctypes.data, buf.size) == 0
+tr = buf.reshape(2048, 12).astype(np.int64)
+live = tr[:, 0] != 0
+print(f"== tn_gemm_dw_all_kernel: {int(live.sum())} working workgroups traced")
+w0 = tr[live, 4].min()
+st, en = (tr[live, 4] - w0) / 100.0, (tr[live, 5] - w0) / 100.0
+print(f"  wall-clock us: last start {st.max():.1f}, first end {en.min():.1f}, last end {en.max():.1f}")
+for tag in sorted(set(tr[live, 6])):
+    sel = live & (tr[:, 6] == tag)
+    pro = (tr[sel, 1] - tr[sel, 0]).mean()
+    loop = (tr[sel, 2] - tr[sel, 1]).mean()
+    epi = (tr[sel, 3] - tr[sel, 2]).mean()
+    its = tr[sel, 7].mean()
+    life = ((tr[sel, 5] - tr[sel, 4]) / 100.0)
+    print(f"  class WM*100+TN={int(tag)}: {int(sel.sum())} wgs, life {life.mean():.1f} us "
+          f"(max {life.max():.1f}); cycles: prologue {pro:.0f}, loop {loop:.0f} "
+          f"({its:.1f} tiles, {loop / max(its, 1):.0f} per tile), epilogue {epi:.0f}")
+    half = np.maximum((tr[sel, 7] + 1) // 2, 1)[:, None]
+    ph = (tr[sel, 8:12] / half).mean(0)
+    print(f"    per even tile: multiply {ph[0]:.0f}, store to LDS (+ wait for its loads) "
+          f"{ph[1]:.0f}, load issue {ph[2]:.0f}, barrier {ph[3]:.0f}")
+
