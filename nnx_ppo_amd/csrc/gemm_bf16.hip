@@ -314,39 +314,67 @@ __device__ __forceinline__ void dw_body(const DwTable& tab, unsigned hw, unsigne
   Stage st0, st1;
   const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
   const int64_t r_last = r_end - 1;  // r_end > r_begin for every launched split
+  // Full tiles (every row below r_end — all but a split's last one or two) load through
+  // per-slot RUNNING POINTERS advanced by BK rows per call (the per-tile 64-bit
+  // row * ld products were ~90 VALU instructions per tile beside 40 MFMAs) and are stored
+  // without the zeroing select when the tile lies inside both operands' columns.
+  // Threads beyond a tile's chunk count read rows below the tile (valid while the whole
+  // A_ROWS / B_ROWS window is below r_end; never stored).
+  // (slot p of a thread is kThreads / (row chunks) rows below slot 0: ONE running pointer
+  // per operand, the slots at uniform offsets)
+  constexpr int A_RPS = kThreads / (BM / 8), B_RPS = kThreads / (BN / 8);  // rows per slot
+  static_assert(kThreads % (BM / 8) == 0 && kThreads % (BN / 8) == 0, "slot stride");
+  constexpr int A_ROWS = A_PT * A_RPS, B_ROWS = B_PT * B_RPS;  // rows a call touches
+  const int64_t gi_t = i0 + (tid % (BM / 8)) * 8, gj_t = j0 + (tid % (BN / 8)) * 8;
+  const bf16_t* pa0 = A + (r_begin + tid / (BM / 8)) * lda + (gi_t < lda ? gi_t : 0);
+  const bf16_t* pb0 = B + (r_begin + tid / (BN / 8)) * ldb + (gj_t < ldb ? gj_t : 0);
+  const bool all_cols = i0 + BM <= lda && j0 + BN <= ldb;
   auto load_tile = [&](int64_t r0, Stage& sg) {
+    if (r0 + A_ROWS <= r_end && r0 + B_ROWS <= r_end) {
 #pragma unroll
-    for (int p = 0; p < A_PT; ++p) {
-      const int c = tid + p * kThreads;
-      const int r = c / (BM / 8), ic = c % (BM / 8);
-      const int64_t gr = r0 + r, gi = i0 + ic * 8;
-      sg.a[p] = *reinterpret_cast<const u32x4*>(A + (gr < r_end ? gr : r_last) * lda +
-                                                (gi < lda ? gi : 0));
-    }
+      for (int p = 0; p < A_PT; ++p)
+        sg.a[p] = *reinterpret_cast<const u32x4*>(pa0 + (int64_t)(p * A_RPS) * lda);
 #pragma unroll
-    for (int p = 0; p < B_PT; ++p) {
-      const int c = tid + p * kThreads;
-      const int r = c / (BN / 8), jc = c % (BN / 8);
-      const int64_t gr = r0 + r, gj = j0 + jc * 8;
-      sg.b[p] = *reinterpret_cast<const u32x4*>(B + (gr < r_end ? gr : r_last) * ldb +
-                                                (gj < ldb ? gj : 0));
+      for (int p = 0; p < B_PT; ++p)
+        sg.b[p] = *reinterpret_cast<const u32x4*>(pb0 + (int64_t)(p * B_RPS) * ldb);
+    } else {
+#pragma unroll
+      for (int p = 0; p < A_PT; ++p) {
+        const int c = tid + p * kThreads;
+        const int r = c / (BM / 8), ic = c % (BM / 8);
+        const int64_t gr = r0 + r, gi = i0 + ic * 8;
+        sg.a[p] = *reinterpret_cast<const u32x4*>(A + (gr < r_end ? gr : r_last) * lda +
+                                                  (gi < lda ? gi : 0));
+      }
+#pragma unroll
+      for (int p = 0; p < B_PT; ++p) {
+        const int c = tid + p * kThreads;
+        const int r = c / (BN / 8), jc = c % (BN / 8);
+        const int64_t gr = r0 + r, gj = j0 + jc * 8;
+        sg.b[p] = *reinterpret_cast<const u32x4*>(B + (gr < r_end ? gr : r_last) * ldb +
+                                                  (gj < ldb ? gj : 0));
+      }
     }
+    // the calls walk the tiles in order: r_begin, + BK, + 2 BK, ...
+    pa0 += BK * lda;
+    pb0 += BK * ldb;
   };
   // (the zeroing select happens here, when the values are consumed, so that only the raw
   // loaded registers stay live across an iteration)
   auto store_tile = [&](int buf, const Stage& sg, int64_t r0) {
+    const bool plain = all_cols && r0 + BK <= r_end;
 #pragma unroll
     for (int p = 0; p < A_PT; ++p) {
       const int c = tid + p * kThreads;
       const int r = c / (BM / 8), ic = c % (BM / 8);
-      const bool ok = r0 + r < r_end && i0 + ic * 8 < lda;
+      const bool ok = plain || (r0 + r < r_end && i0 + ic * 8 < lda);
       if (c < A_CH) *reinterpret_cast<u32x4*>(&As[buf][r][ic * 8]) = ok ? sg.a[p] : zero4;
     }
 #pragma unroll
     for (int p = 0; p < B_PT; ++p) {
       const int c = tid + p * kThreads;
       const int r = c / (BN / 8), jc = c % (BN / 8);
-      const bool ok = r0 + r < r_end && j0 + jc * 8 < ldb;
+      const bool ok = plain || (r0 + r < r_end && j0 + jc * 8 < ldb);
       if (c < B_CH) *reinterpret_cast<u32x4*>(&Bs[buf][r][jc * 8]) = ok ? sg.b[p] : zero4;
     }
   };
