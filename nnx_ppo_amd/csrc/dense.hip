@@ -285,14 +285,14 @@ reduce_slabs_grouped_kernel(RedTable tab, int accumulate) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) v += t[u];
     }
-    for (; s + 8 <= pr.S; s += 8) {
-      float t[8];
+    if (s < pr.S) {  // the remainder as ONE predicated batch (it was one round trip per slab)
+      float t[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = pr.slabs[(s + u) * stride + i];
+      for (int u = 0; u < 16; ++u) t[u] = s + u < pr.S ? pr.slabs[(s + u) * stride + i] : 0.0f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += t[u];
+      for (int u = 0; u < 16; ++u)
+        if (s + u < pr.S) v += t[u];
     }
-    for (; s < pr.S; ++s) v += pr.slabs[s * stride + i];
     if (i < pr.KN) {
       pr.gw[i] = accumulate ? pr.gw[i] + v : v;
     } else if (pr.gb) {

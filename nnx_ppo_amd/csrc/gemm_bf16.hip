@@ -749,20 +749,24 @@ extern "C" int mi_dense_bwd_dx_bf16(const void* dz_bf, int64_t lddz, const void*
 
 // rows per split / number of splits shared by every problem of a launch (they
 // share M): enough workgroups to cover the chip about twice, >= 128 rows each.
-// `classes`: tile classes that share the launch.  The launch as a whole aims at ~2.25
-// workgroups per CU: every split adds a K x N fp32 slab that is written and read again
-// (at C2 and 512 workgroups per class the slabs moved as many bytes as the operands);
-// measured on bench.py with MIPPO_DW_BLOCKS = 64 .. 768 per class, best at 160-192.
-static void dw_split_plan(int64_t M, int64_t total_tiles, int classes, int64_t* rows,
-                          int64_t* S) {
-  // MIPPO_DW_BLOCKS overrides the per-class target workgroup count (tuning aid)
+// `total_tiles`: output tiles of EVERY problem of the launch, whatever their class: one
+// split count for all of them.  A 64-row tile costs a workgroup 2 400-3 000 cycles in
+// every class (tools/trace_policy.py: the iteration is bound by its latency chain, not by
+// the tile's MFMA count), so equal tiles per workgroup make the classes finish together —
+// per-class targets left the 128x128 class with 15 tiles per workgroup beside 7-10 in the
+// narrow ones and the kernel as long as its slowest class.  The launch stays inside ONE
+// resident wave of workgroups (2 per CU: 73 KB of LDS each) and every split also adds a
+// K x N fp32 slab that is written and read again; measured on bench.py (C2: 13 tiles)
+// with MIPPO_DW_BLOCKS = 416 .. 640: 416 (32 splits, 15 row tiles per workgroup) is best,
+// 455-500 (35-39 splits) cost +19-25 % in this kernel, 544+ need a second wave.
+// MIPPO_DW_BLOCKS overrides the target (tuning aid).
+static void dw_split_plan(int64_t M, int64_t total_tiles, int64_t* rows, int64_t* S) {
   static const int64_t override_target = [] {
     const char* e = getenv("MIPPO_DW_BLOCKS");
     return e ? (int64_t)atoi(e) : (int64_t)0;
   }();
-  const int64_t target = override_target > 0
-                             ? override_target
-                             : (int64_t)9 * mippo::kNumCU / 4 / (classes < 1 ? 1 : classes);
+  const int64_t target =
+      override_target > 0 ? override_target : (int64_t)13 * mippo::kNumCU / 8;
   int64_t s = mippo::ceil_div(target, total_tiles < 1 ? 1 : total_tiles);
   const int64_t max_s = mippo::ceil_div(M, 128);
   if (s > max_s) s = max_s;
@@ -789,7 +793,7 @@ extern "C" int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const
   int64_t total = 0;
   for (int64_t l = 0; l < n; ++l) {
     int64_t rows, S;
-    dw_split_plan(M, dw_tiles(K[l], N[l]), 1, &rows, &S);
+    dw_split_plan(M, dw_tiles(K[l], N[l]), &rows, &S);
     total += S * (K[l] * N[l] + N[l]);
   }
   return total * (int64_t)sizeof(float);
@@ -818,30 +822,25 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
   // side; all classes go out in ONE launch
   DwAll all = {};
   unsigned next = 0;
-  int n_classes = 0;
-  {
-    bool has[3] = {false, false, false};
-    for (int64_t l = 0; l < n; ++l) has[N[l] > 64 ? 0 : (N[l] > 16 ? 1 : 2)] = true;
-    n_classes = (int)has[0] + (int)has[1] + (int)has[2];
-  }
+  int64_t tiles_all = 0;
+  for (int64_t l = 0; l < n; ++l) tiles_all += dw_tiles(K[l], N[l]);
+  int64_t rows, S;
+  dw_split_plan(M, tiles_all, &rows, &S);
   size_t lds = 0;
   for (int cls = 0; cls < 3; ++cls) {
     DwTable& tab = all.cls[cls];
     int idx[kMaxDwProblems];
-    int64_t tiles = 0, gx = 0, gy = 0;
+    int64_t gx = 0, gy = 0;
     for (int64_t l = 0; l < n; ++l) {
       const int c = N[l] > 64 ? 0 : (N[l] > 16 ? 1 : 2);
       if (c != cls) continue;
       idx[tab.n++] = (int)l;
-      tiles += dw_tiles(K[l], N[l]);
       const int64_t tx = mippo::ceil_div(K[l], 128), ty = mippo::ceil_div(N[l], dw_tile_n(N[l]));
       if (tx > gx) gx = tx;
       if (ty > gy) gy = ty;
     }
     all.begin[cls] = next;
     if (tab.n == 0) continue;
-    int64_t rows, S;
-    dw_split_plan(M, tiles, n_classes, &rows, &S);
     tab.M = M;
     tab.rows_per_split = rows;
     for (int q = 0; q < tab.n; ++q) {
