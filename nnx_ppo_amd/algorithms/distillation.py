@@ -174,11 +174,21 @@ def distillation_step(env, teacher: StatefulModule, distillation_state: Distilla
         teacher_rollout_extras=rollout_data.teacher_rollout_extras)
 
     per_step: dict = {}
+    # every minibatch of the update in one gather launch (as ppo_step does)
+    mb_leaves = tree_leaves(loss_view)
+    st_leaves = tree_leaves(distillation_state.student_states)
+    gather_src = mb_leaves + [x.unsqueeze(0) for x in st_leaves]
+    mb_size = all_indices.shape[1]
+    per_step_bytes = sum(x[:, :1].numel() * x.element_size() for x in gather_src) * mb_size
+    gather_all = per_step_bytes * total_iterations <= (1 << 30)
+    if gather_all:
+        all_gathered = ops.gather_cols_multi(gather_src, all_indices.reshape(-1).contiguous(),
+                                             groups=total_iterations)
     for i in range(total_iterations):
-        inds = all_indices[i].contiguous()
-        mb_leaves = tree_leaves(loss_view)
-        st_leaves = tree_leaves(distillation_state.student_states)
-        gathered = ops.gather_cols_multi(mb_leaves + [x.unsqueeze(0) for x in st_leaves], inds)
+        if gather_all:
+            gathered = [g[i] for g in all_gathered]
+        else:
+            gathered = ops.gather_cols_multi(gather_src, all_indices[i].contiguous())
         it = iter(gathered)
         minibatch = tree_map(lambda x: next(it), loss_view)
         student_state_subset = tree_map(lambda x: next(it).squeeze(0),
