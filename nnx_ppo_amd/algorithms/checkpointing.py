@@ -57,15 +57,56 @@ def _encode(x: Any) -> Any:
                     "enums, dicts, lists, tuples, numbers and strings only)")
 
 
-def _lookup(spec: str):
+# Classes a checkpoint may name.  A checkpoint only ever NAMES classes (it holds no code),
+# and a name is honoured only if (a) its module is on this allow-list, (b) the module is
+# already imported, and (c) the object found there is the kind of class the tag claims — a
+# dataclass type for `__dataclass__`, an `enum.Enum` subclass for `__enum__`.  Without
+# these checks a crafted metadata.pt could name any callable of any imported module
+# (`os:system`) and have it called with a value from the file.
+_ALLOWED_MODULE_PREFIXES: list[str] = ["nnx_ppo_amd."]
+
+
+def allow_checkpoint_module(module: str) -> None:
+    """Let checkpoints restore dataclasses / enums defined in `module` (e.g. the module of
+    a user env's `State`).  Exact module name, or a package prefix ending in '.'."""
+    if module not in _ALLOWED_MODULE_PREFIXES:
+        _ALLOWED_MODULE_PREFIXES.append(module)
+
+
+def _module_allowed(module: str) -> bool:
+    for a in _ALLOWED_MODULE_PREFIXES:
+        if module == a or module == a.rstrip(".") or (a.endswith(".") and module.startswith(a)):
+            return True
+    return False
+
+
+def _lookup(spec: str, kind: str):
+    if not isinstance(spec, str):
+        raise RuntimeError(f"checkpoint: malformed class reference {spec!r}")
     module, _, qual = spec.partition(":")
+    if not _module_allowed(module):
+        raise RuntimeError(
+            f"checkpoint refers to {spec}, whose module is not on the allow-list; call "
+            f"checkpointing.allow_checkpoint_module({module!r}) before loading if you trust it")
     mod = sys.modules.get(module)
     if mod is None:
         raise RuntimeError(f"checkpoint refers to {spec}; import {module} before loading "
                            "(classes are looked up, never imported, while loading)")
     obj = mod
     for part in qual.split("."):
+        if not part or part.startswith("_"):
+            raise RuntimeError(f"checkpoint: refusing private attribute in {spec}")
         obj = getattr(obj, part)
+    if not isinstance(obj, type):
+        raise RuntimeError(f"checkpoint: {spec} is not a class")
+    if kind == "dataclass":
+        if not dataclasses.is_dataclass(obj):
+            raise RuntimeError(f"checkpoint: {spec} is not a dataclass")
+    elif kind == "enum":
+        if not issubclass(obj, enum.Enum):
+            raise RuntimeError(f"checkpoint: {spec} is not an Enum")
+    else:  # pragma: no cover
+        raise AssertionError(kind)
     return obj
 
 
@@ -74,12 +115,14 @@ def _decode(x: Any, device) -> Any:
         return x.to(device)
     if isinstance(x, dict):
         if _TAG in x:
-            cls = _lookup(x[_TAG])
-            if not dataclasses.is_dataclass(cls):
-                raise RuntimeError(f"{x[_TAG]} is not a dataclass")
-            return cls(**{k: _decode(v, device) for k, v in x["fields"].items()})
+            cls = _lookup(x[_TAG], "dataclass")
+            names = {f.name for f in dataclasses.fields(cls)}
+            fields = x.get("fields")
+            if not isinstance(fields, dict) or not set(fields) <= names:
+                raise RuntimeError(f"checkpoint: fields of {x[_TAG]} do not match the class")
+            return cls(**{k: _decode(v, device) for k, v in fields.items()})
         if _ENUM in x:
-            return _lookup(x[_ENUM])(x["value"])
+            return _lookup(x[_ENUM], "enum")(x["value"])
         if _TUPLE in x:
             return tuple(_decode(v, device) for v in x[_TUPLE])
         return {k: _decode(v, device) for k, v in x.items()}

@@ -99,3 +99,63 @@ def test_mismatched_architecture_is_refused(tmp_path):
     tmpl = ppo.new_training_state(env, other, 4, 1, device="cpu")
     with pytest.raises(ValueError):
         load_checkpoint(str(tmp_path / "step_0000000001"), tmpl.networks, tmpl.optimizer)
+
+
+def test_crafted_class_references_are_refused(tmp_path):
+    """A checkpoint names classes; a name is honoured only for allow-listed modules and
+    only if it is the kind of class its tag claims (`__enum__: os:system`)."""
+    from nnx_ppo_amd.algorithms import checkpointing as ck
+
+    for bad in ({"__enum__": "os:getenv", "value": "HOME"},
+                {"__enum__": "builtins:print", "value": "x"},
+                {"__enum__": "nnx_ppo_amd.algorithms.checkpointing:make_checkpoint_fn",
+                 "value": "/tmp/x"},
+                {"__enum__": "nnx_ppo_amd.algorithms.config:TrainConfig", "value": 1},
+                {"__dataclass__": "os:system", "fields": {}},
+                {"__dataclass__": "nnx_ppo_amd.algorithms.types:LoggingLevel", "fields": {}},
+                {"__dataclass__": "nnx_ppo_amd.algorithms.config:TrainConfig",
+                 "fields": {"not_a_field": 1}},
+                {"__dataclass__": "nnx_ppo_amd.algorithms.checkpointing:_lookup", "fields": {}}):
+        with pytest.raises(RuntimeError):
+            ck._decode(bad, "cpu")
+    # the legitimate forms still decode
+    from nnx_ppo_amd.algorithms.types import LoggingLevel
+
+    enc = ck._encode(TrainConfig(ppo=PPOConfig(logging_level=LoggingLevel.LOSSES)))
+    assert ck._decode(enc, "cpu") == TrainConfig(ppo=PPOConfig(logging_level=LoggingLevel.LOSSES))
+    # and a crafted metadata.pt is refused by load_checkpoint as a whole
+    make_checkpoint_fn(str(tmp_path))(_state(), step=1)
+    meta_path = tmp_path / "step_0000000001" / "metadata.pt"
+    meta = torch.load(meta_path, weights_only=True)
+    meta["config"] = {"__enum__": "os:getenv", "value": "HOME"}
+    torch.save(meta, meta_path)
+    tmpl = _state(seed=3)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(str(tmp_path / "step_0000000001"), tmpl.networks, tmpl.optimizer)
+
+
+def test_user_module_needs_allow_listing():
+    import dataclasses as dc
+    import sys
+    import types
+
+    from nnx_ppo_amd.algorithms import checkpointing as ck
+
+    mod = types.ModuleType("user_env_mod")
+
+    @dc.dataclass
+    class S:
+        a: int = 0
+
+    S.__module__, S.__qualname__ = "user_env_mod", "S"
+    mod.S = S
+    sys.modules["user_env_mod"] = mod
+    try:
+        enc = ck._encode(S(3))
+        with pytest.raises(RuntimeError):
+            ck._decode(enc, "cpu")
+        ck.allow_checkpoint_module("user_env_mod")
+        assert ck._decode(enc, "cpu") == S(3)
+    finally:
+        ck._ALLOWED_MODULE_PREFIXES.remove("user_env_mod")
+        del sys.modules["user_env_mod"]
