@@ -6,8 +6,21 @@ rollout + update (BASELINE.json configs[1]; per GPU when sharded).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full `ppo_step` iteration (rollout -> n_epochs x n_minibatches
-replay/GAE/loss/Adam steps -> normaliser update) including the reference's one
-host sync per iteration (`int(steps_taken)`, nnx_ppo/algorithms/ppo.py:209).
+replay/GAE/loss/Adam steps -> normaliser update) run exactly as `train_ppo` runs it
+(`nnx_ppo_amd/algorithms/loop.py`: one HIP-graph launch per iteration and ONE host sync
+per iteration — the read of the iteration's metrics, the counterpart of the reference's
+`int(steps_taken)`, nnx_ppo/algorithms/ppo.py:209 — inside the timed region; iteration
+i+1 is enqueued before the host waits for iteration i, as `train_ppo` does when no
+callback is due).
+
+Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each
+bracketed by barrier + device synchronise on both sides and reduced with MAX over ranks;
+the window is repeated until >= 1 s has been timed.  `value` = env-steps of one window /
+the MEDIAN window time; `iteration_ms` = p10 / p50 / p90 of the per-iteration wall times
+(host sync to host sync) over all windows.  `back_to_back` is the same graph replayed K
+times with no host read in between (round 1's definition), and `train_ppo` is
+`throughput/train_sps` as the drop-in entry point itself reports it on this box.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), with
 `roofline` (dominant kernel, timed live with HIP events on the launch stream)
 and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
@@ -24,31 +37,6 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
-
-CAPTURE_FAILED_RC = 17
-
-
-def _supervise() -> None:
-    """N > 1: every rank's bench runs as a CHILD of this (GPU-free, torch-free)
-    process.  The iteration's RCCL all-reduces are captured into the HIP graph with it;
-    if that capture is refused, the ranks agree on it and exit with CAPTURE_FAILED_RC,
-    and the benchmark is started again with eager launches in a FRESH process — an
-    aborted capture leaves HIP streams unusable, so falling back inside the same
-    process is not reliable (it segfaulted in rehearsal)."""
-    import subprocess
-
-    env = dict(os.environ, MIPPO_BENCH_CHILD="1", MIPPO_BENCH_ATTEMPT="0")
-    cmd = [sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]]
-    rc = subprocess.call(cmd, env=env)
-    if rc == CAPTURE_FAILED_RC and "--eager" not in sys.argv:
-        env["MIPPO_BENCH_ATTEMPT"] = "1"
-        rc = subprocess.call(cmd + ["--eager"], env=env)
-    sys.exit(rc)
-
-
-if (__name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) > 1
-        and os.environ.get("MIPPO_BENCH_CHILD") != "1"):
-    _supervise()
 
 import torch  # noqa: E402
 
@@ -82,7 +70,7 @@ GEMM_SYMBOLS = {
 }
 
 
-def build(device):
+def build(device, state: bool = True):
     from nnx_ppo_amd.algorithms import ppo
     from nnx_ppo_amd.envs import cartpole_shaped
     from nnx_ppo_amd.networks import factories
@@ -92,7 +80,7 @@ def build(device):
     env = EpisodeWrapper(cartpole_shaped(max_steps=1000), 1000)
     net = factories.make_mlp_actor_critic(OBS, ACT, ACTOR_H, CRITIC_H, Rngs(SEED),
                                           normalize_obs=True)
-    ts = ppo.new_training_state(env, net, N_ENVS, SEED, 1e-4, device=device)
+    ts = ppo.new_training_state(env, net, N_ENVS, SEED, 1e-4, device=device) if state else None
     return env, net, ts
 
 
@@ -241,10 +229,11 @@ def roofline_of_dominant_kernel(env, ts):
     return ts, roof, per_kernel
 
 
-def cpu_baseline(iters: int = 2):
+def cpu_baseline(min_seconds: float = 12.0, max_iters: int = 12):
     """The CPU oracle (torch-CPU fp32 restatement of the reference's ppo_step,
-    autograd through the T-step scan) on the same workload, on this box's host
-    cores.  Bounded sample: 1 warm-up + `iters` timed iterations at full C2 size."""
+    autograd through the T-step scan) on the same workload, on ALL of this box's host
+    cores.  Bounded sample: 1 warm-up iteration, then full-size iterations until
+    `min_seconds` of CPU work have been timed (at most `max_iters`)."""
     from nnx_ppo_amd import random as keys
     from nnx_ppo_amd.envs import cartpole_shaped
     from nnx_ppo_amd.networks import factories
@@ -254,24 +243,61 @@ def cpu_baseline(iters: int = 2):
     from oracle import ppo as op
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    threads = min(cores, 16)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(cores)
     net = factories.make_mlp_actor_critic(OBS, ACT, ACTOR_H, CRITIC_H, Rngs(SEED))
     onet = on.from_product(net, torch.float32)
     env = EpisodeWrapper(cartpole_shaped(max_steps=1000), 1000)
     ts = op.new_training_state(env, onet, N_ENVS, SEED, keys)
     ts, _ = op.ppo_step(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, N_EPOCHS, N_MB, keys)
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    times = []
+    while sum(times) < min_seconds and len(times) < max_iters:
+        t0 = time.perf_counter()
         ts, _ = op.ppo_step(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, N_EPOCHS, N_MB, keys)
-    dt = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
     return {
-        "value": round(N_ENVS * T * iters / dt, 1), "unit": "env-steps/s", "cores": threads,
+        "value": round(N_ENVS * T / med, 1), "unit": "env-steps/s", "cores": cores,
         "kind": "port",
-        "sample": f"{iters} timed ppo_step iterations (+1 warm-up) of the CPU oracle at the "
-                  f"full workload ({N_ENVS} envs x {T} steps, {N_EPOCHS}x{N_MB} grad steps), "
-                  "torch-CPU fp32",
+        "sample": f"median of {len(times)} timed ppo_step iterations (+1 warm-up, "
+                  f"{sum(times):.1f} s of CPU work) of the CPU oracle at the full workload "
+                  f"({N_ENVS} envs x {T} steps, {N_EPOCHS}x{N_MB} grad steps), torch-CPU fp32, "
+                  f"{cores} threads",
     }
+
+
+def _pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return float("nan")
+    pos = q * (len(xs) - 1)
+    lo = int(pos)
+    hi = min(lo + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (pos - lo)
+
+
+def train_ppo_throughput(device, compute: str, iterations: int = 45):
+    """`throughput/train_sps` as the drop-in `train_ppo` reports it (fresh state, same
+    workload): median over the iterations after the eager first one and the capture."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.config import EvalConfig, PPOConfig, TrainConfig
+    from nnx_ppo_amd.algorithms.types import LoggingLevel
+
+    env, net, _ = build(device, state=False)
+    cfg = TrainConfig(
+        ppo=PPOConfig(n_envs=N_ENVS, rollout_length=T, total_steps=N_ENVS * T * iterations,
+                      n_epochs=N_EPOCHS, n_minibatches=N_MB, learning_rate=1e-4,
+                      logging_level=LoggingLevel.LOSSES | LoggingLevel.THROUGHPUT),
+        eval=EvalConfig(enabled=False), seed=SEED, checkpoint_every_steps=0)
+    sps = []
+    ppo.train_ppo(env, net, cfg, compute_dtype=compute,
+                  log_fn=lambda m, s: sps.append(float(m["throughput/train_sps"])))
+    steady = sps[5:]
+    return {"train_sps_median": round(_pct(steady, 0.5), 1),
+            "train_sps_p10": round(_pct(steady, 0.1), 1),
+            "train_sps_p90": round(_pct(steady, 0.9), 1), "iterations": len(steady),
+            "note": "train_ppo(..., log_fn=...) with LoggingLevel.THROUGHPUT, eval disabled; "
+                    "first 5 iterations (eager + capture) dropped"}
 
 
 def main():
@@ -280,93 +306,63 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-ppo", action="store_true",
+                    help="skip the cross-check run of train_ppo itself")
+    ap.add_argument("--min-timed-seconds", type=float, default=1.0)
     ap.add_argument("--compute", choices=["f32", "bf16"], default="bf16",
                     help="MFMA path of the Dense layers (BASELINE configs[1] is bf16)")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from Python instead of replaying the captured "
                          "HIP graph of the iteration")
-    ap.add_argument("--capture-collectives", action="store_true",
-                    help="N > 1: capture the RCCL all-reduces INTO the iteration's HIP graph "
-                         "(one graph launch per iteration) instead of the default sequence of "
-                         "graphs with eager collectives between them")
+    ap.add_argument("--transport", choices=["auto", "oneshot", "rccl"], default="auto",
+                    help="N > 1: how gradients / statistics travel.  oneshot = the one-shot "
+                         "peer kernels over IPC-mapped buffers (one HIP graph per iteration); "
+                         "rccl = torch.distributed collectives between HIP-graph segments; "
+                         "auto = oneshot if its self-check against RCCL passes, else rccl")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal on a one-GPU box: MIPPO_DIST_BACKEND=gloo MIPPO_SINGLE_DEVICE=1 runs the
-    # N > 1 code path (collectives through gloo, every rank on cuda:0, eager launches)
+    # N > 1 code path (collectives through gloo, every rank on cuda:0)
     backend = os.environ.get("MIPPO_DIST_BACKEND", "nccl")
     if os.environ.get("MIPPO_SINGLE_DEVICE") == "1":
         local_rank = 0
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    transport = "none"
     if world > 1:
         import datetime
 
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
         # a short timeout: a wedged collective should fail this run, not hang the node
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        # own key prefix per attempt: a second attempt (see _supervise) must not read the
-        # first one's rendezvous keys from the launcher's store
-        agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
-        store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world,
-                              is_master=(rank == 0 and not agent_store),
-                              timeout=datetime.timedelta(seconds=180))
-        store = dist.PrefixStore("mippo_bench_" + os.environ.get("MIPPO_BENCH_ATTEMPT", "0"),
-                                 store)
-        dist.init_process_group(backend, store=store, rank=rank, world_size=world,
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=180), **kw)
+        from nnx_ppo_amd import parallel
+
+        if args.transport in ("auto", "oneshot"):
+            ok, why = parallel.enable_oneshot(device)
+            if not ok:
+                if args.transport == "oneshot":
+                    raise SystemExit(f"[bench] one-shot transport unavailable: {why}")
+                if rank == 0:
+                    print(f"[bench] one-shot transport not used ({why}); RCCL collectives "
+                          "between graph segments", file=sys.stderr)
+        transport = parallel.transport()
     elif args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
 
     from nnx_ppo_amd import config as mi_config
+    from nnx_ppo_amd.algorithms.loop import IterationRunner
 
     mi_config.set_compute_dtype(args.compute)
     env, net, ts = build(device)
-    graphed = None
-    if not args.eager:
-        from nnx_ppo_amd.algorithms.graph import GraphedPPOStep, SegmentedPPOStep
-
-        # N > 1: by default a sequence of graphs with the collectives between them (needs
-        # nothing from RCCL); --capture-collectives records them into ONE graph
-        Recorder = GraphedPPOStep if (world == 1 or args.capture_collectives) else SegmentedPPOStep
-        try:
-            graphed = Recorder(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, False, N_EPOCHS,
-                               N_MB, warmup=2)
-        except Exception as exc:  # capture unsupported for something in the iteration
-            print(f"[bench] rank {rank}: HIP-graph capture failed ({exc!r}); running eager",
-                  file=sys.stderr)
-            graphed = None
-        if world > 1:
-            # every rank must take the same path (the collectives of a replayed graph and
-            # of eager launches pair up only if all ranks issue them the same way)
-            import torch.distributed as dist
-
-            ok = torch.tensor([1 if graphed is not None else 0], dtype=torch.int32)
-            ok = ok.to(device) if backend == "nccl" else ok
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                # start over with eager launches in a fresh process (see _supervise)
-                sys.stderr.flush()
-                os._exit(CAPTURE_FAILED_RC)
-    if graphed is None:
-        args.eager = True
-        ts_box = [ts]
-
-        def run_one():
-            ts_box[0], m = one_iter(env, ts_box[0])
-            return m
-    else:
-        ts_box = [graphed.ts]
-
-        def run_one():
-            ts_, m = graphed()  # no host read: train_ppo counts the steps on the host
-            return m
-    for _ in range(args.warmup):
-        run_one()
+    # a capture failure raises (GraphCaptureError): nothing here falls back to eager
+    # launches by itself — rerun with --eager for that number
+    runner = IterationRunner(lambda st: one_iter(env, st), ts, hip_graph=not args.eager)
 
     def barrier():
         if world > 1:
@@ -375,24 +371,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        metrics = run_one()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def run_window(k: int, stamps=None) -> float:
+        """EXACTLY k iterations as the training loop issues them; returns wall seconds."""
+        barrier()
+        t0 = time.perf_counter()
+        ticket = runner.launch()
+        for i in range(k):
+            nxt = runner.launch() if i + 1 < k else None
+            m = runner.collect(ticket)  # the iteration's host sync
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+            ticket = nxt
+        barrier()
+        run_window.metrics = m
+        return time.perf_counter() - t0
+
+    # warm-up: iteration 1 is eager, iteration 2 records the graph — at least 3 so the
+    # timed region only sees replays
+    warm = max(args.warmup, 1 if args.eager else 3)
+    run_window(warm)
+    # size the repetition count from one untimed window
+    est = run_window(args.steps)
+    reps = max(1, min(200, int(args.min_timed_seconds / max(est, 1e-6)) + 1))
+    windows, iter_ms = [], []
+    for _ in range(reps):
+        stamps = [time.perf_counter()]
+        windows.append(run_window(args.steps, stamps))
+        # the first interval holds the window's launch of its first iteration; the
+        # steady-state intervals are host sync to host sync
+        iter_ms += [(b - a) * 1e3 for a, b in zip(stamps[1:-1], stamps[2:])]
+    metrics = run_window.metrics
+    wt = torch.tensor(windows, dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if backend != "nccl":
+            wt = wt.cpu()
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+    windows = [float(x) for x in wt.cpu()]
+    elapsed = _pct(windows, 0.5)
 
-    roof = per_kernel = None
-    if rank == 0:
-        pass
+    # the same graph replayed back to back, no host read in between (round 1's number)
+    b2b = None
+    if runner._graph is not None:
+        barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(runner.stream):
+            for _ in range(args.steps):
+                runner._graph()
+        barrier()
+        b2b = time.perf_counter() - t0
+
     # instrumented iteration on every rank (collectives must match), reported by rank 0
-    ts, roof, per_kernel = roofline_of_dominant_kernel(env, ts_box[0])
+    ts, roof, per_kernel = roofline_of_dominant_kernel(env, runner.state)
 
     if rank == 0:
         total_env_steps = world * N_ENVS * T * args.steps
@@ -402,7 +433,7 @@ def main():
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": warm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
@@ -416,24 +447,40 @@ def main():
                             f"{N_MB} minibatches, normalize_obs, Adam",
                 "n_envs_per_gpu": N_ENVS, "rollout_length": T,
                 "global_n_envs": world * N_ENVS, "parallelism": f"env-sharded dp{world}",
+                "transport": transport,
             },
-            "launch_mode": "eager" if args.eager else (
-                "hip-graph (one hipGraphLaunch per iteration)"
-                if (world == 1 or args.capture_collectives) else
-                f"{sum(1 for x in graphed.program if isinstance(x, torch.cuda.CUDAGraph))} HIP "
-                f"graphs per iteration with "
-                f"{sum(1 for x in graphed.program if not isinstance(x, torch.cuda.CUDAGraph))} "
-                "eager collectives between them"),
+            "timing": {
+                "definition": "train_ppo's loop: one graph launch + one host sync (metric "
+                              "read) per iteration; window = exactly `steps` iterations "
+                              "between barrier+synchronize pairs, MAX over ranks; value from "
+                              "the median window",
+                "windows": len(windows), "timed_s": round(sum(windows), 3),
+                "window_ms": {"p10": round(_pct(windows, 0.1) * 1e3, 3),
+                              "p50": round(_pct(windows, 0.5) * 1e3, 3),
+                              "p90": round(_pct(windows, 0.9) * 1e3, 3)},
+                "iteration_ms": {"p10": round(_pct(iter_ms, 0.1), 4),
+                                 "p50": round(_pct(iter_ms, 0.5), 4),
+                                 "p90": round(_pct(iter_ms, 0.9), 4), "n": len(iter_ms)},
+            },
+            "back_to_back": None if b2b is None else {
+                "value": round(total_env_steps / b2b, 1),
+                "ms_per_step": round(b2b / args.steps * 1e3, 3),
+                "note": "K graph replays enqueued with no host read, one final synchronise "
+                        "(rank 0's clock)"},
+            "launch_mode": runner.launch_mode,
             "roofline": roof,
             "kernels_ms_per_iter": per_kernel,
             "final_losses": {k: float(v) for k, v in metrics.items() if k.startswith("losses/")},
         }
+        if world == 1 and not args.no_train_ppo and not args.eager:
+            line["train_ppo"] = train_ppo_throughput(device, args.compute)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
 
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -99,6 +99,13 @@ int mi_welford_merge_f32(float* mean, float* m2, float* counter,
                          const float* batch_stats, int64_t F, int advance_counter,
                          mi_stream_t stream);
 
+/* a17 — `compute_metrics` / `_log_metric`, `nnx_ppo/algorithms/metrics.py:17-100`, for the
+ * LOSSES family: x is row-major [R, C] (one row per gradient step, one column per loss
+ * term); out[0][c] = mean_r(scale * x[r][c]), out[1][c] = population std (as `jp.std`).
+ * fp64 accumulation in row order.  `scale` = 1 / world_size after a sum all-reduce. */
+int mi_col_mean_std_f32(const float* x, int64_t R, int64_t C, float scale, float* out,
+                        mi_stream_t stream);
+
 /* ---- a10: tanh-Gaussian sampler ---------------------------------------- */
 
 /* NormalTanhSampler.__call__, `nnx_ppo/networks/sampling_layers.py:82-147`.

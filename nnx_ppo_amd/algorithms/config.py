@@ -53,12 +53,25 @@ class VideoConfig:
 
 
 @dataclass
+class BackendConfig:
+    """Not in the reference: what `nnx.jit` / XLA decide there is chosen here.
+    `compute_dtype` None = the process-wide `nnx_ppo_amd.config.compute_dtype()`;
+    `hip_graph` = replay the iteration as one captured HIP graph (the `nnx.jit(ppo_step)`
+    of ppo.py:105); `overlap_logging` = enqueue iteration i+1 before the host waits for
+    iteration i's metrics when no eval / video / checkpoint is due (algorithms/loop.py)."""
+    compute_dtype: Optional[str] = None
+    hip_graph: bool = True
+    overlap_logging: bool = True
+
+
+@dataclass
 class TrainConfig:
     ppo: PPOConfig = field(default_factory=PPOConfig)
     eval: EvalConfig = field(default_factory=EvalConfig)
     video: VideoConfig = field(default_factory=VideoConfig)
     seed: int = 17
     checkpoint_every_steps: int = 500_000
+    backend: BackendConfig = field(default_factory=BackendConfig)
 
 
 @dataclass
@@ -99,6 +112,7 @@ class DistillationTrainConfig:
     video: VideoConfig = field(default_factory=VideoConfig)
     seed: int = 17
     checkpoint_every_steps: int = 500_000
+    backend: BackendConfig = field(default_factory=BackendConfig)
 
 
 @dataclass

@@ -10,12 +10,14 @@ loss has no launch of its own — its gradient with respect to every log-likelih
 constant -1/(T B) and with respect to every regulariser element +1/(T B)."""
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 from collections.abc import Callable
 from typing import Any, Optional
 
 import torch
 
+from .. import config as mi_config
 from .. import ops
 from .. import random as rnd
 from ..networks.types import PPONetworkOutput, StatefulModule, bump_param_epoch
@@ -23,6 +25,7 @@ from ..optim import Optimizer
 from ..tree import tree_leaves, tree_map
 from . import rollout
 from .config import (DistillationTrainConfig, DistillationTrainResult, VideoData)
+from .loop import IterationRunner, run_training_loop
 from .metrics import _log_metric
 from .ppo import _advance_noise, _should_run, minibatch_indices
 from .rollout import _as_bool, tree_where
@@ -271,9 +274,13 @@ def train_distillation(
     checkpoint_fn: Optional[Callable[[DistillationState, int], None]] = None,
     eval_env=None,
     initial_state: Optional[DistillationState] = None,
+    compute_dtype: Optional[str] = None,
+    hip_graph: Optional[bool] = None,
+    overlap_logging: Optional[bool] = None,
 ) -> DistillationTrainResult:
     """distillation.py:420-603.  The teacher is put in eval (deterministic) mode, so its
-    samplers emit their mean; the student is trained in place."""
+    samplers emit their mean; the student is trained in place.  `compute_dtype`,
+    `hip_graph`, `overlap_logging`: as in `train_ppo` (they override `config.backend`)."""
     if config is None:
         config = default_distillation_config()
     if total_steps is not None:
@@ -284,6 +291,21 @@ def train_distillation(
         config = dataclasses.replace(config, seed=seed)
     if eval_env is None:
         eval_env = env
+    backend = config.backend
+    compute_dtype = backend.compute_dtype if compute_dtype is None else compute_dtype
+    hip_graph = backend.hip_graph if hip_graph is None else hip_graph
+    overlap_logging = backend.overlap_logging if overlap_logging is None else overlap_logging
+    dtype_ctx = (mi_config.use_compute_dtype(compute_dtype) if compute_dtype is not None
+                 else contextlib.nullcontext())
+    with dtype_ctx:
+        return _train_distillation(env, teacher, student, config, log_fn, checkpoint_fn,
+                                   eval_env, initial_state, bool(hip_graph),
+                                   bool(overlap_logging))
+
+
+def _train_distillation(env, teacher, student, config, log_fn, checkpoint_fn, eval_env,
+                        initial_state, hip_graph: bool,
+                        overlap: bool) -> DistillationTrainResult:
     teacher.eval()
     dc = config.distillation
     if initial_state is None:
@@ -298,7 +320,6 @@ def train_distillation(
     last_eval_step = -config.eval.every_steps
     last_checkpoint_step = -config.checkpoint_every_steps
     metrics: dict = {}
-    n_iterations = 0
 
     def run_eval(steps: int) -> dict:
         student.eval()
@@ -323,29 +344,32 @@ def train_distillation(
     if log_fn is not None and metrics:
         log_fn(metrics, steps)
 
-    steps_per_iteration = dc.rollout_length * dc.n_envs  # host mirror of `steps_taken`
-    while steps < dc.total_steps:
-        distillation_state, metrics = distillation_step(
-            env, teacher, distillation_state, dc.n_envs, dc.rollout_length, dc.n_epochs,
-            dc.n_minibatches, dc.logging_level, dc.logging_percentiles)
-        n_iterations += 1
-        steps += steps_per_iteration
-        if config.eval.enabled and _should_run(steps, last_eval_step, config.eval.every_steps):
-            eval_metrics = run_eval(steps)
-            metrics.update(eval_metrics)
-            eval_history.append({"step": steps, **eval_metrics})
-            last_eval_step = steps
-        if checkpoint_fn is not None and _should_run(steps, last_checkpoint_step,
-                                                     config.checkpoint_every_steps):
-            checkpoint_fn(distillation_state, steps)
-            last_checkpoint_step = steps
-        if log_fn is not None:
-            log_fn(metrics, steps)
-
+    step_fn = lambda st: distillation_step(
+        env, teacher, st, dc.n_envs, dc.rollout_length, dc.n_epochs, dc.n_minibatches,
+        dc.logging_level, dc.logging_percentiles)
+    runner = IterationRunner(step_fn, distillation_state, hip_graph=hip_graph,
+                             networks=[student, teacher])
+    loop_metrics, steps, n_iterations = run_training_loop(
+        runner, total_steps=dc.total_steps, steps=steps,
+        steps_per_iteration=dc.rollout_length * dc.n_envs,  # host mirror of `steps_taken`
+        local_steps_per_iteration=dc.rollout_length * dc.n_envs,
+        measure_throughput=LoggingLevel.THROUGHPUT in dc.logging_level,
+        eval_every=config.eval.every_steps, video_every=0,
+        checkpoint_every=config.checkpoint_every_steps,
+        last_eval_step=last_eval_step, last_video_step=0,
+        last_checkpoint_step=last_checkpoint_step,
+        run_eval=run_eval if config.eval.enabled else None, run_video=None,
+        checkpoint_fn=checkpoint_fn, log_fn=log_fn, eval_history=eval_history,
+        overlap=overlap)
+    if n_iterations:
+        metrics = loop_metrics
+    distillation_state = runner.state
+    device_steps = int(distillation_state.steps_taken)
+    assert device_steps == steps, (device_steps, steps)
     return DistillationTrainResult(
         training_state=distillation_state,
         final_metrics=metrics,
         eval_history=eval_history,
-        total_steps=int(distillation_state.steps_taken),
+        total_steps=device_steps,
         total_iterations=n_iterations,
     )

@@ -12,6 +12,34 @@ import torch
 from .types import LoggingLevel, Transition
 
 
+_PCT_CACHE: dict = {}
+
+
+def percentiles(x: torch.Tensor, levels: tuple) -> torch.Tensor:
+    """`jp.percentile(x, levels)` (linear interpolation between order statistics) from one
+    sort.  The interpolation indices and weights depend on (levels, x.numel()) only, so
+    they are built once per device and cached: nothing is copied from the host when the
+    call is replayed inside a captured HIP graph, and — unlike `torch.quantile` — there is
+    no 16M-element limit."""
+    flat = x.float().reshape(-1)
+    n = flat.numel()
+    key = (tuple(float(l) for l in levels), n, str(flat.device))
+    c = _PCT_CACHE.get(key)
+    if c is None:
+        pos = [min(max(float(l), 0.0), 100.0) / 100.0 * (n - 1) for l in levels]
+        lo = [int(p) for p in pos]
+        hi = [min(i + 1, n - 1) for i in lo]
+        w = [p - i for p, i in zip(pos, lo)]
+        c = (torch.tensor(lo, dtype=torch.int64, device=flat.device),
+             torch.tensor(hi, dtype=torch.int64, device=flat.device),
+             torch.tensor(w, dtype=torch.float32, device=flat.device))
+        _PCT_CACHE[key] = c
+    lo, hi, w = c
+    s = flat.sort().values
+    a, b = s[lo], s[hi]
+    return a + (b - a) * w
+
+
 def _log_metric(metrics: dict, name: str, x: Any,
                 percentile_levels: Optional[tuple] = None) -> None:
     """metrics.py:72-100."""
@@ -29,8 +57,7 @@ def _log_metric(metrics: dict, name: str, x: Any,
         metrics[f"{name}/mean"] = mu
         metrics[f"{name}/std"] = sd
     else:
-        q = torch.tensor(percentile_levels, dtype=torch.float32, device=x.device) / 100.0
-        pct = torch.quantile(x.float().reshape(-1), q)
+        pct = percentiles(x, tuple(percentile_levels))
         for pl, p in zip(percentile_levels, pct):
             metrics[f"{name}/p{int(pl)}"] = p
 

@@ -15,6 +15,7 @@ HIP kernels of libmippo:
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import time
 from collections.abc import Callable
@@ -22,6 +23,7 @@ from typing import Any, Optional
 
 import torch
 
+from .. import config as mi_config
 from .. import ops, parallel
 from .. import random as rnd
 from ..networks.adapter import _Fork, _can_fork
@@ -29,8 +31,9 @@ from ..networks.types import PPONetworkOutput, StatefulModule, bump_param_epoch
 from ..optim import Optimizer
 from ..tree import tree_leaves, tree_map
 from . import rollout
-from .config import (EvalConfig, PPOConfig, TrainConfig, TrainResult, VideoConfig,  # noqa: F401
-                     VideoData)
+from .config import (BackendConfig, EvalConfig, PPOConfig, TrainConfig,  # noqa: F401
+                     TrainResult, VideoConfig, VideoData)
+from .loop import IterationRunner, run_training_loop, should_run
 from .metrics import compute_metrics, log_weight_stats
 from .types import LoggingLevel, TrainingState, Transition
 
@@ -41,9 +44,7 @@ def default_config() -> TrainConfig:
 
 def _should_run(steps: int, last_step: int, every_steps: int) -> bool:
     """ppo.py:34-38."""
-    if every_steps <= 0:
-        return False
-    return (steps // every_steps) > (last_step // every_steps)
+    return should_run(steps, last_step, every_steps)
 
 
 def train_ppo(
@@ -58,8 +59,25 @@ def train_ppo(
     checkpoint_fn: Optional[Callable[[TrainingState, int], None]] = None,
     eval_env=None,
     initial_state: Optional[TrainingState] = None,
+    compute_dtype: Optional[str] = None,
+    hip_graph: Optional[bool] = None,
+    overlap_logging: Optional[bool] = None,
 ) -> TrainResult:
-    """ppo.py:41-251.  `networks` is trained in place."""
+    """ppo.py:41-251.  `networks` is trained in place.
+
+    The three trailing keywords (and `TrainConfig.backend`, which they override) are this
+    build's counterpart of what `nnx.jit` decides for the reference:
+      compute_dtype   "f32" | "bf16": MFMA path of the Dense layers (BASELINE configs[1]
+                      is quoted in bf16); default: the process-wide `nnx_ppo_amd.config`.
+      hip_graph       True (default): iteration 1 runs eagerly, iteration 2 is recorded
+                      into a HIP graph, later ones are one `hipGraphLaunch` each — the
+                      role of `nnx.jit(ppo_step)` (ppo.py:105).  An env or module that
+                      cannot be captured raises `GraphCaptureError`; pass False for it.
+      overlap_logging True (default): iteration i+1 is enqueued before the host waits
+                      for iteration i's metrics whenever no eval / video / checkpoint is
+                      due in between (`algorithms/loop.py`).
+    `log_fn` receives 0-d CPU tensors (one device-to-host copy per iteration — the host
+    sync of ppo.py:209)."""
     if config is None:
         config = default_config()
     if total_steps is not None:
@@ -69,7 +87,22 @@ def train_ppo(
         config = dataclasses.replace(config, seed=seed)
     if eval_env is None:
         eval_env = env
+    backend = config.backend
+    if compute_dtype is None:
+        compute_dtype = backend.compute_dtype
+    if hip_graph is None:
+        hip_graph = backend.hip_graph
+    if overlap_logging is None:
+        overlap_logging = backend.overlap_logging
+    dtype_ctx = (mi_config.use_compute_dtype(compute_dtype) if compute_dtype is not None
+                 else contextlib.nullcontext())
+    with dtype_ctx:
+        return _train_ppo(env, networks, config, log_fn, video_fn, checkpoint_fn, eval_env,
+                          initial_state, bool(hip_graph), bool(overlap_logging))
 
+
+def _train_ppo(env, networks, config, log_fn, video_fn, checkpoint_fn, eval_env, initial_state,
+               hip_graph: bool, overlap: bool) -> TrainResult:
     if initial_state is None:
         training_state = new_training_state(
             env, networks, config.ppo.n_envs, config.seed, config.ppo.learning_rate,
@@ -83,7 +116,6 @@ def train_ppo(
     last_video_step = -config.video.every_steps
     last_checkpoint_step = -config.checkpoint_every_steps
     metrics: dict = {}
-    n_iterations = 0
     measure_throughput = LoggingLevel.THROUGHPUT in config.ppo.logging_level
 
     def run_eval(steps: int) -> dict:
@@ -113,7 +145,7 @@ def train_ppo(
         eval_history.append({"step": steps, **eval_metrics})
         last_eval_step = steps
     if config.video.enabled:
-        metrics.update(run_video(steps, n_iterations))
+        metrics.update(run_video(steps, 0))
         last_video_step = steps
     if checkpoint_fn is not None and _should_run(steps, last_checkpoint_step,
                                                  config.checkpoint_every_steps):
@@ -122,44 +154,32 @@ def train_ppo(
     if log_fn is not None and metrics:
         log_fn(metrics, steps)
 
+    c = config.ppo
+    step_fn = lambda ts: ppo_step(
+        env, ts, c.n_envs, c.rollout_length, c.gae_lambda, c.discounting_factor, c.clip_range,
+        c.normalize_advantages, c.combine_advantages, c.n_epochs, c.n_minibatches,
+        c.critic_loss_weight, c.logging_level, c.logging_percentiles)
+    runner = IterationRunner(step_fn, training_state, hip_graph=hip_graph,
+                             networks=[networks])
     # `steps_taken` advances by the same constant every iteration (ppo.py:338), so the loop
-    # counts it on the host: reading the device scalar each iteration (ppo.py:209) would
-    # drain the GPU queue once per iteration for a number the host already knows
-    steps_per_iteration = config.ppo.rollout_length * config.ppo.n_envs * parallel.world_size()
-    while steps < config.ppo.total_steps:
-        t0 = time.perf_counter() if measure_throughput else None
-        training_state, metrics = ppo_step(
-            env, training_state, config.ppo.n_envs, config.ppo.rollout_length,
-            config.ppo.gae_lambda, config.ppo.discounting_factor, config.ppo.clip_range,
-            config.ppo.normalize_advantages, config.ppo.combine_advantages,
-            config.ppo.n_epochs, config.ppo.n_minibatches, config.ppo.critic_loss_weight,
-            config.ppo.logging_level, config.ppo.logging_percentiles)
-        n_iterations += 1
-        steps += steps_per_iteration
-        if measure_throughput:
-            if device.type == "cuda":
-                torch.cuda.synchronize(device)
-            elapsed = time.perf_counter() - t0
-            metrics["throughput/train_sps"] = (
-                config.ppo.n_envs * config.ppo.rollout_length / elapsed)
-
-        if config.eval.enabled and _should_run(steps, last_eval_step, config.eval.every_steps):
-            eval_metrics = run_eval(steps)
-            metrics.update(eval_metrics)
-            eval_history.append({"step": steps, **eval_metrics})
-            last_eval_step = steps
-        if config.video.enabled and _should_run(steps, last_video_step,
-                                                config.video.every_steps):
-            metrics.update(run_video(steps, n_iterations))
-            last_video_step = steps
-        if checkpoint_fn is not None and _should_run(steps, last_checkpoint_step,
-                                                     config.checkpoint_every_steps):
-            checkpoint_fn(training_state, steps)
-            last_checkpoint_step = steps
-        if log_fn is not None:
-            log_fn(metrics, steps)
-
-    device_steps = int(training_state.steps_taken)  # the one host read of the run
+    # counts it on the host and checks it against the device counter once, at the end
+    loop_metrics, steps, n_iterations = run_training_loop(
+        runner, total_steps=c.total_steps, steps=steps,
+        steps_per_iteration=c.rollout_length * c.n_envs * parallel.world_size(),
+        local_steps_per_iteration=c.rollout_length * c.n_envs,
+        measure_throughput=measure_throughput,
+        eval_every=config.eval.every_steps, video_every=config.video.every_steps,
+        checkpoint_every=config.checkpoint_every_steps,
+        last_eval_step=last_eval_step, last_video_step=last_video_step,
+        last_checkpoint_step=last_checkpoint_step,
+        run_eval=run_eval if config.eval.enabled else None,
+        run_video=run_video if config.video.enabled else None,
+        checkpoint_fn=checkpoint_fn, log_fn=log_fn, eval_history=eval_history,
+        overlap=overlap)
+    if n_iterations:
+        metrics = loop_metrics
+    training_state = runner.state
+    device_steps = int(training_state.steps_taken)  # the one host read of the counter
     assert device_steps == steps, (device_steps, steps)
     return TrainResult(
         training_state=training_state,
@@ -244,10 +264,11 @@ def ppo_step(
         metrics={}, rollout_extras=rollout_data.rollout_extras)
 
     device = rollout_data.done.device
-    loss_rows = torch.zeros(total_iterations, 4, dtype=torch.float32, device=device)
+    # every entry is written by the loss launch of its gradient step: no zero-fill launch
+    loss_rows = torch.empty(total_iterations, 4, dtype=torch.float32, device=device)
     grad_norms = None
     if LoggingLevel.GRAD_NORM in logging_level:
-        grad_norms = torch.zeros(total_iterations, dtype=torch.float32, device=device)
+        grad_norms = torch.empty(total_iterations, dtype=torch.float32, device=device)
 
     critic_extra: dict = {}
     # minibatch gather x[:, inds] (ppo.py:297-300).  The indices of every gradient step are
@@ -279,33 +300,51 @@ def ppo_step(
                          normalize_advantages, combine_advantages, discounting_factor,
                          gae_lambda, critic_loss_weight, logging_level, loss_out=loss_rows[i],
                          want_total=False)
-        for k in ("losses/advantages", "losses/critic_R^2"):
-            if k in lm:
-                critic_extra.setdefault(k, []).append(lm[k])
-        have_norm = False
-        if grad_norms is not None:
-            grad_norms[i:i + 1].copy_(optimizer.compute_grad_norm())
-            have_norm = True
-        optimizer.update(have_norm=have_norm)
+        for k, v in lm.items():
+            # per-step diagnostics that are not columns of `loss_rows`: CRITIC_EXTRA, and
+            # the per-key trees of a PyTree reward / value / log-likelihood setup
+            if k in ("losses/advantages", "losses/critic_R^2") or not isinstance(v, torch.Tensor):
+                critic_extra.setdefault(k, []).append(v)
+        # GRAD_NORM (ppo.py:313-315): the norm of the gradient the optimiser applies,
+        # written straight into its row (sharded: taken after the all-reduce)
+        optimizer.update(norm_out=None if grad_norms is None else grad_norms[i:i + 1])
 
+    scale = 1.0
     if parallel.is_distributed():
         parallel.allreduce_sum_(loss_rows)
-        loss_rows = loss_rows / parallel.world_size()
+        scale = 1.0 / parallel.world_size()
 
-    loss_metrics: dict = {}
+    # metrics.py:72-100 for the loss rows: mean / population std over the gradient steps of
+    # all four columns in ONE launch (percentiles, when asked for, go through `_log_metric`)
+    names = []
     if LoggingLevel.LOSSES in logging_level:
-        loss_metrics["losses/actor"] = loss_rows[:, 0]
-        loss_metrics["losses/critic"] = loss_rows[:, 1]
-        loss_metrics["losses/regularization"] = loss_rows[:, 2]
+        names += [(0, "losses/actor"), (1, "losses/critic"), (2, "losses/regularization")]
     if LoggingLevel.ACTOR_EXTRA in logging_level:
-        loss_metrics["losses/clipping_fraction"] = loss_rows[:, 3]
+        names += [(3, "losses/clipping_fraction")]
+    loss_metrics: dict = {}
+    ready: dict = {}
+    if names and not logging_percentiles:
+        ms = ops.col_mean_std(loss_rows, scale)
+        for col, name in names:
+            ready[f"{name}/mean"] = ms[0, col]
+            ready[f"{name}/std"] = ms[1, col]
+    else:
+        rows = loss_rows if scale == 1.0 else loss_rows * scale
+        for col, name in names:
+            loss_metrics[name] = rows[:, col]
     if grad_norms is not None:
         loss_metrics["grad_norm"] = grad_norms
     for k, v in critic_extra.items():  # stacked over the gradient steps, as the scan does
-        loss_metrics[k] = torch.stack(v, dim=0)
+        loss_metrics[k] = tree_map(lambda *xs: torch.stack(xs, dim=0), v[0], *v[1:])
+        # a per-key tree (PyTree rewards / values / log-likelihoods) replaces the summed
+        # column of the same name
+        ready.pop(f"{k}/mean", None)
+        ready.pop(f"{k}/std", None)
 
     total_steps = training_state.steps_taken + rollout_length * n_envs * parallel.world_size()
-    metrics = compute_metrics(loss_metrics, rollout_data, logging_level, logging_percentiles)
+    metrics = dict(ready)
+    metrics.update(compute_metrics(loss_metrics, rollout_data, logging_level,
+                                   logging_percentiles))
     metrics["total_steps"] = total_steps
     if LoggingLevel.WEIGHTS in logging_level:
         # the parameters themselves, not the arena (its alignment padding is zeros)
@@ -394,10 +433,10 @@ def ppo_loss(
     single = (isinstance(rewards, torch.Tensor) and isinstance(values, torch.Tensor)
               and isinstance(ll_new, torch.Tensor))
     if not single:
-        g_ll, g_v, loss_out = _pytree_loss_terms(
+        g_ll, g_v, loss_out, detail = _pytree_loss_terms(
             rewards, values, last_values, ll_new, ll_old, reg_seq, done, truncated,
             clip_range, normalize_advantages, combine_advantages, discounting_factor,
-            gae_lambda, critic_loss_weight, loss_out)
+            gae_lambda, critic_loss_weight, loss_out, logging_level)
         if backward:
             networks.replay_backward(
                 ctx, PPONetworkOutput(actions=None, loglikelihoods=g_ll, value_estimates=g_v),
@@ -444,6 +483,8 @@ def ppo_loss(
         loss_metrics["losses/regularization"] = loss_out[2]
     if LoggingLevel.ACTOR_EXTRA in logging_level:
         loss_metrics["losses/clipping_fraction"] = loss_out[3]
+    if not single:
+        loss_metrics.update(detail)  # per-key trees replace the summed scalars
     total = None
     if want_total:  # three tiny launches: the training loop reads `loss_out` instead
         total = loss_out[0] + critic_loss_weight * loss_out[1] + loss_out[2]
@@ -452,7 +493,7 @@ def ppo_loss(
 
 def _pytree_loss_terms(rewards, values, last_values, ll_new, ll_old, reg_seq, done, truncated,
                        clip_range, normalize_advantages, combine_advantages, gamma, lambda_,
-                       critic_loss_weight, loss_out):
+                       critic_loss_weight, loss_out, logging_level=LoggingLevel.NONE):
     """ppo.py:440-510 for PyTree rewards / value heads / log-likelihoods.
 
     One GAE per reward key (`done` / `truncated` are shared, ppo.py:440-445); the critic
@@ -462,7 +503,7 @@ def _pytree_loss_terms(rewards, values, last_values, ll_new, ll_old, reg_seq, do
     ppo.py:462-474); each advantage tree leaf is normalised on its own (477-480).
     One loss launch per leaf; the scalars are summed (`jax.tree.reduce`, 505-507).
     Returns (g_ll tree, g_v tree, loss_out[4] = summed actor, critic, reg, mean clip
-    fraction)."""
+    fraction, detail = the per-key metric trees of ppo.py:509-528)."""
     T, B = done.shape
     d_, t_ = done.contiguous(), truncated.contiguous()
     adv = tree_map(
@@ -473,15 +514,18 @@ def _pytree_loss_terms(rewards, values, last_values, ll_new, ll_old, reg_seq, do
     if loss_out is None:
         loss_out = torch.empty(4, dtype=torch.float32, device=dev)
     parts = []
+    detail: dict = {}
     # critic terms, per reward key, on the raw advantages
 
     def critic(v, a):
         _, gv, lo = ops.ppo_loss(None, None, a.reshape(-1), v.contiguous().reshape(-1), None,
                                  None, clip_range, critic_loss_weight)
         parts.append(lo)
-        return gv.view(T, B)
+        return gv.view(T, B), lo
 
-    g_v = tree_map(critic, values, adv)
+    cr = tree_map(critic, values, adv)
+    g_v = _tree_pick(cr, values, 0)
+    critic_rows = _tree_pick(cr, values, 1)
     # actor advantages
     if combine_advantages:
         leaves = tree_leaves(adv)
@@ -513,9 +557,11 @@ def _pytree_loss_terms(rewards, values, last_values, ll_new, ll_old, reg_seq, do
                                  a.contiguous().reshape(-1), None, reg, stats, clip_range,
                                  critic_loss_weight)
         parts.append(lo)
-        return gl.view(T, B)
+        return gl.view(T, B), lo
 
-    g_ll = tree_map(actor, ll_new, ll_old, actor_adv)
+    ac = tree_map(actor, ll_new, ll_old, actor_adv)
+    g_ll = _tree_pick(ac, ll_new, 0)
+    actor_rows = _tree_pick(ac, ll_new, 1)
     n_actor = len(tree_leaves(ll_new))
     total = parts[0]
     for p_ in parts[1:]:
@@ -523,7 +569,27 @@ def _pytree_loss_terms(rewards, values, last_values, ll_new, ll_old, reg_seq, do
     loss_out.copy_(total)
     if n_actor > 1:
         loss_out[3:4].div_(float(n_actor))  # clipping fraction: mean over the policy terms
-    return g_ll, g_v, loss_out
+    # the per-key trees the reference logs (ppo.py:509-528)
+    if LoggingLevel.LOSSES in logging_level:
+        detail["losses/actor"] = tree_map(lambda r: r[0], actor_rows)
+        detail["losses/critic"] = tree_map(lambda r: r[1], critic_rows)
+    if LoggingLevel.ACTOR_EXTRA in logging_level:
+        detail["losses/clipping_fraction"] = tree_map(lambda r: r[3], actor_rows)
+    if LoggingLevel.CRITIC_EXTRA in logging_level:
+        def norm(a):
+            return (a - a.mean()) / (a.std(unbiased=False) + 1e-8) if normalize_advantages else a
+
+        detail["losses/advantages"] = tree_map(norm, actor_adv)
+        detail["losses/critic_R^2"] = tree_map(
+            lambda r, v, a: 1.0 - 2.0 * r[1] / ((v + a).var(unbiased=False) + 1e-8),
+            critic_rows, values, adv)
+    return g_ll, g_v, loss_out, detail
+
+
+def _tree_pick(pairs_tree, like, i: int):
+    """`pairs_tree` has the structure of `like` with a tuple at every leaf: pick item i."""
+    it = iter(tree_leaves(pairs_tree, is_leaf=lambda x: isinstance(x, tuple)))
+    return tree_map(lambda _: next(it)[i], like)
 
 
 def new_training_state(

@@ -172,8 +172,9 @@ def _add_reward_metrics(out: dict, name: str, reward: Any,
         for k, v in reward.items():
             _add_reward_metrics(out, f"{name}/{k}", v, percentile_levels)
     elif percentile_levels is not None:
-        q = torch.tensor(percentile_levels, dtype=torch.float32, device=reward.device) / 100.0
-        pct = torch.quantile(reward.float(), q)
+        from .metrics import percentiles
+
+        pct = percentiles(reward, tuple(percentile_levels))
         for pl, p in zip(percentile_levels, pct):
             out[f"{name}/p{int(pl)}"] = p
     else:
@@ -206,7 +207,9 @@ def eval_rollout(env, networks: StatefulModule, n_envs: int, max_episode_length:
     metrics = dict(lifespan_mean=lifespan.mean(), lifespan_std=lifespan.std(unbiased=False))
     _add_reward_metrics(metrics, "episode_reward", cuml_reward, logging_percentiles)
     if logging_percentiles is not None:
-        q = torch.tensor(logging_percentiles, dtype=torch.float32, device=dev) / 100.0
-        for pl, p in zip(logging_percentiles, torch.quantile(lifespan, q)):
+        from .metrics import percentiles
+
+        for pl, p in zip(logging_percentiles,
+                         percentiles(lifespan, tuple(logging_percentiles))):
             metrics[f"lifespan/p{int(pl)}"] = p
     return metrics

@@ -200,6 +200,39 @@ extern "C" int mi_normalize_bwd_f32(const float* g_out, const float* m2,
   return mippo::check_launch("mi_normalize_bwd_f32");
 }
 
+namespace {
+// a17: mean / population std of every column of a small row-major [R][C] matrix (the
+// per-gradient-step loss rows of an iteration), fp64 accumulation in row order.  One
+// thread per column; R is the number of gradient steps (16), so this is one tiny launch
+// in place of one torch `std_mean` launch per metric.
+__global__ void __launch_bounds__(64)
+col_mean_std_kernel(const float* __restrict__ x, int64_t R, int64_t C, float scale,
+                    float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int64_t r = 0; r < R; ++r) s += (double)(x[r * C + c] * scale);
+  const double mean = s / (double)R;
+  double q = 0.0;
+  for (int64_t r = 0; r < R; ++r) {
+    const double d = (double)(x[r * C + c] * scale) - mean;
+    q += d * d;
+  }
+  out[c] = (float)mean;
+  out[C + c] = (float)sqrt(q / (double)R);
+}
+}  // namespace
+
+extern "C" int mi_col_mean_std_f32(const float* x, int64_t R, int64_t C, float scale,
+                                   float* out, mi_stream_t stream) {
+  MI_REQUIRE(R >= 1 && C >= 1, "mi_col_mean_std_f32: bad shape R=%lld C=%lld", (long long)R,
+             (long long)C);
+  MI_REQUIRE(x && out, "mi_col_mean_std_f32: null pointer");
+  hipLaunchKernelGGL(col_mean_std_kernel, dim3((unsigned)mippo::ceil_div(C, 64)), dim3(64), 0,
+                     mippo::as_stream(stream), x, R, C, scale, out);
+  return mippo::check_launch("mi_col_mean_std_f32");
+}
+
 static int welford_chunks(int64_t M) {
   int64_t g = mippo::ceil_div(M, 256);  // >= 256 rows per partial
   if (g > 512) g = 512;

@@ -135,6 +135,17 @@ def welford_merge(mean, m2, counter, batch_stats, advance_counter: bool) -> None
                                      stream()), "mi_welford_merge_f32")
 
 
+def col_mean_std(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """[2, C] = (mean, population std) of every column of a small [R, C] fp32 matrix."""
+    _need(x.dim() == 2 and x.dtype == f32 and x.shape[0] >= 1 and x.is_contiguous(),
+          "col_mean_std: x must be a contiguous [R, C] f32 matrix")
+    R, C = x.shape
+    out = torch.empty(2, C, dtype=f32, device=x.device)
+    check(lib().mi_col_mean_std_f32(ptr(x, f32), R, C, float(scale), ptr(out, f32), stream()),
+          "mi_col_mean_std_f32")
+    return out
+
+
 # ----------------------------------------------------------- a10: sampler
 def tanh_gauss_fwd(mean_and_std, extras, rng_state, offset_add: int, *, min_std: float,
                    std_scale: float, entropy_weight: float, deterministic: bool,

@@ -74,17 +74,24 @@ class Optimizer:
             ops.begin_grad_step(self.grads, None)
         self._clean = False
 
-    def compute_grad_norm(self) -> torch.Tensor:
-        return ops.global_norm(self.grads, out=self.grad_norm)
+    def compute_grad_norm(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.global_norm(self.grads, out=self.grad_norm if out is None else out)
 
-    def update(self, have_norm: bool = False) -> None:
-        """All-reduce (if sharded), optional global-norm clip, Adam(W)."""
+    def update(self, have_norm: bool = False, norm_out: Optional[torch.Tensor] = None) -> None:
+        """All-reduce (if sharded), optional global-norm clip, Adam(W).  `norm_out`
+        (float32 [1]) receives the global norm of the gradient that is applied — in a
+        sharded run the norm AFTER the all-reduce, the one `clip_by_global_norm` sees
+        (`ppo.py:313-316`).  `have_norm`: `self.grad_norm` already holds it (single GPU)."""
         if parallel.is_distributed():
             parallel.allreduce_mean_(self.grads)
             have_norm = False
         gn = None
-        if self.gradient_clipping is not None:
+        if norm_out is not None:
+            gn = self.compute_grad_norm(norm_out)
+        elif self.gradient_clipping is not None:
             gn = self.grad_norm if have_norm else self.compute_grad_norm()
+        if self.gradient_clipping is None:
+            gn = None  # logged only: the Adam launch must not clip
         # Dense kernels with bf16 shadows get the new values written into the shadows by
         # the same launch (up to 16 layers; the rest refresh lazily at their next use)
         from .networks import dense_chain

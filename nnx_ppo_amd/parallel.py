@@ -30,6 +30,17 @@ def rank() -> int:
     return dist.get_rank() if is_distributed() else 0
 
 
+# How the exchanges travel: "rccl" = torch.distributed collectives (RCCL on GPUs, gloo in
+# the CPU tests); "oneshot" = the one-shot peer kernels over IPC-mapped buffers
+# (`comm.py`, csrc/comm.hip) — plain kernel launches, so a sharded iteration is ONE HIP
+# graph.  `enable_oneshot()` switches after verifying the peer path against RCCL.
+_transport = "rccl"
+
+
+def transport() -> str:
+    return _transport if is_distributed() else "none"
+
+
 # While an iteration is being recorded as a SEQUENCE of HIP graphs
 # (algorithms/graph.py:SegmentedPPOStep) the recorder sits here: every collective
 # closes the graph being captured, runs eagerly, and opens the next one.
