@@ -34,7 +34,8 @@ typedef void* mi_stream_t; /* hipStream_t */
 
 /* Activation codes shared by the dense / MLP entry points
  * (`nnx_ppo/networks/factories.py:107-110`: relu | swish | tanh; 0 = none). */
-enum { MI_ACT_NONE = 0, MI_ACT_RELU = 1, MI_ACT_TANH = 2, MI_ACT_SWISH = 3 };
+enum { MI_ACT_NONE = 0, MI_ACT_RELU = 1, MI_ACT_TANH = 2, MI_ACT_SWISH = 3,
+       MI_ACT_SIGMOID = 4 /* LSTM gate functions only */ };
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -334,27 +335,37 @@ int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_pre
 
 /* The recurrence of the reference's LSTM layer over a whole sequence with
  * reset-on-done (`ppo.py:411-413`): a = gi[t] + h W_h (gate order i, f, g, o),
- * c' = f c + i g, h' = o tanh(c'); carry <- done[t] ? 0 : (h', c').
+ * c' = f c + i g, h' = o act(c'); carry <- done[t] ? (h_init, c_init) : (h', c').
  * gi [T,B,4H] = x W_i + b_h (a time-batched dense launch); w_h [H,4H]; h0, c0 [B,H];
- * done [T,B] nullable.  Outputs: h_out [T,B,H]; training (nullable): h_prev_out,
- * c_prev_out [T,B,H] (the carry entering each step) and gates_out [T,B,5H] =
- * (i, f, g, o, tanh(c')); h_final, c_final [B,H].  H <= 256. */
+ * done [T,B] nullable.  h_init, c_init [H]: the learnable initial state of
+ * `recurrent.py:85-88,143-161` (both null: zeros).  gate_act (i, f, o) and cell_act (g and
+ * the new cell state) are MI_ACT_NONE / RELU / TANH / SIGMOID — `gate_fn` /
+ * `activation_fn` of `recurrent.py:36-37`; the reference's defaults are SIGMOID / TANH.
+ * Outputs: h_out [T,B,H]; training (nullable): h_prev_out, c_prev_out [T,B,H] (the carry
+ * entering each step) and gates_out [T,B,5H] = (i, f, g, o, act(c')); h_final, c_final
+ * [B,H].  H <= 1024. */
 int mi_lstm_seq_fwd_f32(const float* gi, const float* w_h, const float* h0, const float* c0,
                         const uint8_t* done, float* h_out, float* h_prev_out, float* c_prev_out,
-                        float* gates_out, float* h_final, float* c_final, int64_t T, int64_t B,
+                        float* gates_out, float* h_final, float* c_final, const float* h_init,
+                        const float* c_init, int gate_act, int cell_act, int64_t T, int64_t B,
                         int64_t H, mi_stream_t stream);
 
 /* BPTT of the above: from g_h [T,B,H] to d_gates [T,B,4H] (gradient w.r.t. the gate
  * pre-activations, i.e. w.r.t. gi and w.r.t. h W_h); dh0, dc0 [B,H] nullable.
  * dW_h = h_prev^T d_gates, db_h = colsum(d_gates), dW_i, dx follow as time-batched
- * GEMMs (dense kernels). */
+ * GEMMs (dense kernels).  dinit_part (nullable) [mi_lstm_seq_bwd_blocks(B, H)][2][H]:
+ * per-workgroup sums of the carried (dh, dc) over the rows whose carry was reset to the
+ * learnable initial state (done[t]); summing the blocks gives d h_init, d c_init. */
+int64_t mi_lstm_seq_bwd_blocks(int64_t B, int64_t H);
 int mi_lstm_seq_bwd_f32(const float* g_h, const float* gates, const float* c_prev,
                         const float* w_h, const uint8_t* done, float* d_gates, float* dh0,
-                        float* dc0, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+                        float* dc0, float* dinit_part, int gate_act, int cell_act, int64_t T,
+                        int64_t B, int64_t H, mi_stream_t stream);
 
 /* The LSTM recurrence and BPTT with h W_h (d_gates W_h^T) on the bf16 matrix cores
  * (operands rounded to bf16, fp32 accumulation, fp32 cell arithmetic and carries):
- * same arguments as mi_lstm_seq_fwd_f32 / mi_lstm_seq_bwd_f32; H in {32, 64, 96, 128};
+ * the arguments of mi_lstm_seq_fwd_f32 / mi_lstm_seq_bwd_f32 without the initial-state and
+ * gate-function options (sigmoid / tanh, zero reset); H in {32, 64, 96, 128};
  * h_prev_out, c_prev_out and gates_out are all null (inference) or all given. */
 int mi_lstm_seq_fwd_bf16(const float* gi, const float* w_h, const float* h0, const float* c0,
                          const uint8_t* done, float* h_out, float* h_prev_out,

@@ -5,3 +5,4 @@ provide the Cartpole-/Cheetah-shaped workloads the benchmark is quoted on
 (real mujoco_playground envs are JAX programs and cannot run here)."""
 from .synthetic import (DummyCounterEnv, MockEnv, MoveToCenterEnv, TwoArmEnv,  # noqa: F401
                         cartpole_shaped, cheetah_shaped)
+from .vmap_env import VmapEnv  # noqa: F401

@@ -145,35 +145,63 @@ class GRU(StatefulModule):
         return g_x.view(T, B, self.in_features)
 
 
+def _lstm_act_code(fn, default: int, what: str) -> int:
+    """`gate_fn` / `activation_fn` (recurrent.py:36-37) -> kernel code.  Accepted: None
+    (the reference's default), the strings / markers of `networks.activations`
+    ("sigmoid", "tanh", "relu", "identity" / "none"), and the torch functions of the same
+    names.  BPTT keeps the gate OUTPUTS, so only functions whose derivative can be written
+    in terms of the output are available (swish is not)."""
+    if fn is None:
+        return default
+    from . import activations as A
+
+    table = {"sigmoid": ops.ACT_SIGMOID, "tanh": ops.ACT_TANH, "relu": ops.ACT_RELU,
+             "identity": ops.ACT_NONE, "none": ops.ACT_NONE, "linear": ops.ACT_NONE}
+    if isinstance(fn, str) and fn in table:
+        return table[fn]
+    if isinstance(fn, A._Activation) and fn.name in table:
+        return table[fn.name]
+    name = getattr(fn, "__name__", None)
+    if name in table and fn in (torch.sigmoid, torch.tanh, torch.relu,
+                                torch.nn.functional.relu, torch.nn.functional.sigmoid,
+                                torch.nn.functional.tanh):
+        return table[name]
+    raise NotImplementedError(
+        f"LSTM: {what}={fn!r} is not available; use 'sigmoid', 'tanh', 'relu' or 'identity' "
+        "(functions whose derivative is a function of their output)")
+
+
 class LSTM(StatefulModule):
     """recurrent.py:16-161 — a wrapper of flax's (Optimized)LSTMCell with the carry
-    `(h, c)`, each `[B, H]`: zeros at `initialize_state`, zeros-like at `reset_state`,
-    output = new hidden state, `regularization_loss = zeros(B)`, no rollout extras.
+    `(h, c)`, each `[B, H]`: zeros (or, with `trainable_initial_state`, the learnable
+    `initial_h` / `initial_c` broadcast over the batch, recurrent.py:85-88,132-161) at
+    `initialize_state` and `reset_state`, output = new hidden state,
+    `regularization_loss = zeros(B)`, no rollout extras.
     Cell (flax, third-party: arithmetic PARITY UNPINNED), gate order (i, f, g, o),
     bias on the hidden-side projection only:
 
         a = x W_i + h W_h + b_h
-        c' = sigmoid(a_f) c + sigmoid(a_i) tanh(a_g) ;  h' = sigmoid(a_o) tanh(c')
+        c' = gate(a_f) c + gate(a_i) act(a_g) ;  h' = gate(a_o) act(c')
 
     Weights are packed `w_i [in, 4H]`, `w_h [H, 4H]`, `b_h [4H]`.  The input projection
     (with the bias) is one time-batched GEMM; the recurrence runs in a persistent kernel
-    (csrc/lstm.hip); BPTT is its mirror plus time-batched GEMMs for the weights.
-    `use_optimized` is accepted and ignored (both flax cells compute the same function).
-    Not in this build: custom `gate_fn` / `activation_fn`, `trainable_initial_state`."""
+    (csrc/lstm.hip, H <= 1024; on the bf16 path csrc/lstm_mfma.hip for the default cell
+    with H in {32, 64, 96, 128}); BPTT is its mirror plus time-batched GEMMs for the
+    weights.  A learnable initial state or non-default `gate_fn` / `activation_fn`
+    (sigmoid / tanh / relu / identity) run the fp32 recurrence kernel.  `use_optimized` is
+    accepted and ignored (both flax cells compute the same function)."""
 
     def __init__(self, in_features: int, hidden_features: int, rngs: Rngs, *, gate_fn=None,
                  activation_fn=None, kernel_init=None, recurrent_kernel_init=None,
                  bias_init=None, use_optimized: bool = True,
                  trainable_initial_state: bool = False):
-        if hidden_features > 256:
-            raise ValueError("LSTM: hidden_features <= 256 in this build")
-        if gate_fn is not None or activation_fn is not None:
-            raise NotImplementedError("LSTM: sigmoid gates / tanh activation only in this build")
-        if trainable_initial_state:
-            raise NotImplementedError("LSTM: trainable_initial_state is not in this build")
+        if hidden_features > 1024:
+            raise ValueError("LSTM: hidden_features <= 1024 in this build")
+        self.gate_act = _lstm_act_code(gate_fn, ops.ACT_SIGMOID, "gate_fn")
+        self.cell_act = _lstm_act_code(activation_fn, ops.ACT_TANH, "activation_fn")
         self.in_features = in_features
         self.hidden_features = hidden_features
-        self.trainable_initial_state = False
+        self.trainable_initial_state = bool(trainable_initial_state)
         gen = rngs.generator()
         ki = kernel_init or initializers.lecun_normal()
         kr = recurrent_kernel_init or initializers.orthogonal()
@@ -185,9 +213,23 @@ class LSTM(StatefulModule):
         b = np.zeros(4 * H, dtype=np.float32) if bias_init is None else \
             np.asarray(bias_init(gen, (4 * H,)), dtype=np.float32)
         self.b_h = Parameter(b)
+        if self.trainable_initial_state:  # recurrent.py:85-88: single vectors, zeros
+            self.initial_h = Parameter(np.zeros(H, dtype=np.float32))
+            self.initial_c = Parameter(np.zeros(H, dtype=np.float32))
+
+    def _default_cell(self) -> bool:
+        return (not self.trainable_initial_state and self.gate_act == ops.ACT_SIGMOID
+                and self.cell_act == ops.ACT_TANH)
 
     def _mfma(self) -> bool:
         """bf16 compute: the recurrent product runs on the matrix cores (lstm_mfma.hip)."""
+        from .. import config
+
+        return (config.compute_dtype() == "bf16" and self._default_cell()
+                and ops.gru_mfma_ok(self.hidden_features))
+
+    def _bf16_proj(self) -> bool:
+        """bf16 compute: the input projection runs on the bf16 GEMMs."""
         from .. import config
 
         return config.compute_dtype() == "bf16" and ops.gru_mfma_ok(self.hidden_features)
@@ -207,23 +249,40 @@ class LSTM(StatefulModule):
             return dense_chain.forward_infer([self._proj()], x2)
         return ops.dense_fwd(x2, self.w_i.data, self.b_h.data, ops.ACT_NONE)
 
+    def _init_vectors(self):
+        if not self.trainable_initial_state:
+            return None, None
+        return self.initial_h.data, self.initial_c.data
+
+    def _cell_kw(self) -> dict:
+        hi, ci = self._init_vectors()
+        return dict(h_init=hi, c_init=ci, gate_act=self.gate_act, cell_act=self.cell_act)
+
     def __call__(self, state, x: torch.Tensor, rollout_extras: Any = None):
         h, c = state
         B = x.shape[0]
         gi = self._gi(x.reshape(B, self.in_features)).view(1, B, 4 * self.hidden_features)
+        mfma = self._mfma()
+        kw = {} if mfma else self._cell_kw()
         h_out, _, _, _, h_f, c_f = ops.lstm_seq_fwd(gi, self.w_h.data, h.contiguous(),
                                                     c.contiguous(), None, train=False,
-                                                    mfma=self._mfma())
+                                                    mfma=mfma, **kw)
         return StatefulModuleOutput(next_state=(h_f, c_f), output=h_out[0],
                                     regularization_loss=torch.zeros(B, device=x.device),
                                     metrics={}, rollout_extras=None)
 
     def initialize_state(self, batch_size: int):
-        z = lambda: torch.zeros(batch_size, self.hidden_features, dtype=torch.float32,
-                                device=self.device)
+        H = self.hidden_features
+        if self.trainable_initial_state:  # recurrent.py:132-141
+            return (self.initial_h.data.expand(batch_size, H).contiguous(),
+                    self.initial_c.data.expand(batch_size, H).contiguous())
+        z = lambda: torch.zeros(batch_size, H, dtype=torch.float32, device=self.device)
         return (z(), z())
 
     def reset_state(self, prev_state):
+        if self.trainable_initial_state:  # recurrent.py:154-158
+            return (self.initial_h.data.expand(prev_state[0].shape).contiguous(),
+                    self.initial_c.data.expand(prev_state[1].shape).contiguous())
         return (torch.zeros_like(prev_state[0]), torch.zeros_like(prev_state[1]))
 
     # ---- training protocol --------------------------------------------------------
@@ -243,17 +302,32 @@ class LSTM(StatefulModule):
         else:
             gi = self._gi(x2).view(T, B, 4 * H)
         h0, c0 = state0
+        kw = {} if mfma else self._cell_kw()
         h_out, h_prev, c_prev, gates, h_f, c_f = ops.lstm_seq_fwd(
             gi, self.w_h.data, h0.contiguous(), c0.contiguous(), done_seq.contiguous(),
-            train=True, mfma=mfma)
+            train=True, mfma=mfma, **kw)
         ctx = (x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx)
         return ctx, h_out, None, (h_f, c_f)
 
     def replay_backward(self, ctx, g_out, g_reg):
         x2, h_prev, c_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx
         H = self.hidden_features
-        da = ops.lstm_seq_bwd(g_out.contiguous(), gates, c_prev, self.w_h.data,
-                              done_seq.contiguous(), mfma=mfma)
+        if mfma:
+            da = ops.lstm_seq_bwd(g_out.contiguous(), gates, c_prev, self.w_h.data,
+                                  done_seq.contiguous(), mfma=True)
+        elif self.trainable_initial_state:
+            # the carry a done row is reset to is (initial_h, initial_c): the BPTT hands
+            # back what flows into it.  (The sequence's own first carry is data — the
+            # stored pre-rollout state, ppo.py:298-300 — and receives no gradient.)
+            da, d_h, d_c = ops.lstm_seq_bwd(
+                g_out.contiguous(), gates, c_prev, self.w_h.data, done_seq.contiguous(),
+                want_dinit=True, gate_act=self.gate_act, cell_act=self.cell_act)
+            self.initial_h.grad.add_(d_h)
+            self.initial_c.grad.add_(d_c)
+        else:
+            da = ops.lstm_seq_bwd(g_out.contiguous(), gates, c_prev, self.w_h.data,
+                                  done_seq.contiguous(), gate_act=self.gate_act,
+                                  cell_act=self.cell_act)
         da2 = da.view(T * B, 4 * H)
         if mfma:
             from . import dense_chain

@@ -1004,9 +1004,15 @@ def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False):
 
 
 # ------------------------------------------------------------- f2: LSTM
-def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool, mfma: bool = False):
+ACT_SIGMOID = 4  # LSTM gate functions only (MI_ACT_SIGMOID)
+
+
+def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool, mfma: bool = False, h_init=None,
+                 c_init=None, gate_act: int = ACT_SIGMOID, cell_act: int = ACT_TANH):
     """gi [T,B,4H] -> (h_out [T,B,H], h_prev | None, c_prev | None, gates [T,B,5H] | None,
-    h_final [B,H], c_final [B,H]).  `mfma`: h W_h on the bf16 matrix cores."""
+    h_final [B,H], c_final [B,H]).  `mfma`: h W_h on the bf16 matrix cores (default gate
+    functions and zero reset only).  `h_init` / `c_init` [H]: the carry a done row is reset
+    to (the learnable initial state); `gate_act` / `cell_act`: MI_ACT codes."""
     T, B, H4 = gi.shape
     H = H4 // 4
     _need(w_h.shape == (H, H4) and h0.shape == (B, H) and c0.shape == (B, H),
@@ -1021,21 +1027,50 @@ def lstm_seq_fwd(gi, w_h, h0, c0, done, train: bool, mfma: bool = False):
     d = None if done is None else _as_u8(done)
     if d is not None:
         _need(d.shape == (T, B), "lstm_seq_fwd: done must be [T, B]")
-    fn = lib().mi_lstm_seq_fwd_bf16 if mfma else lib().mi_lstm_seq_fwd_f32
-    check(fn(ptr(gi, f32), ptr(w_h, f32), ptr(h0, f32), ptr(c0, f32), ptr(d), ptr(h_out, f32),
-             ptr(h_prev, f32), ptr(c_prev, f32), ptr(gates, f32), ptr(h_final, f32),
-             ptr(c_final, f32), T, B, H, stream()),
-          "mi_lstm_seq_fwd_bf16" if mfma else "mi_lstm_seq_fwd_f32")
+    if mfma:
+        _need(h_init is None and c_init is None and gate_act == ACT_SIGMOID
+              and cell_act == ACT_TANH, "lstm_seq_fwd: the matrix-core recurrence takes the "
+              "default gate functions and a zero reset")
+        check(lib().mi_lstm_seq_fwd_bf16(
+            ptr(gi, f32), ptr(w_h, f32), ptr(h0, f32), ptr(c0, f32), ptr(d), ptr(h_out, f32),
+            ptr(h_prev, f32), ptr(c_prev, f32), ptr(gates, f32), ptr(h_final, f32),
+            ptr(c_final, f32), T, B, H, stream()), "mi_lstm_seq_fwd_bf16")
+    else:
+        _need((h_init is None) == (c_init is None), "lstm_seq_fwd: h_init and c_init go together")
+        _need(h_init is None or (h_init.shape == (H,) and c_init.shape == (H,)),
+              "lstm_seq_fwd: h_init / c_init must be [H]")
+        check(lib().mi_lstm_seq_fwd_f32(
+            ptr(gi, f32), ptr(w_h, f32), ptr(h0, f32), ptr(c0, f32), ptr(d), ptr(h_out, f32),
+            ptr(h_prev, f32), ptr(c_prev, f32), ptr(gates, f32), ptr(h_final, f32),
+            ptr(c_final, f32), ptr(h_init, f32), ptr(c_init, f32), int(gate_act), int(cell_act),
+            T, B, H, stream()), "mi_lstm_seq_fwd_f32")
     return h_out, h_prev, c_prev, gates, h_final, c_final
 
 
-def lstm_seq_bwd(g_h, gates, c_prev, w_h, done, mfma: bool = False):
-    """Returns d_gates [T,B,4H] (gradient w.r.t. the gate pre-activations)."""
+def lstm_seq_bwd(g_h, gates, c_prev, w_h, done, mfma: bool = False, want_dinit: bool = False,
+                 gate_act: int = ACT_SIGMOID, cell_act: int = ACT_TANH):
+    """Returns d_gates [T,B,4H] (gradient w.r.t. the gate pre-activations), and — with
+    `want_dinit` — the gradients (d h_init [H], d c_init [H]) of a learnable initial state."""
     T, B, H = g_h.shape
     da = torch.empty(T, B, 4 * H, dtype=f32, device=g_h.device)
     d = None if done is None else _as_u8(done)
-    fn = lib().mi_lstm_seq_bwd_bf16 if mfma else lib().mi_lstm_seq_bwd_f32
-    check(fn(ptr(g_h, f32), ptr(gates, f32), ptr(c_prev, f32), ptr(w_h, f32), ptr(d),
-             ptr(da, f32), None, None, T, B, H, stream()),
-          "mi_lstm_seq_bwd_bf16" if mfma else "mi_lstm_seq_bwd_f32")
+    if mfma:
+        _need(not want_dinit and gate_act == ACT_SIGMOID and cell_act == ACT_TANH,
+              "lstm_seq_bwd: the matrix-core BPTT takes the default gate functions only")
+        check(lib().mi_lstm_seq_bwd_bf16(
+            ptr(g_h, f32), ptr(gates, f32), ptr(c_prev, f32), ptr(w_h, f32), ptr(d),
+            ptr(da, f32), None, None, T, B, H, stream()), "mi_lstm_seq_bwd_bf16")
+        return da
+    part = None
+    if want_dinit:
+        G = lib().mi_lstm_seq_bwd_blocks(B, H)
+        _need(G >= 1, "lstm_seq_bwd: bad shape")
+        part = torch.empty(G, 2, H, dtype=f32, device=g_h.device)
+    check(lib().mi_lstm_seq_bwd_f32(
+        ptr(g_h, f32), ptr(gates, f32), ptr(c_prev, f32), ptr(w_h, f32), ptr(d), ptr(da, f32),
+        None, None, ptr(part, f32), int(gate_act), int(cell_act), T, B, H, stream()),
+        "mi_lstm_seq_bwd_f32")
+    if want_dinit:
+        dinit = part.sum(dim=0)  # block order: deterministic
+        return da, dinit[0], dinit[1]
     return da

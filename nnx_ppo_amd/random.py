@@ -19,6 +19,28 @@ def _ops():
     return ops
 
 
+# The key functions below run as one kernel launch each on the GPU (csrc/keys.hip) and as
+# plain integer torch arithmetic on the CPU — the same bits either way.  Inside
+# `torch.func.vmap` (envs/vmap_env.py lifts single-env code with it) a kernel launch is
+# not possible (a batched tensor has no device pointer), so `torch_only()` routes GPU
+# tensors through the torch arithmetic too.
+_TORCH_ONLY = [0]
+
+
+class torch_only:
+    def __enter__(self):
+        _TORCH_ONLY[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _TORCH_ONLY[0] -= 1
+        return False
+
+
+def _kernel(k: torch.Tensor) -> bool:
+    return k.is_cuda and not _TORCH_ONLY[0]
+
+
 _GOLDEN = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
 _M1 = -4658895280553007687  # 0xBF58476D1CE4E5B9
 _M2 = -7723592293110705685  # 0x94D049BB133111EB
@@ -50,17 +72,17 @@ def split(k: torch.Tensor, num=2) -> torch.Tensor:
     n = 1
     for s in shape:
         n *= s
-    if k.is_cuda:  # same integers, one launch (csrc/keys.hip)
-        return _ops().key_expand(k, n, 0).reshape(*k.shape, *shape)
+    if _kernel(k):  # same integers, one launch (csrc/keys.hip)
+        return _ops().key_expand(k, n, 0).reshape((*k.shape, *shape))
     idx = torch.arange(1, n + 1, dtype=torch.int64, device=k.device)
     out = _mix(k.unsqueeze(-1) + idx * _GOLDEN)
-    return out.reshape(*k.shape, *shape)
+    return out.reshape((*k.shape, *shape))
 
 
 def split2(k: torch.Tensor):
     """`a, b = split(k)` as two CONTIGUOUS tensors of k's shape (one launch on the
     GPU; same integers as `split(k)[..., 0]`, `split(k)[..., 1]`)."""
-    if k.is_cuda:
+    if _kernel(k):
         out = _ops().key_expand(k, 2, 0, child_major=True)
         return out[0], out[1]
     s = split(k, 2)
@@ -95,11 +117,11 @@ def bits(k: torch.Tensor, shape=()) -> torch.Tensor:
     n = 1
     for s in shape:
         n *= s
-    if k.is_cuda:
-        return _ops().key_expand(k, n, 1).reshape(*k.shape, *shape)
+    if _kernel(k):
+        return _ops().key_expand(k, n, 1).reshape((*k.shape, *shape))
     idx = torch.arange(1, n + 1, dtype=torch.int64, device=k.device)
     out = _mix(_mix(k).unsqueeze(-1) ^ (idx * _M2))
-    return out.reshape(*k.shape, *shape)
+    return out.reshape((*k.shape, *shape))
 
 
 def randint(k: torch.Tensor, shape, minval: int, maxval: int) -> torch.Tensor:
@@ -108,17 +130,17 @@ def randint(k: torch.Tensor, shape, minval: int, maxval: int) -> torch.Tensor:
     if span <= 0:
         return torch.full((*k.shape, *tuple(shape)), int(minval), dtype=torch.int64,
                           device=k.device)
-    if k.is_cuda:
-        return _ops().key_expand(k, _numel(shape), 2, minval, maxval).reshape(*k.shape,
-                                                                             *tuple(shape))
+    if _kernel(k):
+        return _ops().key_expand(k, _numel(shape), 2, minval, maxval).reshape(
+            (*k.shape, *tuple(shape)))
     b = _lsr(bits(k, shape), 1)  # non-negative 63-bit
     return b % span + int(minval)
 
 
 def uniform(k: torch.Tensor, shape=(), dtype=torch.float32) -> torch.Tensor:
     """U[0,1) with 24 random bits — exact in fp32, identical on CPU and GPU."""
-    if k.is_cuda and dtype == torch.float32:
-        return _ops().key_expand(k, _numel(shape), 3).reshape(*k.shape, *tuple(shape))
+    if _kernel(k) and dtype == torch.float32:
+        return _ops().key_expand(k, _numel(shape), 3).reshape((*k.shape, *tuple(shape)))
     b = _lsr(bits(k, shape), 40)  # 24 bits
     return b.to(dtype) * (1.0 / (1 << 24))
 
@@ -130,9 +152,9 @@ def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32,
     envs use it where the reference's test envs draw `jax.random.normal`
     (`test_dummies/mock_env.py:41-52`).  `fold` (int64, k's shape): draw from
     `fold_key(k, fold)` — on the GPU in the same launch."""
-    if k.is_cuda and dtype == torch.float32:
-        return _ops().key_expand(k, _numel(shape), 4, fold=fold).reshape(*k.shape,
-                                                                        *tuple(shape))
+    if _kernel(k) and dtype == torch.float32:
+        return _ops().key_expand(k, _numel(shape), 4, fold=fold).reshape(
+            (*k.shape, *tuple(shape)))
     if fold is not None:
         k = fold_key(k, fold)
     u = uniform(k, shape, dtype)
@@ -142,7 +164,7 @@ def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32,
 def fold_key(k: torch.Tensor, data: torch.Tensor) -> torch.Tensor:
     """Per-element fold of an int64 tensor into keys of the same shape:
     mix(k ^ mix(data + GOLDEN))."""
-    if k.is_cuda:
+    if _kernel(k):
         return _ops().key_fold(k, data)
     return _mix(k ^ _mix(data + _GOLDEN))
 
@@ -159,7 +181,7 @@ def permutations(k: torch.Tensor, n_perm: int, n: int) -> torch.Tensor:
     n <= 8192) one launch for all of them."""
     if k.dim() != 0:
         raise ValueError("permutations expects a scalar key")
-    if k.is_cuda and n <= 8192:
+    if _kernel(k) and n <= 8192:
         return _ops().key_permutations(k, n_perm, n)
     return torch.stack([permutation(fold_in(k, e), n) for e in range(n_perm)], dim=0)
 

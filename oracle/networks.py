@@ -516,39 +516,56 @@ class Scale(Module):
                    None)
 
 
-class LSTM(Module):
-    """`nnx_ppo/networks/recurrent.py:16-161`: carry (h, c), zeros init, zeros-like
-    reset, reg = zeros(B), extras None, output = new h.  Cell arithmetic of
-    flax.nnx.LSTMCell (third-party, PARITY UNPINNED), gate order (i, f, g, o):
-        a = x W_i + h W_h + b_h ;  c' = sig(a_f) c + sig(a_i) tanh(a_g) ;  h' = sig(a_o) tanh(c')"""
+_LSTM_FNS = {0: lambda x: x, 1: torch.relu, 2: torch.tanh, 4: torch.sigmoid}
 
-    def __init__(self, w_i, w_h, b_h, dtype=DTYPE):
+
+class LSTM(Module):
+    """`nnx_ppo/networks/recurrent.py:16-161`: carry (h, c); zeros — or, with
+    `trainable_initial_state`, the learnable `initial_h` / `initial_c` broadcast over the
+    batch (85-88, 132-161) — at init and reset; reg = zeros(B), extras None, output = new h.
+    Cell arithmetic of flax.nnx.LSTMCell (third-party, PARITY UNPINNED), gate order
+    (i, f, g, o), `gate_fn` on i, f, o and `activation_fn` on g and the new cell state:
+        a = x W_i + h W_h + b_h ;  c' = gate(a_f) c + gate(a_i) act(a_g) ;  h' = gate(a_o) act(c')"""
+
+    def __init__(self, w_i, w_h, b_h, dtype=DTYPE, initial_h=None, initial_c=None,
+                 gate_act: int = 4, cell_act: int = 2):
         self.w_i = _t(w_i, dtype).requires_grad_(True)
         self.w_h = _t(w_h, dtype).requires_grad_(True)
         self.b_h = _t(b_h, dtype).requires_grad_(True)
         self.H = self.w_h.shape[0]
         self.dtype = dtype
+        self.initial_h = None if initial_h is None else _t(initial_h, dtype).requires_grad_(True)
+        self.initial_c = None if initial_c is None else _t(initial_c, dtype).requires_grad_(True)
+        self.gate, self.act = _LSTM_FNS[gate_act], _LSTM_FNS[cell_act]
 
     def own_parameters(self):
-        return [self.w_i, self.w_h, self.b_h]
+        ps = [self.w_i, self.w_h, self.b_h]
+        if self.initial_h is not None:
+            ps += [self.initial_h, self.initial_c]
+        return ps
 
     def __call__(self, state, x, extras=None):
         h, c = state
         H = self.H
         a = x @ self.w_i + h @ self.w_h + self.b_h
-        i = torch.sigmoid(a[:, :H])
-        f = torch.sigmoid(a[:, H:2 * H])
-        g = torch.tanh(a[:, 2 * H:3 * H])
-        o = torch.sigmoid(a[:, 3 * H:])
+        i = self.gate(a[:, :H])
+        f = self.gate(a[:, H:2 * H])
+        g = self.act(a[:, 2 * H:3 * H])
+        o = self.gate(a[:, 3 * H:])
         c2 = f * c + i * g
-        h2 = o * torch.tanh(c2)
+        h2 = o * self.act(c2)
         return Out((h2, c2), h2, torch.zeros(x.shape[0], dtype=self.dtype), {}, None)
 
     def initialize_state(self, batch_size):
+        if self.initial_h is not None:
+            return (self.initial_h.expand(batch_size, self.H),
+                    self.initial_c.expand(batch_size, self.H))
         z = lambda: torch.zeros(batch_size, self.H, dtype=self.dtype)
         return (z(), z())
 
     def reset_state(self, prev):
+        if self.initial_h is not None:
+            return (self.initial_h.expand(prev[0].shape), self.initial_c.expand(prev[1].shape))
         return (torch.zeros_like(prev[0]), torch.zeros_like(prev[1]))
 
 
@@ -593,5 +610,8 @@ def from_product(net: Any, dtype=DTYPE) -> Module:
     if name == "GRU":
         return GRU(net.w_i.data, net.b_i.data, net.w_h.data, net.b_hn.data, dtype)
     if name == "LSTM":
-        return LSTM(net.w_i.data, net.w_h.data, net.b_h.data, dtype)
+        ih = net.initial_h.data if getattr(net, "trainable_initial_state", False) else None
+        ic = net.initial_c.data if getattr(net, "trainable_initial_state", False) else None
+        return LSTM(net.w_i.data, net.w_h.data, net.b_h.data, dtype, ih, ic,
+                    getattr(net, "gate_act", 4), getattr(net, "cell_act", 2))
     raise NotImplementedError(f"oracle twin of {name}")

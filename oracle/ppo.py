@@ -265,6 +265,7 @@ def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discoun
             rows.append(perm[: n_minibatches * mb_size].reshape(n_minibatches, mb_size))
         minibatch_inds = torch.cat(rows, 0)
     rows_out = {k: [] for k in ("actor", "critic", "regularization", "clipping_fraction")}
+    diag: dict = {"grad_norm": [], "advantages": [], "critic_R^2": []}
     grads_first = None
     for i in range(n_epochs * n_minibatches):
         inds = minibatch_inds[i]
@@ -278,6 +279,11 @@ def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discoun
         grads = [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
         if grads_first is None:
             grads_first = [g.clone() for g in grads]
+        if isinstance(lm["advantages"], torch.Tensor):  # single reward key
+            from .metrics import step_diagnostics
+
+            for k, v in step_diagnostics(grads, lm, normalize_advantages).items():
+                diag[k].append(v)
         ts.optimizer.update(grads)
         for k in rows_out:
             rows_out[k].append(lm[k])
@@ -286,6 +292,9 @@ def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discoun
                         ts.steps_taken + rollout_length * n_envs)
     info = {k: torch.stack(v) for k, v in rows_out.items()}
     info["rollout"] = ro
+    for k, v in diag.items():  # rows behind GRAD_NORM / CRITIC_EXTRA (ppo.py:313-315,520-528)
+        if v:
+            info[k] = torch.stack(v)
     info["grads_first"] = grads_first
     info["minibatch_inds"] = minibatch_inds
     return new, info

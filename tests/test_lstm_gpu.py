@@ -100,11 +100,12 @@ def test_lstm_contract(dev):
     _, seq, _, sf = m.replay(st, xs, torch.zeros(5, 8, dtype=torch.bool, device=dev), None, False)
     assert torch.equal(seq, torch.stack(outs))
     assert torch.equal(sf[0], s[0]) and torch.equal(sf[1], s[1])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # swish keeps no pre-activation for BPTT
+        from nnx_ppo_amd.networks import activations
         from nnx_ppo_amd.networks.recurrent import LSTM
         from nnx_ppo_amd.networks.types import Rngs
 
-        LSTM(4, 8, Rngs(0), trainable_initial_state=True)
+        LSTM(4, 8, Rngs(0), gate_fn=activations.swish)
 
 
 def _lstm_actor_critic(obs, act, H, critic_h, rngs):
@@ -229,3 +230,168 @@ def test_lstm_matrix_core_path_vs_oracle(dev, T, B, I, H):
             assert close(p_.grad, w)
     finally:
         config.set_compute_dtype(prev)
+
+
+# ---- trainable initial state, gate functions, wide cells (recurrent.py:31-90,132-161) ------
+def _opt_lstm(dev, in_f, H, seed=0, **kw):
+    from nnx_ppo_amd.networks.recurrent import LSTM
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.optim import Optimizer
+
+    m = LSTM(in_f, H, Rngs(seed), **kw)
+    rng = np.random.default_rng(seed + 1)
+    m.b_h.data = torch.tensor(rng.normal(0, 0.1, size=4 * H), dtype=torch.float32)
+    if kw.get("trainable_initial_state"):
+        m.initial_h.data = torch.tensor(rng.normal(0, 0.5, size=H), dtype=torch.float32)
+        m.initial_c.data = torch.tensor(rng.normal(0, 0.5, size=H), dtype=torch.float32)
+    m.to(dev)
+    opt = Optimizer(m, 1e-3, device=dev)
+    return m, opt
+
+
+def test_lstm_trainable_initial_state_contract(dev):
+    """recurrent_test.py:95-152: the initial state is a pair of learnable [H] vectors
+    (zeros at construction), broadcast to the batch by `initialize_state` and to the
+    previous state's shape by `reset_state`."""
+    from nnx_ppo_amd.networks.recurrent import LSTM
+    from nnx_ppo_amd.networks.types import Rngs
+
+    m = LSTM(4, 8, Rngs(0), trainable_initial_state=True).to(dev)
+    names = [n for n, _ in m.named_parameters()]
+    assert "initial_h" in names and "initial_c" in names
+    assert m.initial_h.shape == (8,) and float(m.initial_h.data.abs().sum()) == 0
+    st = m.initialize_state(3)
+    assert all(s.shape == (3, 8) and float(s.abs().sum()) == 0 for s in st)
+    m.initial_h.data.copy_(torch.arange(8.0))
+    m.initial_c.data.copy_(-torch.arange(8.0))
+    h, c = m.initialize_state(5)
+    assert h.shape == (5, 8) and torch.equal(h[3].cpu(), torch.arange(8.0))
+    assert torch.equal(c[0].cpu(), -torch.arange(8.0))
+    out = m((h, c), torch.ones(5, 4, device=dev))
+    rh, rc = m.reset_state(out.next_state)
+    assert torch.equal(rh, h) and torch.equal(rc, c)
+    # without the option there are no such parameters
+    assert "initial_h" not in [n for n, _ in LSTM(4, 8, Rngs(0)).named_parameters()]
+
+
+@pytest.mark.parametrize("T,B,I,H", [(9, 37, 5, 32), (30, 64, 16, 64), (6, 2051, 5, 64),
+                                     (5, 19, 7, 320)])
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_lstm_trainable_init_replay_vs_oracle(dev, T, B, I, H, compute):
+    """Replay with resets to the LEARNED initial state, and BPTT including d initial_h /
+    d initial_c (what flows into the carry of every step that follows a done), against
+    fp64 autograd through the oracle's step-wise scan (ppo.py:411-418).  Same numbers under
+    compute_dtype bf16: this option runs the fp32 recurrence kernel either way."""
+    from nnx_ppo_amd import config
+
+    with config.use_compute_dtype(compute):
+        m, opt = _opt_lstm(dev, I, H, seed=T + B, trainable_initial_state=True)
+        om = on.from_product(m)
+        rng = np.random.default_rng(B)
+        x = rng.normal(size=(T, B, I)).astype(np.float32)
+        h0 = rng.normal(size=(B, H)).astype(np.float32)
+        c0 = rng.normal(size=(B, H)).astype(np.float32)
+        done = rng.random((T, B)) < 0.25
+        gy = rng.normal(size=(T, B, H)).astype(np.float32)
+        t = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt).to(dev)
+        ctx, out, reg, (h_f, c_f) = m.replay((t(h0), t(c0)), t(x), t(done, torch.bool), None,
+                                              need_input_grad=True)
+        x64 = torch.tensor(x, dtype=D, requires_grad=True)
+        state = (torch.tensor(h0, dtype=D), torch.tensor(c0, dtype=D))
+        outs = []
+        for k in range(T):
+            o = om(state, x64[k])
+            outs.append(o.output)
+            state = op.tree_where(torch.tensor(done[k]), om.reset_state(o.next_state),
+                                  o.next_state)
+        want = torch.stack(outs)
+        assert np.allclose(out.cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=3e-5)
+        assert np.allclose(h_f.cpu().numpy(), state[0].detach().numpy(), rtol=1e-4, atol=3e-5)
+        assert np.allclose(c_f.cpu().numpy(), state[1].detach().numpy(), rtol=1e-4, atol=3e-5)
+        opt.begin()
+        gx = m.replay_backward(ctx, t(gy), 0.0)
+        grads = torch.autograd.grad((want * torch.tensor(gy, dtype=D)).sum(),
+                                    [x64, om.w_i, om.w_h, om.b_h, om.initial_h, om.initial_c])
+        s = max(1.0, float(np.sqrt(T * B)))
+        assert np.allclose(gx.cpu().numpy(), grads[0].numpy(), rtol=1e-3, atol=1e-4)
+        for p, w in zip((m.w_i, m.w_h, m.b_h, m.initial_h, m.initial_c), grads[1:]):
+            assert np.allclose(p.grad.cpu().numpy(), w.numpy(), rtol=1e-3, atol=3e-5 * s)
+        assert float(m.initial_h.grad.abs().sum()) > 0  # there were resets to learn from
+
+
+@pytest.mark.parametrize("gate,act", [("sigmoid", "relu"), ("tanh", "tanh"),
+                                      ("sigmoid", "identity"), ("relu", "sigmoid")])
+def test_lstm_gate_functions_vs_oracle(dev, gate, act):
+    """`gate_fn` / `activation_fn` (recurrent.py:36-37): forward and every gradient."""
+    T, B, I, H = 8, 33, 6, 48
+    m, opt = _opt_lstm(dev, I, H, seed=3, gate_fn=gate, activation_fn=act)
+    m.w_h.data.mul_(0.5)  # keep the unbounded (relu / identity) cells in range
+    om = on.from_product(m)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(T, B, I)).astype(np.float32)
+    done = rng.random((T, B)) < 0.2
+    gy = rng.normal(size=(T, B, H)).astype(np.float32)
+    t = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt).to(dev)
+    st = m.initialize_state(B)
+    ctx, out, _, _ = m.replay(st, t(x), t(done, torch.bool), None, need_input_grad=True)
+    x64 = torch.tensor(x, dtype=D, requires_grad=True)
+    state = om.initialize_state(B)
+    outs = []
+    for k in range(T):
+        o = om(state, x64[k])
+        outs.append(o.output)
+        state = op.tree_where(torch.tensor(done[k]), om.reset_state(o.next_state), o.next_state)
+    want = torch.stack(outs)
+    assert np.allclose(out.cpu().numpy(), want.detach().numpy(), rtol=1e-4, atol=3e-5)
+    opt.begin()
+    gx = m.replay_backward(ctx, t(gy), 0.0)
+    grads = torch.autograd.grad((want * torch.tensor(gy, dtype=D)).sum(),
+                                [x64, om.w_i, om.w_h, om.b_h])
+    s = float(np.sqrt(T * B))
+    assert np.allclose(gx.cpu().numpy(), grads[0].numpy(), rtol=1e-3, atol=1e-4)
+    for p, w in zip((m.w_i, m.w_h, m.b_h), grads[1:]):
+        assert np.allclose(p.grad.cpu().numpy(), w.numpy(), rtol=1e-3, atol=3e-5 * s)
+    # the one-step interface agrees with the sequence kernel
+    o1 = m(st, t(x[0]))
+    assert torch.equal(o1.output, out[0])
+
+
+def test_ppo_step_with_trainable_initial_state_vs_oracle(dev):
+    """The whole iteration with an LSTM actor whose reset state is learned: rollout resets
+    use it (rollout.py:42-43), the loss replay resets to it and trains it."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import activations, factories
+    from nnx_ppo_amd.networks.adapter import PPOAdapter
+    from nnx_ppo_amd.networks.containers import Sequential
+    from nnx_ppo_amd.networks.feedforward import Dense
+    from nnx_ppo_amd.networks.normalizer import Normalizer
+    from nnx_ppo_amd.networks.recurrent import LSTM
+    from nnx_ppo_amd.networks.sampling_layers import NormalTanhSampler
+    from nnx_ppo_amd.networks.types import Rngs
+
+    rngs = Rngs(9)
+    lstm = LSTM(32, 32, rngs, trainable_initial_state=True)
+    actor = Sequential([Dense(16, 32, rngs, activation=activations.relu), lstm,
+                        Dense(32, 8, rngs, activation=None),
+                        NormalTanhSampler(rngs, entropy_weight=1e-3)])
+    critic = factories.make_mlp([16, 32, 1], rngs, activation_last_layer=False)
+    net = Sequential([Normalizer(16), PPOAdapter(action=actor, value=critic)])
+    gen = np.random.default_rng(1)
+    lstm.initial_h.data = torch.tensor(gen.normal(0, 0.3, 32), dtype=torch.float32)
+    lstm.initial_c.data = torch.tensor(gen.normal(0, 0.3, 32), dtype=torch.float32)
+    N, T = 64, 16
+    env, oenv = MockEnv(16, 4, max_steps=5), MockEnv(16, 4, max_steps=5)
+    ts = ppo.new_training_state(env, net, N, 42, 1e-3, device=dev)
+    onet = on.from_product(net)
+    ots = op.new_training_state(oenv, onet, N, 42, keys, 1e-3)
+    ih0 = lstm.initial_h.data.clone()
+    for k in range(2):
+        ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 2, 2)
+        ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 2, keys)
+        for name in ("actor", "critic", "regularization"):
+            got, want = m[f"losses/{name}/mean"].item(), info[name].numpy().mean()
+            assert np.isfinite(got) and np.allclose(got, want, rtol=2e-3, atol=1e-5), (k, name)
+    assert not torch.equal(lstm.initial_h.data, ih0)  # it is being trained
+    for (n, p), q in zip(net.named_parameters(), onet.parameters()):
+        assert float((p.data.cpu() - q.detach()).abs().max()) < 5e-4, n
