@@ -242,7 +242,7 @@ def cpu_baseline(min_seconds: float = 12.0, max_iters: int = 12):
     from oracle import networks as on
     from oracle import ppo as op
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores, how = _usable_cores()
     torch.set_num_threads(cores)
     net = factories.make_mlp_actor_critic(OBS, ACT, ACTOR_H, CRITIC_H, Rngs(SEED))
     onet = on.from_product(net, torch.float32)
@@ -254,6 +254,7 @@ def cpu_baseline(min_seconds: float = 12.0, max_iters: int = 12):
         t0 = time.perf_counter()
         ts, _ = op.ppo_step(env, ts, N_ENVS, T, 0.95, 0.99, 0.2, True, N_EPOCHS, N_MB, keys)
         times.append(time.perf_counter() - t0)
+        _log(f"  cpu iteration {len(times)}: {times[-1]:.2f} s on {cores} threads")
     times.sort()
     med = times[len(times) // 2]
     return {
@@ -262,8 +263,41 @@ def cpu_baseline(min_seconds: float = 12.0, max_iters: int = 12):
         "sample": f"median of {len(times)} timed ppo_step iterations (+1 warm-up, "
                   f"{sum(times):.1f} s of CPU work) of the CPU oracle at the full workload "
                   f"({N_ENVS} envs x {T} steps, {N_EPOCHS}x{N_MB} grad steps), torch-CPU fp32, "
-                  f"{cores} threads",
+                  f"{cores} threads = every core this process may use ({how})",
     }
+
+
+_T0 = time.perf_counter()
+
+
+def _usable_cores():
+    """All the host cores this process may actually run on: the scheduler affinity,
+    capped by the container's CPU quota (cgroup cpu.max) — asking torch for more threads
+    than the quota allows only makes them take turns."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    quota = q / period
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return cores, f"affinity {aff}, cgroup quota {'none' if quota is None else round(quota, 1)}"
+
+
+def _log(msg: str) -> None:
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def _pct(xs, q):
@@ -389,10 +423,13 @@ def main():
     # warm-up: iteration 1 is eager, iteration 2 records the graph — at least 3 so the
     # timed region only sees replays
     warm = max(args.warmup, 1 if args.eager else 3)
+    _log(f"built; warm-up {warm} iterations (1 eager, 1 recorded, rest replayed)")
     run_window(warm)
+    _log("warm-up done")
     # size the repetition count from one untimed window
     est = run_window(args.steps)
     reps = max(1, min(200, int(args.min_timed_seconds / max(est, 1e-6)) + 1))
+    _log(f"one window of {args.steps} iterations = {est * 1e3:.1f} ms; timing {reps} windows")
     windows, iter_ms = [], []
     for _ in range(reps):
         stamps = [time.perf_counter()]
@@ -411,6 +448,7 @@ def main():
     windows = [float(x) for x in wt.cpu()]
     elapsed = _pct(windows, 0.5)
 
+    _log(f"timed: median window {elapsed * 1e3:.2f} ms")
     # the same graph replayed back to back, no host read in between (round 1's number)
     b2b = None
     if runner._graph is not None:
@@ -423,7 +461,9 @@ def main():
         b2b = time.perf_counter() - t0
 
     # instrumented iteration on every rank (collectives must match), reported by rank 0
+    _log("instrumented iteration (HIP events around every C-ABI call)")
     ts, roof, per_kernel = roofline_of_dominant_kernel(env, runner.state)
+    _log("roofline done")
 
     if rank == 0:
         total_env_steps = world * N_ENVS * T * args.steps
@@ -473,9 +513,12 @@ def main():
             "final_losses": {k: float(v) for k, v in metrics.items() if k.startswith("losses/")},
         }
         if world == 1 and not args.no_train_ppo and not args.eager:
+            _log("train_ppo cross-check")
             line["train_ppo"] = train_ppo_throughput(device, args.compute)
         if world == 1 and not args.no_cpu_baseline:
+            _log("cpu baseline (oracle on the host cores)")
             line["cpu_baseline"] = cpu_baseline()
+        _log("done")
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -522,6 +522,80 @@ int mi_episode_step_select(const int64_t* counter, const void* inner_done, int d
                            const int64_t* row_bytes, int64_t n_leaves, int64_t B,
                            mi_stream_t stream);
 
+/* a13 + a14 in ONE launch for a single reward key at minibatch size (T <= 32, N <= 16384;
+ * mi_gae_ppo_loss_supported): `gae` (ppo.py:351-394), the advantage statistics and
+ * normalisation (ppo.py:477-480, `normalize` != 0) and the loss terms with their gradients
+ * (ppo.py:456-503) — what mi_gae_stats_f32 followed by mi_ppo_loss_f32 compute, with the
+ * advantages kept in registers in between.  advantages [T,N] and adv_stats [3] are
+ * nullable outputs (diagnostics); reg [T,N] is nullable.  Advantages, statistics and both
+ * gradients are bit-identical to the two-launch path; the four loss scalars agree to fp64
+ * summation order.  workspace: mi_gae_ppo_loss_workspace_bytes(), zero-initialised once
+ * (the kernel re-arms it). */
+int64_t mi_gae_ppo_loss_workspace_bytes(void);
+int mi_gae_ppo_loss_supported(int64_t T, int64_t N);
+int mi_gae_ppo_loss_f32(const float* rewards, const float* values, const float* last_value,
+                        const uint8_t* done, const uint8_t* truncated, const float* ll_new,
+                        const float* ll_old, const float* reg, float gamma, float lambda,
+                        int normalize, float clip_range, float critic_weight,
+                        float* advantages, double* adv_stats, float* g_ll, float* g_v,
+                        float* loss_out, void* workspace, int64_t T, int64_t N,
+                        mi_stream_t stream);
+
+/* ---- e: one-shot peer exchange (new; the reference is single-device) -------- */
+
+/* Env-sharded data parallelism (BASELINE.json north_star): one process per
+ * GPU; the only exchanges are the gradient arena once per gradient step (the loss of
+ * `ppo.py:301-316` is a mean over envs, so the global-minibatch gradient is the mean of the
+ * shards' gradients), the advantage-statistics triple of `ppo.py:477-480`, the
+ * normaliser's batch statistics (`normalizer.py:98-136`) and the logged loss rows.
+ *
+ * Transport: each rank owns one fine-grained device buffer, exported through HIP IPC and
+ * mapped by every peer.  A collective is ONE plain kernel launch per rank: write this
+ * rank's contribution into its slot on every peer (one xGMI hop, all links at once),
+ * raise per-chunk flags behind a system-scope release, wait (bounded) for the peers'
+ * flags, reduce the `world` slots in rank order — every rank gets bit-identical results,
+ * and the launch is HIP-graph capturable.
+ *
+ * Host protocol (the only entry points that allocate or synchronise; not capturable):
+ *   mi_comm_create   allocate the local region (2 parities x world slots of slot_bytes
+ *                    each, slot_bytes a multiple of 4096) and return its IPC handle
+ *                    (mi_comm_handle_bytes() bytes) for the caller to all-gather by any
+ *                    host channel (torch.distributed, MPI, a file);
+ *   mi_comm_connect  map the peers' regions from the gathered handles
+ *                    (world x mi_comm_handle_bytes() bytes, in rank order);
+ *   mi_comm_status   synchronise and report (collectives completed, spins that timed out);
+ *   mi_comm_destroy  unmap and free.
+ * `timeout_seconds` bounds every wait inside a kernel: a peer that never arrives makes
+ * the kernel count an error and finish instead of hanging the device. */
+int64_t mi_comm_handle_bytes(void);
+int mi_comm_create(int rank, int world, int64_t slot_bytes, double timeout_seconds,
+                   void** comm_out, void* handle_out);
+int mi_comm_connect(void* comm, const void* all_handles);
+int mi_comm_status(void* comm, int64_t* seq_out, int64_t* errors_out);
+int64_t mi_comm_slot_bytes(void* comm);
+int mi_comm_destroy(void* comm);
+
+/* buf[i] <- scale * sum_r buf_r[i], summed in rank order (in place, n * size <= slot). */
+int mi_allreduce_oneshot_f32(void* comm, float* buf, int64_t n, float scale,
+                             mi_stream_t stream);
+int mi_allreduce_oneshot_f64(void* comm, double* buf, int64_t n, double scale,
+                             mi_stream_t stream);
+
+/* dst[r][0..nbytes) <- rank r's src (dst: world x nbytes bytes; nbytes <= slot). */
+int mi_allgather_oneshot(void* comm, const void* src, int64_t nbytes, void* dst,
+                         mi_stream_t stream);
+
+/* mi_adam_step_f32 (no clipping) with the gradient all-reduce-MEAN inside the launch:
+ * chunk by chunk, exchange, reduce in rank order, scale by 1 / world, Adam.  One launch
+ * per gradient step for exchange + optimiser + bf16 images + gradient zeroing. */
+int mi_adam_step_allreduce_f32(void* comm, float* params, float* grads, float* m, float* v,
+                               int64_t n, float lr, float b1, float b2, float eps,
+                               float weight_decay, int64_t* step, void* begin_next_ticket,
+                               int64_t n_shadows, const int64_t* shadow_begin,
+                               const int64_t* shadow_K, const int64_t* shadow_N,
+                               void* const* w_bf, void* const* wt_bf, void* const* frag_fwd,
+                               void* const* frag_bwd, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import contextlib
 import dataclasses
+import os
 import time
 from collections.abc import Callable
 from typing import Any, Optional
@@ -36,6 +37,11 @@ from .config import (BackendConfig, EvalConfig, PPOConfig, TrainConfig,  # noqa:
 from .loop import IterationRunner, run_training_loop, should_run
 from .metrics import compute_metrics, log_weight_stats
 from .types import LoggingLevel, TrainingState, Transition
+
+
+# MIPPO_FUSED_GAE_LOSS=0: GAE and loss as two launches (A/B timing, and what a sharded run
+# uses: the advantage statistics are exchanged between them)
+FUSED_GAE_LOSS = os.environ.get("MIPPO_FUSED_GAE_LOSS", "1") != "0"
 
 
 def default_config() -> TrainConfig:
@@ -444,22 +450,35 @@ def ppo_loss(
     else:
         del combine_advantages  # single reward key: nothing to combine
         values = values.contiguous()
-        stats = None
-        if normalize_advantages:
-            # the statistics of ppo.py:477-480 come out of the GAE launch itself
-            adv, stats = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
-                                 done.contiguous(), truncated.contiguous(), discounting_factor,
-                                 gae_lambda, with_stats=True)
-            if parallel.is_distributed():
-                parallel.allreduce_sum_(stats)
-        else:
-            adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
-                          done.contiguous(), truncated.contiguous(), discounting_factor,
-                          gae_lambda)
         reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
-        g_ll, g_v, loss_out = ops.ppo_loss(
-            ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1), values.reshape(-1),
-            reg_flat, stats, clip_range, critic_loss_weight, loss_out=loss_out)
+        fused_loss = (FUSED_GAE_LOSS and not parallel.is_distributed()
+                      and ops.gae_ppo_loss_supported(T, B))
+        if fused_loss:
+            # GAE, advantage statistics, loss terms and gradients in ONE launch (the
+            # advantages never leave registers); a sharded run exchanges the statistics
+            # between the two phases and keeps the two launches
+            g_ll, g_v, loss_out, adv = ops.gae_ppo_loss(
+                rewards.contiguous(), values, last_values.contiguous(), done.contiguous(),
+                truncated.contiguous(), ll_new.contiguous(), ll_old.contiguous(),
+                None if reg_seq is None else reg_seq.contiguous(), discounting_factor,
+                gae_lambda, normalize_advantages, clip_range, critic_loss_weight,
+                loss_out=loss_out, want_adv=LoggingLevel.CRITIC_EXTRA in logging_level)
+        else:
+            stats = None
+            if normalize_advantages:
+                # the statistics of ppo.py:477-480 come out of the GAE launch itself
+                adv, stats = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
+                                     done.contiguous(), truncated.contiguous(),
+                                     discounting_factor, gae_lambda, with_stats=True)
+                if parallel.is_distributed():
+                    parallel.allreduce_sum_(stats)
+            else:
+                adv = ops.gae(rewards.contiguous(), values, last_values.contiguous(),
+                              done.contiguous(), truncated.contiguous(), discounting_factor,
+                              gae_lambda)
+            g_ll, g_v, loss_out = ops.ppo_loss(
+                ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1), values.reshape(-1),
+                reg_flat, stats, clip_range, critic_loss_weight, loss_out=loss_out)
         if backward:
             g_out = PPONetworkOutput(actions=None, loglikelihoods=g_ll.view(T, B),
                                      value_estimates=g_v.view(T, B))

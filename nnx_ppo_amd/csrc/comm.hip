@@ -1,0 +1,427 @@
+// e — one-shot peer exchange over IPC-mapped device buffers (SURVEY §5 last row, §8b
+// `mi_allreduce_oneshot`, §8e "Transport").  The reference is single-device: it has no
+// collective at all, so everything here is new work that BASELINE.json's north_star
+// asks for (env-sharded data parallelism, gradient all-reduce over xGMI).
+//
+// Why not a ring: the messages are tiny (the whole gradient arena is 322 KB at C2/C5, the
+// advantage statistics are 24 bytes) and an 8-GPU MI355X node is fully connected
+// point-to-point (7 xGMI links per GPU), so a ring all-reduce pays 14 dependent hops of
+// latency for nothing.  One shot: every rank WRITES its contribution into a slot it owns
+// in every peer's buffer (7 concurrent link transfers, one hop), raises a per-chunk flag
+// behind a system-scope release, waits for the same flags from its peers, and reduces the
+// `world` slots locally in rank order — so every rank computes bit-identical sums.  The
+// exchange is a plain kernel on the launch stream: a sharded iteration is ONE HIP graph.
+//
+// Memory (one hipExtMallocWithFlags(..., hipDeviceMallocUncached) region per rank, exported
+// with hipIpcGetMemHandle and mapped by every peer):
+//   [0, 4096)                 header (local use): seq, finish ticket, error count
+//   flags [2][world][chunks]  uint32 sequence numbers, written by the owning peer
+//   slots [2][world][slot]    payload, slot (p, r) written by rank r
+// Two parities: a rank can run at most one collective ahead of a peer (finishing
+// collective k needs every peer's flags for k, which a peer raises only after it has
+// finished READING collective k-1), so slot set k&1 is never overwritten while in use.
+//
+// Every spin is bounded (wall clock): a peer that never arrives makes the kernel count an
+// error and finish with garbage instead of hanging the GPU; the host reads the count
+// (mi_comm_status) and raises.
+#include "bf16_common.h"
+#include "optim_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxWorld = 16;
+constexpr int64_t kChunkBytes = 4096;     // one block-pass: 256 threads x 16 B
+constexpr int64_t kHeaderBytes = 4096;
+constexpr int kMaxBlocks = 256;
+
+struct CommHeader {
+  unsigned long long seq;      // collectives completed on this rank
+  unsigned int ticket;         // blocks finished in the running collective
+  unsigned int errors;         // spins that timed out (sticky)
+  unsigned long long timeout;  // wall-clock ticks (100 MHz) a spin may last
+};
+
+struct Comm {                  // host object behind the opaque handle
+  int rank, world;
+  int64_t slot_bytes, chunks, region_bytes;
+  char* local;                 // this rank's region
+  char* peer[kMaxWorld];       // every rank's region as mapped here (peer[rank] == local)
+  bool opened[kMaxWorld];
+};
+
+struct CommDev {               // by value in the kernel arguments
+  int rank, world;
+  int64_t slot_bytes, chunks;
+  char* peer[kMaxWorld];
+};
+
+__host__ __device__ inline int64_t flags_off(const int64_t chunks, int world, int parity, int r) {
+  return kHeaderBytes + ((int64_t)(parity * world + r) * chunks) * 4;
+}
+__host__ __device__ inline int64_t slots_base(const int64_t chunks, int world) {
+  const int64_t f = kHeaderBytes + (int64_t)2 * world * chunks * 4;
+  return (f + 4095) / 4096 * 4096;
+}
+__host__ __device__ inline int64_t slot_off(const int64_t chunks, int world, int64_t slot_bytes,
+                                            int parity, int r) {
+  return slots_base(chunks, world) + (int64_t)(parity * world + r) * slot_bytes;
+}
+
+CommDev dev_view(const Comm* c) {
+  CommDev d;
+  d.rank = c->rank;
+  d.world = c->world;
+  d.slot_bytes = c->slot_bytes;
+  d.chunks = c->chunks;
+  for (int r = 0; r < kMaxWorld; ++r) d.peer[r] = r < c->world ? c->peer[r] : nullptr;
+  return d;
+}
+
+// ---- device side ---------------------------------------------------------------------
+
+// Push one chunk of this rank's payload into slot (parity, me) of every peer, then raise
+// the chunk's flag there.  `src` points at the chunk (nbytes <= kChunkBytes of it valid).
+__device__ inline void push_chunk(const CommDev& c, int parity, unsigned int seq, int64_t chunk,
+                                  const char* __restrict__ src, int64_t nbytes) {
+  const int64_t off = slot_off(c.chunks, c.world, c.slot_bytes, parity, c.rank) +
+                      chunk * kChunkBytes;
+  const int tid = threadIdx.x;
+  const bool vec = (nbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  for (int r = 0; r < c.world; ++r) {
+    if (r == c.rank) continue;  // own contribution is read from `src` directly
+    char* dst = c.peer[r] + off;
+    if (vec) {
+      if ((int64_t)tid * 16 < nbytes)
+        reinterpret_cast<uint4*>(dst)[tid] = reinterpret_cast<const uint4*>(src)[tid];
+    } else {
+      for (int64_t i = tid; i < nbytes; i += kThreads) dst[i] = src[i];
+    }
+  }
+  // system-scope release by every storing thread (the stores of one wave to a peer are
+  // not ordered with another wave's), then one lane raises the flags
+  __threadfence_system();
+  __syncthreads();
+  if (tid < c.world && tid != c.rank) {
+    unsigned int* flag = reinterpret_cast<unsigned int*>(
+        c.peer[tid] + flags_off(c.chunks, c.world, parity, c.rank)) + chunk;
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Wait until every peer has raised this chunk's flag for `seq` (bounded), then make the
+// payload they wrote visible to every wave of the workgroup.
+__device__ inline void wait_chunk(const CommDev& c, CommHeader* hdr, int parity,
+                                  unsigned int seq, int64_t chunk) {
+  const int tid = threadIdx.x;
+  if (tid < c.world && tid != c.rank) {
+    const unsigned int* flag = reinterpret_cast<const unsigned int*>(
+        c.peer[c.rank] + flags_off(c.chunks, c.world, parity, tid)) + chunk;
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long limit = hdr->timeout;
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > limit) {
+        atomicAdd(&hdr->errors, 1u);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // every wave invalidates for itself (an acquire only covers the issuing wave's later
+  // loads); system scope: the payload was written by another device
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// The collective counts itself once every block has finished (so a block that starts late
+// still reads the old `seq`).
+__device__ inline void finish(CommHeader* hdr, unsigned long long seq_new) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int blocks = gridDim.x;
+    if (__hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+        blocks - 1) {
+      hdr->seq = seq_new;
+      __hip_atomic_store(&hdr->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+allreduce_kernel(CommDev c, T* __restrict__ buf, int64_t n, T scale) {
+  CommHeader* hdr = reinterpret_cast<CommHeader*>(c.peer[c.rank]);
+  const unsigned long long seq64 = hdr->seq + 1;
+  const unsigned int seq = (unsigned int)seq64;
+  const int parity = (int)(seq64 & 1);
+  constexpr int kPer = (int)(kChunkBytes / sizeof(T));  // elements per chunk
+  const int64_t nchunks = mippo::ceil_div(n, (int64_t)kPer);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t e0 = ch * kPer;
+    const int64_t cnt = n - e0 < kPer ? n - e0 : kPer;
+    push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(buf + e0), cnt * (int64_t)sizeof(T));
+    wait_chunk(c, hdr, parity, seq, ch);
+    for (int64_t i = threadIdx.x; i < cnt; i += kThreads) {
+      T s = T(0);
+      for (int r = 0; r < c.world; ++r) {  // fixed rank order: identical on every rank
+        const T v = r == c.rank
+                        ? buf[e0 + i]
+                        : reinterpret_cast<const T*>(
+                              c.peer[c.rank] + slot_off(c.chunks, c.world, c.slot_bytes, parity, r) +
+                              ch * kChunkBytes)[i];
+        s += v;
+      }
+      buf[e0 + i] = s * scale;
+    }
+    __syncthreads();  // the flags of the next chunk are raised by other lanes
+  }
+  finish(hdr, seq64);
+}
+
+__global__ void __launch_bounds__(kThreads)
+allgather_kernel(CommDev c, const char* __restrict__ src, int64_t nbytes, char* __restrict__ dst) {
+  CommHeader* hdr = reinterpret_cast<CommHeader*>(c.peer[c.rank]);
+  const unsigned long long seq64 = hdr->seq + 1;
+  const unsigned int seq = (unsigned int)seq64;
+  const int parity = (int)(seq64 & 1);
+  const int64_t nchunks = mippo::ceil_div(nbytes, kChunkBytes);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t b0 = ch * kChunkBytes;
+    const int64_t cnt = nbytes - b0 < kChunkBytes ? nbytes - b0 : kChunkBytes;
+    push_chunk(c, parity, seq, ch, src + b0, cnt);
+    wait_chunk(c, hdr, parity, seq, ch);
+    for (int r = 0; r < c.world; ++r) {
+      const char* from = r == c.rank
+                             ? src + b0
+                             : c.peer[c.rank] +
+                                   slot_off(c.chunks, c.world, c.slot_bytes, parity, r) + b0;
+      for (int64_t i = threadIdx.x; i < cnt; i += kThreads) dst[(int64_t)r * nbytes + b0 + i] = from[i];
+    }
+    __syncthreads();
+  }
+  finish(hdr, seq64);
+}
+
+// The optimiser step with the gradient exchange inside it: chunk by chunk, push this
+// rank's gradients, wait for the peers', reduce in rank order, scale by 1/world (the
+// all-reduce-MEAN of equal shards) and run the Adam body on the result.
+__global__ void __launch_bounds__(kThreads)
+adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
+  CommHeader* hdr = reinterpret_cast<CommHeader*>(c.peer[c.rank]);
+  const unsigned long long seq64 = hdr->seq + 1;
+  const unsigned int seq = (unsigned int)seq64;
+  const int parity = (int)(seq64 & 1);
+  const mippo_optim::AdamStep st = mippo_optim::adam_begin(a);
+  constexpr int kPer = (int)(kChunkBytes / sizeof(float));  // 1024 elements = 4 passes of 256
+  const int64_t nchunks = mippo::ceil_div(a.n, (int64_t)kPer);
+  const float inv_world = 1.0f / (float)c.world;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t e0 = ch * kPer;
+    const int64_t cnt = a.n - e0 < kPer ? a.n - e0 : kPer;
+    push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(a.g + e0), cnt * 4);
+    wait_chunk(c, hdr, parity, seq, ch);
+    for (int64_t pass = 0; pass < cnt; pass += kThreads) {
+      const int64_t i = e0 + pass + threadIdx.x;
+      if (i < a.n && pass + threadIdx.x < cnt) {
+        float s = 0.0f;
+        for (int r = 0; r < c.world; ++r) {
+          const float v = r == c.rank
+                              ? a.g[i]
+                              : reinterpret_cast<const float*>(
+                                    c.peer[c.rank] +
+                                    slot_off(c.chunks, c.world, c.slot_bytes, parity, r) +
+                                    ch * kChunkBytes)[pass + threadIdx.x];
+          s += v;
+        }
+        mippo_optim::adam_element(a, st, i, e0 + pass, s * inv_world);
+      }
+    }
+    __syncthreads();
+  }
+  mippo_optim::adam_end(a, st);
+  finish(hdr, seq64);
+}
+
+int grid_for(int64_t nchunks) {
+  return (int)(nchunks < 1 ? 1 : (nchunks > kMaxBlocks ? kMaxBlocks : nchunks));
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------------
+
+extern "C" int64_t mi_comm_handle_bytes(void) { return (int64_t)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int mi_comm_create(int rank, int world, int64_t slot_bytes, double timeout_seconds,
+                              void** comm_out, void* handle_out) {
+  MI_REQUIRE(comm_out && handle_out, "mi_comm_create: null pointer");
+  MI_REQUIRE(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world,
+             "mi_comm_create: bad rank %d / world %d (world <= %d)", rank, world, kMaxWorld);
+  MI_REQUIRE(slot_bytes >= kChunkBytes && slot_bytes % kChunkBytes == 0,
+             "mi_comm_create: slot_bytes must be a positive multiple of %lld",
+             (long long)kChunkBytes);
+  MI_REQUIRE(timeout_seconds > 0.0, "mi_comm_create: timeout must be positive");
+  Comm* c = new Comm();
+  c->rank = rank;
+  c->world = world;
+  c->slot_bytes = slot_bytes;
+  c->chunks = slot_bytes / kChunkBytes;
+  c->region_bytes = slot_off(c->chunks, world, slot_bytes, 2, 0);  // end of the last slot
+  for (int r = 0; r < kMaxWorld; ++r) {
+    c->peer[r] = nullptr;
+    c->opened[r] = false;
+  }
+  void* p = nullptr;
+  // uncached (fine-grained) device memory: peers' stores and this device's loads meet in
+  // memory, not in an L2 that the other side cannot see
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)c->region_bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&p, (size_t)c->region_bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    mippo::set_error("mi_comm_create: cannot allocate %lld bytes of fine-grained device memory: %s",
+                     (long long)c->region_bytes, hipGetErrorString(e));
+    delete c;
+    return -ENOMEM;
+  }
+  c->local = static_cast<char*>(p);
+  c->peer[rank] = c->local;
+  e = hipMemset(p, 0, (size_t)c->region_bytes);
+  if (e == hipSuccess) {
+    CommHeader h = {};
+    h.timeout = (unsigned long long)(timeout_seconds * 1e8);  // wall_clock64: 100 MHz
+    e = hipMemcpy(p, &h, sizeof(h), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess)
+    e = hipIpcGetMemHandle(static_cast<hipIpcMemHandle_t*>(handle_out), p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    delete c;
+    mippo::set_error("mi_comm_create: %s", hipGetErrorString(e));
+    return -EIO;
+  }
+  *comm_out = c;
+  return 0;
+}
+
+extern "C" int mi_comm_connect(void* comm, const void* all_handles) {
+  MI_REQUIRE(comm && all_handles, "mi_comm_connect: null pointer");
+  Comm* c = static_cast<Comm*>(comm);
+  const hipIpcMemHandle_t* hs = static_cast<const hipIpcMemHandle_t*>(all_handles);
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank || c->opened[r]) continue;
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, hs[r], hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      mippo::set_error("mi_comm_connect: hipIpcOpenMemHandle(rank %d) failed: %s", r,
+                       hipGetErrorString(e));
+      return -EIO;
+    }
+    c->peer[r] = static_cast<char*>(p);
+    c->opened[r] = true;
+  }
+  return 0;
+}
+
+extern "C" int mi_comm_destroy(void* comm) {
+  if (!comm) return 0;
+  Comm* c = static_cast<Comm*>(comm);
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < c->world; ++r)
+    if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+  if (c->local) (void)hipFree(c->local);
+  (void)hipGetLastError();
+  delete c;
+  return 0;
+}
+
+extern "C" int mi_comm_status(void* comm, int64_t* seq_out, int64_t* errors_out) {
+  MI_REQUIRE(comm, "mi_comm_status: null comm");
+  Comm* c = static_cast<Comm*>(comm);
+  CommHeader h = {};
+  hipError_t e = hipMemcpy(&h, c->local, sizeof(h), hipMemcpyDeviceToHost);  // synchronises
+  if (e != hipSuccess) {
+    mippo::set_error("mi_comm_status: %s", hipGetErrorString(e));
+    return -EIO;
+  }
+  if (seq_out) *seq_out = (int64_t)h.seq;
+  if (errors_out) *errors_out = (int64_t)h.errors;
+  return 0;
+}
+
+extern "C" int64_t mi_comm_slot_bytes(void* comm) {
+  return comm ? static_cast<Comm*>(comm)->slot_bytes : -EINVAL;
+}
+
+#define COMM_READY(c, who)                                                          \
+  for (int r_ = 0; r_ < (c)->world; ++r_)                                            \
+    MI_REQUIRE((c)->peer[r_], who ": rank %d is not connected (mi_comm_connect)", r_)
+
+extern "C" int mi_allreduce_oneshot_f32(void* comm, float* buf, int64_t n, float scale,
+                                        mi_stream_t stream) {
+  MI_REQUIRE(comm && (buf || n == 0) && n >= 0, "mi_allreduce_oneshot_f32: bad arguments");
+  Comm* c = static_cast<Comm*>(comm);
+  COMM_READY(c, "mi_allreduce_oneshot_f32");
+  MI_REQUIRE(n * 4 <= c->slot_bytes, "mi_allreduce_oneshot_f32: %lld bytes exceed the slot (%lld)",
+             (long long)(n * 4), (long long)c->slot_bytes);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((allreduce_kernel<float>), dim3(grid_for(mippo::ceil_div(n * 4, kChunkBytes))),
+                     dim3(kThreads), 0, mippo::as_stream(stream), dev_view(c), buf, n, scale);
+  return mippo::check_launch("mi_allreduce_oneshot_f32");
+}
+
+extern "C" int mi_allreduce_oneshot_f64(void* comm, double* buf, int64_t n, double scale,
+                                        mi_stream_t stream) {
+  MI_REQUIRE(comm && (buf || n == 0) && n >= 0, "mi_allreduce_oneshot_f64: bad arguments");
+  Comm* c = static_cast<Comm*>(comm);
+  COMM_READY(c, "mi_allreduce_oneshot_f64");
+  MI_REQUIRE(n * 8 <= c->slot_bytes, "mi_allreduce_oneshot_f64: %lld bytes exceed the slot (%lld)",
+             (long long)(n * 8), (long long)c->slot_bytes);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((allreduce_kernel<double>), dim3(grid_for(mippo::ceil_div(n * 8, kChunkBytes))),
+                     dim3(kThreads), 0, mippo::as_stream(stream), dev_view(c), buf, n, scale);
+  return mippo::check_launch("mi_allreduce_oneshot_f64");
+}
+
+extern "C" int mi_allgather_oneshot(void* comm, const void* src, int64_t nbytes, void* dst,
+                                    mi_stream_t stream) {
+  MI_REQUIRE(comm && nbytes >= 0 && ((src && dst) || nbytes == 0),
+             "mi_allgather_oneshot: bad arguments");
+  Comm* c = static_cast<Comm*>(comm);
+  COMM_READY(c, "mi_allgather_oneshot");
+  MI_REQUIRE(nbytes <= c->slot_bytes, "mi_allgather_oneshot: %lld bytes exceed the slot (%lld)",
+             (long long)nbytes, (long long)c->slot_bytes);
+  if (nbytes == 0) return 0;
+  hipLaunchKernelGGL(allgather_kernel, dim3(grid_for(mippo::ceil_div(nbytes, kChunkBytes))),
+                     dim3(kThreads), 0, mippo::as_stream(stream), dev_view(c),
+                     static_cast<const char*>(src), nbytes, static_cast<char*>(dst));
+  return mippo::check_launch("mi_allgather_oneshot");
+}
+
+extern "C" int mi_adam_step_allreduce_f32(
+    void* comm, float* params, float* grads, float* m, float* v, int64_t n, float lr, float b1,
+    float b2, float eps, float weight_decay, int64_t* step, void* begin_next_ticket,
+    int64_t n_shadows, const int64_t* shadow_begin, const int64_t* shadow_K,
+    const int64_t* shadow_N, void* const* w_bf, void* const* wt_bf, void* const* frag_fwd,
+    void* const* frag_bwd, mi_stream_t stream) {
+  MI_REQUIRE(comm, "mi_adam_step_allreduce_f32: null comm");
+  Comm* c = static_cast<Comm*>(comm);
+  COMM_READY(c, "mi_adam_step_allreduce_f32");
+  MI_REQUIRE(n >= 1 && n * 4 <= c->slot_bytes,
+             "mi_adam_step_allreduce_f32: %lld bytes exceed the slot (%lld)", (long long)(n * 4),
+             (long long)c->slot_bytes);
+  mippo_optim::AdamArgs a;
+  int rc = mippo_optim::fill_adam_args(a, "mi_adam_step_allreduce_f32", params, grads, m, v, n, lr,
+                                       b1, b2, eps, weight_decay, step, nullptr, 0.0f,
+                                       begin_next_ticket, n_shadows, shadow_begin, shadow_K,
+                                       shadow_N, w_bf, wt_bf, frag_fwd, frag_bwd);
+  if (rc) return rc;
+  hipLaunchKernelGGL(adam_allreduce_kernel, dim3(grid_for(mippo::ceil_div(n * 4, kChunkBytes))),
+                     dim3(kThreads), 0, mippo::as_stream(stream), dev_view(c), a);
+  return mippo::check_launch("mi_adam_step_allreduce_f32");
+}

@@ -46,13 +46,16 @@ class VmapEnv:
         tensor leaves are mapped over axis 0, everything else is passed through."""
         leaves = [tree_leaves(t) for t in trees]
         flat = [x for ls in leaves for x in ls if _is_tensor(x)]
+        device = flat[0].device
         skeleton: list = [None]
 
         def call(*tensors):
             it = iter(tensors)
             args = [tree_map(lambda x: next(it) if _is_tensor(x) else x, t) for t in trees]
             out = fn(*args)
-            out = tree_map(lambda x: x if _is_tensor(x) else torch.as_tensor(x), out)
+            # Python numbers / bools the single-env code returned (reward=1.0, done=False)
+            out = tree_map(lambda x: x if _is_tensor(x) else torch.as_tensor(x, device=device),
+                           out)
             skeleton[0] = out
             return tuple(tree_leaves(out))
 

@@ -621,6 +621,37 @@ def ppo_loss(ll_new, ll_old, adv, values, reg, stats, clip_range: float, critic_
     return g_ll, g_v, loss_out
 
 
+def gae_ppo_loss_supported(T: int, N: int) -> bool:
+    return bool(lib().mi_gae_ppo_loss_supported(int(T), int(N)))
+
+
+def gae_ppo_loss(rewards, values, last_value, done, truncated, ll_new, ll_old, reg, gamma: float,
+                 lambda_: float, normalize: bool, clip_range: float, critic_weight: float,
+                 loss_out: torch.Tensor | None = None, want_adv: bool = False):
+    """GAE + advantage statistics + loss terms and gradients in one launch
+    (`mi_gae_ppo_loss_f32`).  All operands `[T, N]` (last_value `[N]`), reg may be None.
+    Returns (g_ll [T,N], g_v [T,N], loss_out [4], advantages | None)."""
+    T, N = rewards.shape
+    for t in (values, ll_new, ll_old, done, truncated):
+        _need(t.shape == (T, N), "gae_ppo_loss: operands must be [T, N]")
+    _need(reg is None or reg.numel() == T * N, "gae_ppo_loss: reg must be [T, N]")
+    _need(last_value.shape == (N,), "gae_ppo_loss: last_value must be [N]")
+    dev = rewards.device
+    g_ll = torch.empty(T, N, dtype=f32, device=dev)
+    g_v = torch.empty(T, N, dtype=f32, device=dev)
+    adv = torch.empty(T, N, dtype=f32, device=dev) if want_adv else None
+    if loss_out is None:
+        loss_out = torch.empty(4, dtype=f32, device=dev)
+    ws = workspace(dev, "gae_loss", lib().mi_gae_ppo_loss_workspace_bytes(), zeroed=True)
+    check(lib().mi_gae_ppo_loss_f32(
+        ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32), ptr(_as_u8(done), u8),
+        ptr(_as_u8(truncated), u8), ptr(ll_new, f32), ptr(ll_old, f32), ptr(reg, f32),
+        float(gamma), float(lambda_), int(bool(normalize)), float(clip_range),
+        float(critic_weight), ptr(adv, f32), None, ptr(g_ll, f32), ptr(g_v, f32),
+        ptr(loss_out, f32), ptr(ws), T, N, stream()), "mi_gae_ppo_loss_f32")
+    return g_ll, g_v, loss_out, adv
+
+
 # -------------------------------------------------------- a15: optimiser
 def begin_grad_step(grads: torch.Tensor, step: torch.Tensor | None) -> None:
     check(lib().mi_begin_grad_step_f32(ptr(grads, f32), grads.numel(), ptr(step, i64), stream()),

@@ -82,7 +82,23 @@ class Optimizer:
         (float32 [1]) receives the global norm of the gradient that is applied — in a
         sharded run the norm AFTER the all-reduce, the one `clip_by_global_norm` sees
         (`ppo.py:313-316`).  `have_norm`: `self.grad_norm` already holds it (single GPU)."""
+        from .networks import dense_chain
+
+        shadowed = dense_chain.shadows_in(self.params)[:16]
+        table = [(off, l.kernel.shape[0], l.kernel.shape[1], l._w_bf, l._wt_bf, l._ff, l._fb)
+                 for l, off in shadowed]
         if parallel.is_distributed():
+            comm = parallel.peer_comm()
+            if comm is not None and norm_out is None and self.gradient_clipping is None and \
+                    comm.adam_step_allreduce(
+                        self.params, self.grads, self.m, self.v, self.step,
+                        lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
+                        weight_decay=self.weight_decay, shadows=table):
+                # exchange + mean + Adam + bf16 images + gradient zeroing: one launch
+                self._clean = True
+                bump_param_epoch()
+                dense_chain.mark_fresh([l for l, _ in shadowed])
+                return
             parallel.allreduce_mean_(self.grads)
             have_norm = False
         gn = None
@@ -94,11 +110,6 @@ class Optimizer:
             gn = None  # logged only: the Adam launch must not clip
         # Dense kernels with bf16 shadows get the new values written into the shadows by
         # the same launch (up to 16 layers; the rest refresh lazily at their next use)
-        from .networks import dense_chain
-
-        shadowed = dense_chain.shadows_in(self.params)[:16]
-        table = [(off, l.kernel.shape[0], l.kernel.shape[1], l._w_bf, l._wt_bf, l._ff, l._fb)
-                 for l, off in shadowed]
         ops.adam_step(self.params, self.grads, self.m, self.v, self.step,
                       lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
                       weight_decay=self.weight_decay, grad_norm=gn,

@@ -94,7 +94,12 @@ def unroll_env(env, env_state, networks: Module, network_state, unroll_length: i
     # rollout.py:67-72: value_estimates leaves must match rewards leaves
     for v, r in zip(_leaves(stacked["value_estimates"]), _leaves(stacked["rewards"])):
         assert v.shape == r.shape
-    return carry[0], carry[1], Transition(**stacked)
+    # the carry that leaves the rollout is DATA (the reference stores arrays in
+    # TrainingState; `nnx.grad` differentiates the loss w.r.t. the parameters only,
+    # ppo.py:298-312): a learnable initial state reaches the loss through the resets
+    # inside the replay, not through the stored carry
+    final_net = _tmap(lambda x: x.detach() if isinstance(x, torch.Tensor) else x, carry[0])
+    return final_net, carry[1], Transition(**stacked)
 
 
 # ------------------------------------------------------------------------ gae
@@ -241,7 +246,8 @@ def new_training_state(env, networks: Module, n_envs, seed, keys, learning_rate=
     ks = keys.split(key)
     key, training_key = ks[0], ks[1]
     env_states = env.reset(keys.split(key, n_envs))
-    network_states = networks.initialize_state(n_envs)
+    network_states = _tmap(lambda x: x.detach() if isinstance(x, torch.Tensor) else x,
+                           networks.initialize_state(n_envs))
     opt = Adam(networks.parameters(), learning_rate, gradient_clipping, weight_decay)
     return TrainingState(networks, network_states, env_states, opt, training_key, 0)
 

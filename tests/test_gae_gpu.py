@@ -124,3 +124,66 @@ def test_fused_statistics(dev, T, N):
         # the separate statistics kernel agrees to fp64 rounding
         s2 = ops.adv_stats(plain).cpu().numpy()
         assert np.allclose(s, s2, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("T,N", [(30, 1024), (1, 1), (32, 16384), (7, 100), (30, 65), (12, 64)])
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("with_reg", [True, False])
+def test_fused_gae_loss_equals_two_launches(dev, T, N, normalize, with_reg):
+    """mi_gae_ppo_loss_f32 (ppo.py:351-394 + 456-503 in one launch) against
+    mi_gae_stats_f32 -> mi_ppo_loss_f32: advantages and both gradients bit for bit (the
+    statistics that normalise them are built by the same summation tree), the four loss
+    scalars to fp64 summation order.  Called three times: the workspace re-arms itself."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(T * 1000 + N)
+    t = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt).to(dev)
+    for rep in range(3):
+        r = t(rng.normal(size=(T, N)))
+        v = t(rng.normal(size=(T, N)))
+        lv = t(rng.normal(size=(N,)))
+        done = t(rng.random((T, N)) < 0.1, torch.bool)
+        trunc = done & t(rng.random((T, N)) < 0.5, torch.bool)
+        ll_old = t(rng.normal(-1.0, 0.3, size=(T, N)))
+        ll_new = ll_old + t(rng.normal(0.0, 0.2, size=(T, N)))
+        reg = t(rng.normal(size=(T, N))) if with_reg else None
+        if normalize:
+            adv, stats = ops.gae(r, v, lv, done, trunc, 0.99, 0.95, with_stats=True)
+        else:
+            adv, stats = ops.gae(r, v, lv, done, trunc, 0.99, 0.95), None
+        g_ll0, g_v0, lo0 = ops.ppo_loss(ll_new.reshape(-1), ll_old.reshape(-1), adv.reshape(-1),
+                                        v.reshape(-1), None if reg is None else reg.reshape(-1),
+                                        stats, 0.2, 0.7)
+        assert ops.gae_ppo_loss_supported(T, N)
+        g_ll, g_v, lo, adv1 = ops.gae_ppo_loss(r, v, lv, done, trunc, ll_new, ll_old, reg, 0.99,
+                                               0.95, normalize, 0.2, 0.7, want_adv=True)
+        assert torch.equal(adv1, adv)
+        assert torch.equal(g_ll.reshape(-1), g_ll0), float((g_ll.reshape(-1) - g_ll0).abs().max())
+        assert torch.equal(g_v.reshape(-1), g_v0)
+        assert torch.allclose(lo, lo0, rtol=1e-6, atol=1e-7), (lo, lo0)
+    assert not ops.gae_ppo_loss_supported(33, 64) and not ops.gae_ppo_loss_supported(8, 16385)
+
+
+def test_fused_gae_loss_in_ppo_step(dev):
+    """The iteration with the one-launch GAE + loss equals the two-launch one."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    outs = []
+    for fused in (True, False):
+        ppo.FUSED_GAE_LOSS = fused
+        try:
+            env = EpisodeWrapper(MockEnv(5, 1, max_steps=6), 50)
+            net = factories.make_mlp_actor_critic(5, 1, [32, 32], [64], Rngs(2))
+            ts = ppo.new_training_state(env, net, 128, 3, 1e-3, device=dev)
+            for _ in range(2):
+                ts, m = ppo.ppo_step(env, ts, 128, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
+            outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()}))
+        finally:
+            ppo.FUSED_GAE_LOSS = True
+    assert torch.equal(outs[0][0], outs[1][0])  # same gradients => same parameters
+    for k, v in outs[0][1].items():
+        assert np.isclose(v, outs[1][1][k], rtol=1e-6, atol=1e-8), k
