@@ -522,6 +522,17 @@ int mi_episode_step_select(const int64_t* counter, const void* inner_done, int d
                            const int64_t* row_bytes, int64_t n_leaves, int64_t B,
                            mi_stream_t stream);
 
+/* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
+ * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,
+ * done = step' >= max_steps, obs = unit-variance noise from fold(key, step') written to
+ * n_leaves <= 8 observation leaves [n, leaf_width[l]] (a PyTree observation is the flat
+ * draw cut at the leaf widths).  Bit-identical to mi_key_expand (unit-uniform, folded)
+ * followed by mi_episode_step. */
+int mi_mock_env_step(const int64_t* key, const int64_t* step_count, int64_t max_steps,
+                     int64_t* step_count_out, uint8_t* done_out, float* const* obs_leaf,
+                     const int64_t* leaf_width, int64_t n_leaves, int64_t n,
+                     mi_stream_t stream);
+
 /* a13 + a14 in ONE launch for a single reward key at minibatch size (T <= 32, N <= 16384;
  * mi_gae_ppo_loss_supported): `gae` (ppo.py:351-394), the advantage statistics and
  * normalisation (ppo.py:477-480, `normalize` != 0) and the loss terms with their gradients

@@ -39,9 +39,11 @@ from .metrics import compute_metrics, log_weight_stats
 from .types import LoggingLevel, TrainingState, Transition
 
 
-# MIPPO_FUSED_GAE_LOSS=0: GAE and loss as two launches (A/B timing, and what a sharded run
-# uses: the advantage statistics are exchanged between them)
-FUSED_GAE_LOSS = os.environ.get("MIPPO_FUSED_GAE_LOSS", "1") != "0"
+# MIPPO_FUSED_GAE_LOSS=1: GAE + loss as ONE launch (csrc/gae_loss.hip).  Off by default:
+# measured on one box (tools/microbench_gae_loss.py, [30, 1024]) the one-launch form takes
+# 22 us against 15 us for the two launches — one wave per 64 envs walks its 30 loss terms
+# serially where the loss launch spreads them over 30 720 threads.
+FUSED_GAE_LOSS = os.environ.get("MIPPO_FUSED_GAE_LOSS", "0") == "1"
 
 
 def default_config() -> TrainConfig:

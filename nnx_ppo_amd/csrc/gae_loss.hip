@@ -97,9 +97,11 @@ gae_loss_kernel(Args a) {
       s2 += __shfl_down(s2, off, 64);
     }
     if (threadIdx.x == 0) {
-      sp[2 * blockIdx.x] = s;
-      sp[2 * blockIdx.x + 1] = s2;
-      __threadfence();  // release: the partial is visible device-wide before the arrival
+      // write-through (sc1) stores + a drained wave + the arrival: no L2 write-back
+      // fence on the critical path (MI355X_MICROARCH: handoff-flag, drained sc1 form)
+      __hip_atomic_store(&sp[2 * blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sp[2 * blockIdx.x + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long t0 = wall_clock64();
       while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
@@ -108,7 +110,9 @@ gae_loss_kernel(Args a) {
       }
     }
     __syncthreads();
-    __threadfence();  // acquire: the other workgroups' partials
+    // acquire only (invalidate; nothing of this workgroup needs writing back here): the
+    // other workgroups' partials may sit stale in this XCD's L2 from the previous launch
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // the summation tree of gae_kernel<.., true>'s last block, evaluated by every
     // workgroup: lane-strided, then lane order — the same bits everywhere
     double t1 = 0.0, t2 = 0.0;
@@ -166,14 +170,16 @@ gae_loss_kernel(Args a) {
   __shared__ bool is_last;
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lp[4 * blockIdx.x + k] = q[k];
-    __threadfence();
+    for (int k = 0; k < 4; ++k)
+      __hip_atomic_store(&lp[4 * blockIdx.x + k], q[k], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
               (unsigned)G - 1;
   }
   __syncthreads();
   if (is_last) {
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double z[4] = {0.0, 0.0, 0.0, 0.0};
     for (int g = threadIdx.x; g < G; g += 64)
       for (int k = 0; k < 4; ++k)

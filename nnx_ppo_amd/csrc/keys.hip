@@ -92,6 +92,45 @@ episode_step_kernel(const int64_t* __restrict__ counter, const void* __restrict_
   }
 }
 
+// The whole step of the synthetic benchmark env (envs/synthetic.py: MockEnv.step, restating
+// `nnx_ppo/test_dummies/mock_env.py:25-63`) in ONE launch: step' = step + 1,
+// done = step' >= max_steps, obs = unit_uniform(fold_key(key, step'), (O,)) written into
+// up to 8 observation leaves (a PyTree observation is the flat draw cut at the leaf
+// widths).  Same integer / float expressions as key_expand_kernel (OUT_UNIT_UNIFORM with a
+// fold) and episode_step_kernel, which this replaces for that env: bit-identical.
+struct MockObs {
+  float* leaf[8];
+  int width[8];
+  int n_leaves, total;
+};
+__global__ void __launch_bounds__(kThreads)
+mock_env_step_kernel(const int64_t* __restrict__ key, const int64_t* __restrict__ count,
+                     int64_t max_steps, int64_t* __restrict__ count_out,
+                     uint8_t* __restrict__ done_out, MockObs o, int64_t n) {
+  const int64_t total = n * o.total;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = e / o.total;
+    int j = (int)(e - i * o.total);
+    const int64_t step = count[i] + 1;
+    if (j == 0) {
+      count_out[i] = step;
+      done_out[i] = step >= max_steps ? 1 : 0;
+    }
+    const uint64_t k = mix((uint64_t)key[i] ^ mix((uint64_t)step + kGolden));
+    const uint64_t b = mix(mix(k) ^ ((uint64_t)(j + 1) * kM2));
+    const float u = (float)(int64_t)(b >> 40) * (1.0f / 16777216.0f);
+    const float v = (u - 0.5f) * 3.4641016151377544f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      if (l < o.n_leaves) {
+        if (j >= 0 && j < o.width[l]) o.leaf[l][i * o.width[l] + j] = v;
+        j -= o.width[l];
+      }
+    }
+  }
+}
+
 // Minibatch permutations (ppo.py:284-294): block e sorts the n hashes of key
 // fold_in(key, e) and writes the argsort — `random.permutation(fold_in(key, e), n)`
 // for every epoch in ONE launch.  (key, index) pairs make the order total, so the
@@ -193,6 +232,29 @@ extern "C" int mi_episode_step(const int64_t* counter, const void* inner_done, i
                      mippo::as_stream(stream), counter, inner_done, done_is_float, inner_truncated,
                      max_len, counter_out, truncated_out, done_out, done_flag_out, n);
   return mippo::check_launch("mi_episode_step");
+}
+
+extern "C" int mi_mock_env_step(const int64_t* key, const int64_t* step_count, int64_t max_steps,
+                                int64_t* step_count_out, uint8_t* done_out,
+                                float* const* obs_leaf, const int64_t* leaf_width,
+                                int64_t n_leaves, int64_t n, mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && n_leaves >= 1 && n_leaves <= 8, "mi_mock_env_step: 1 <= n_leaves <= 8");
+  if (n == 0) return 0;
+  MI_REQUIRE(key && step_count && step_count_out && done_out && obs_leaf && leaf_width,
+             "mi_mock_env_step: null pointer");
+  MockObs o = {};
+  o.n_leaves = (int)n_leaves;
+  for (int64_t l = 0; l < n_leaves; ++l) {
+    MI_REQUIRE(obs_leaf[l] && leaf_width[l] >= 1 && leaf_width[l] <= (1 << 20),
+               "mi_mock_env_step: bad leaf %lld", (long long)l);
+    o.leaf[l] = obs_leaf[l];
+    o.width[l] = (int)leaf_width[l];
+    o.total += (int)leaf_width[l];
+  }
+  hipLaunchKernelGGL(mock_env_step_kernel, dim3(stream_grid(n * o.total)), dim3(kThreads), 0,
+                     mippo::as_stream(stream), key, step_count, max_steps, step_count_out,
+                     done_out, o, n);
+  return mippo::check_launch("mi_mock_env_step");
 }
 
 extern "C" int mi_key_permutations(const int64_t* key, int64_t* out, int64_t n_perm, int64_t n,

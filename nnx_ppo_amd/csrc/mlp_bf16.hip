@@ -32,6 +32,7 @@
 //           (.) act'_{l-1}(y_{l-1}); the y_{l-1} values a lane needs are loaded
 //           global -> VGPR before the layer's last MFMAs; every dz_l is copied out
 //           (bf16) for the grouped dW launch.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -157,13 +158,17 @@ struct BFrags {
 // 256 rows — for trunks no wider than 64, where a wave has ONE column tile anyway and
 // three of four slots idled: the same accumulator and operand registers hold 4x the rows,
 // so a quarter of the workgroups pay the per-workgroup latency chain.
-template <int RT, bool BWD, bool POLICY, int NB = 4>
+// INPLACE: ONE activation buffer instead of the ping-pong pair (half the LDS, so more
+// workgroups per CU): a layer's outputs overwrite its inputs, which needs every wave to
+// have finished READING the inputs first — one more barrier per layer, in front of the
+// epilogue — and every layer to be a single column pass (N <= 64 * NB; checked on the host).
+template <int RT, bool BWD, bool POLICY, int NB = 4, bool INPLACE = false>
 __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px) {
   constexpr int ROWS = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int arow = c.arow;
   bf16_t* const act0 = reinterpret_cast<bf16_t*>(lds_raw);
-  bf16_t* const act1 = act0 + ROWS * arow;
+  bf16_t* const act1 = INPLACE ? act0 : act0 + ROWS * arow;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   // wave-uniform by construction; telling the compiler so keeps the column-tile
@@ -688,6 +693,7 @@ __device__ __forceinline__ void chain_body(const Chain& c, const PolicyExtra* px
       bool head = false;
       if constexpr (!BWD)
         head = st.l == cL - 1 && ly.act == MI_ACT_NONE && !ly.out_bf && !ly.pre_bf;
+      if constexpr (INPLACE) __syncthreads();  // every wave has read this layer's inputs
       if (hidden_relu) {
         epilogue_hidden_relu(st, ly);
       } else if (head) {
@@ -747,28 +753,48 @@ mlp_chain_kernel(Chain c) {
 }
 
 // blockIdx.y = 0: action trunk with (RT_A, NB_A), 1: value trunk with (RT_V, NB_V).  Equal
-// shapes share ONE instance of the body (instruction cache).
-template <bool BWD, int RT_A, int NB_A, int RT_V, int NB_V>
+// shapes share ONE instance of the body (instruction cache).  WPS = waves per SIMD the
+// register allocation must leave room for (2: <= 256 VGPRs, 3: <= 168, 4: <= 128).
+template <bool BWD, int RT_A, int NB_A, int RT_V, int NB_V, bool INPLACE>
 __device__ __forceinline__ void policy_trunk(const PolicyArgs& a) {
   if constexpr (RT_A == RT_V && NB_A == NB_V) {
-    chain_body<RT_A, BWD, true, NB_A>(a.c[blockIdx.y], &a.px);
+    chain_body<RT_A, BWD, true, NB_A, INPLACE>(a.c[blockIdx.y], &a.px);
   } else if (blockIdx.y == 0) {
-    chain_body<RT_A, BWD, true, NB_A>(a.c[0], &a.px);
+    chain_body<RT_A, BWD, true, NB_A, INPLACE>(a.c[0], &a.px);
   } else {
-    chain_body<RT_V, BWD, true, NB_V>(a.c[1], &a.px);
+    chain_body<RT_V, BWD, true, NB_V, INPLACE>(a.c[1], &a.px);
   }
 }
 
-template <int RT_A, int NB_A, int RT_V, int NB_V>
-__global__ void __launch_bounds__(kThreads, 2)
+template <int RT_A, int NB_A, int RT_V, int NB_V, bool INPLACE = false, int WPS = 2>
+__global__ void __launch_bounds__(kThreads, WPS)
 policy_kernel(PolicyArgs a) {
-  policy_trunk<false, RT_A, NB_A, RT_V, NB_V>(a);
+  policy_trunk<false, RT_A, NB_A, RT_V, NB_V, INPLACE>(a);
 }
 
-template <int RT_A, int NB_A, int RT_V, int NB_V>
-__global__ void __launch_bounds__(kThreads, 2)
+template <int RT_A, int NB_A, int RT_V, int NB_V, bool INPLACE = false, int WPS = 2>
+__global__ void __launch_bounds__(kThreads, WPS)
 policy_bwd_kernel(PolicyArgs a) {
-  policy_trunk<true, RT_A, NB_A, RT_V, NB_V>(a);
+  policy_trunk<true, RT_A, NB_A, RT_V, NB_V, INPLACE>(a);
+}
+
+// Tuning aid: MIPPO_POLICY_SHAPE="RT_A,NB_A,RT_V,NB_V,INPLACE,WPS" picks the instantiation
+// of the training-size policy kernels (builds with -DMIPPO_POLICY_VARIANTS carry the
+// whole menu; tools/microbench_policy.py sweeps it).
+struct PolicyShape {
+  int rt_a, nb_a, rt_v, nb_v, inplace, wps;
+  bool set;
+};
+const PolicyShape& policy_shape_override() {
+  static const PolicyShape ps = [] {
+    PolicyShape p = {0, 0, 0, 0, 0, 0, false};
+    const char* e = getenv("MIPPO_POLICY_SHAPE");
+    if (e && sscanf(e, "%d,%d,%d,%d,%d,%d", &p.rt_a, &p.nb_a, &p.rt_v, &p.nb_v, &p.inplace,
+                    &p.wps) == 6)
+      p.set = true;
+    return p;
+  }();
+  return ps;
 }
 
 // A trunk no wider than 64 has one column tile per wave: at training sizes it runs with
@@ -875,11 +901,16 @@ int fill_fwd_chain(Chain& c, const char* who, const float* x, int64_t M, int64_t
   return 0;
 }
 
-template <int RT_A, int NB_A, int RT_V, int NB_V>
+template <int RT_A, int NB_A, int RT_V, int NB_V, bool INPLACE = false, int WPS = 2>
 int launch_policy(PolicyArgs& a, int wa, int wc, hipStream_t st) {
   constexpr int ROWS_A = 16 * RT_A, ROWS_V = 16 * RT_V;
-  const int act_a = 2 * ROWS_A * (wa + 8) * (int)sizeof(bf16_t);
-  const int act_v = 2 * ROWS_V * (wc + 8) * (int)sizeof(bf16_t);
+  constexpr int NBUF = INPLACE ? 1 : 2;
+  if (INPLACE)
+    MI_REQUIRE(wa <= 64 * NB_A && wc <= 64 * NB_V,
+               "policy_kernel: the in-place form needs single-pass layers (%d / %d columns)",
+               64 * NB_A, 64 * NB_V);
+  const int act_a = NBUF * ROWS_A * (wa + 8) * (int)sizeof(bf16_t);
+  const int act_v = NBUF * ROWS_V * (wc + 8) * (int)sizeof(bf16_t);
   a.px.ms_off = act_a;  // only the action trunk has the sampler's fp32 rows
   const int ms_bytes = (ROWS_A * 2 * a.px.samp.A * (int)sizeof(float) + 15) / 16 * 16;
   a.c[0].bias_off = act_a + ms_bytes;
@@ -892,16 +923,34 @@ int launch_policy(PolicyArgs& a, int wa, int wc, hipStream_t st) {
                         kRowsMax * 128 * (int)sizeof(float) + CH_MAXL * 512 * 4;
   constexpr int kCap = kWant < kLdsMax ? kWant : kLdsMax;
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&policy_kernel<RT_A, NB_A, RT_V, NB_V>),
+      reinterpret_cast<const void*>(&policy_kernel<RT_A, NB_A, RT_V, NB_V, INPLACE, WPS>),
       hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
   MI_REQUIRE(attr == hipSuccess, "policy_kernel: cannot raise the dynamic LDS limit: %s",
              hipGetErrorString(attr));
   MI_REQUIRE(lds <= (size_t)kCap, "policy_kernel: %zu bytes of LDS needed, %d available", lds, kCap);
   const int64_t ga = mippo::ceil_div(a.c[0].M, ROWS_A), gv = mippo::ceil_div(a.c[1].M, ROWS_V);
-  hipLaunchKernelGGL((policy_kernel<RT_A, NB_A, RT_V, NB_V>),
+  hipLaunchKernelGGL((policy_kernel<RT_A, NB_A, RT_V, NB_V, INPLACE, WPS>),
                      dim3((unsigned)(ga > gv ? ga : gv), 2), dim3(kThreads), lds, st, a);
   return mippo::check_launch("mi_policy_fwd_bf16");
 }
+
+// the menu of training-size instantiations (see policy_shape_override)
+#define MI_POLICY_MENU(X)     \
+  X(16, 1, 4, 4, false, 2)    \
+  X(4, 4, 4, 4, false, 2)
+#ifdef MIPPO_POLICY_VARIANTS
+#define MI_POLICY_MENU_EXTRA(X) \
+  X(16, 1, 4, 4, true, 2)       \
+  X(16, 1, 4, 4, true, 3)       \
+  X(16, 1, 4, 4, false, 3)      \
+  X(8, 1, 2, 4, true, 4)        \
+  X(8, 1, 3, 4, true, 3)        \
+  X(16, 1, 6, 4, true, 2)       \
+  X(12, 1, 6, 4, true, 2)       \
+  X(8, 1, 4, 4, true, 3)
+#else
+#define MI_POLICY_MENU_EXTRA(X)
+#endif
 
 }  // namespace
 
@@ -966,6 +1015,17 @@ extern "C" int mi_policy_fwd_bf16(
   if (M + M_tail <= 8192) return launch_policy<1, 4, 1, 4>(a, wa, wc, st);
   MI_REQUIRE(maxw <= 256, "mi_policy_fwd_bf16: trunks wider than 256 take at most 8192 rows "
                           "(use mi_mlp_fwd_bf16 per trunk)");
+  const PolicyShape& ps = policy_shape_override();
+  if (ps.set) {
+#define MI_X(RA, NA, RV, NV, IP, W)                                                       \
+  if (ps.rt_a == RA && ps.nb_a == NA && ps.rt_v == RV && ps.nb_v == NV &&                 \
+      (ps.inplace != 0) == IP && ps.wps == W && (NA == 4 || wa <= 64))                    \
+    return launch_policy<RA, NA, RV, NV, IP, W>(a, wa, wc, st);
+    MI_POLICY_MENU(MI_X)
+    MI_POLICY_MENU_EXTRA(MI_X)
+#undef MI_X
+    MI_REQUIRE(false, "mi_policy_fwd_bf16: MIPPO_POLICY_SHAPE names no built instantiation");
+  }
   if (wa <= 64 && narrow_trunk_enabled()) return launch_policy<16, 1, 4, 4>(a, wa, wc, st);
   return launch_policy<4, 4, 4, 4>(a, wa, wc, st);
 }
@@ -1029,24 +1089,29 @@ int fill_bwd_chain(Chain& c, const char* who, const float* g_out, const void* au
   return 0;
 }
 
-template <int RT_A, int NB_A, int RT_V, int NB_V>
+template <int RT_A, int NB_A, int RT_V, int NB_V, bool INPLACE = false, int WPS = 2>
 int launch_policy_bwd(PolicyArgs& a, int wa, int wc, hipStream_t st) {
   constexpr int ROWS_A = 16 * RT_A, ROWS_V = 16 * RT_V;
-  const size_t lds_a = (size_t)2 * ROWS_A * (wa + 8) * sizeof(bf16_t);
-  const size_t lds_v = (size_t)2 * ROWS_V * (wc + 8) * sizeof(bf16_t);
+  constexpr int NBUF = INPLACE ? 1 : 2;
+  if (INPLACE)
+    MI_REQUIRE(wa <= 64 * NB_A && wc <= 64 * NB_V,
+               "policy_bwd_kernel: the in-place form needs single-pass layers (%d / %d columns)",
+               64 * NB_A, 64 * NB_V);
+  const size_t lds_a = (size_t)NBUF * ROWS_A * (wa + 8) * sizeof(bf16_t);
+  const size_t lds_v = (size_t)NBUF * ROWS_V * (wc + 8) * sizeof(bf16_t);
   const size_t lds = lds_a > lds_v ? lds_a : lds_v;
   constexpr int kRowsMax = ROWS_A > ROWS_V ? ROWS_A : ROWS_V;
   constexpr int kWant = 2 * kRowsMax * (512 + 8) * (int)sizeof(bf16_t);
   constexpr int kCap = kWant < kLdsMax ? kWant : kLdsMax;
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&policy_bwd_kernel<RT_A, NB_A, RT_V, NB_V>),
+      reinterpret_cast<const void*>(&policy_bwd_kernel<RT_A, NB_A, RT_V, NB_V, INPLACE, WPS>),
       hipFuncAttributeMaxDynamicSharedMemorySize, kCap);
   MI_REQUIRE(attr == hipSuccess, "policy_bwd_kernel: cannot raise the dynamic LDS limit: %s",
              hipGetErrorString(attr));
   MI_REQUIRE(lds <= (size_t)kCap, "policy_bwd_kernel: %zu bytes of LDS needed, %d available", lds,
              kCap);
   const int64_t ga = mippo::ceil_div(a.c[0].M, ROWS_A), gv = mippo::ceil_div(a.c[1].M, ROWS_V);
-  hipLaunchKernelGGL((policy_bwd_kernel<RT_A, NB_A, RT_V, NB_V>),
+  hipLaunchKernelGGL((policy_bwd_kernel<RT_A, NB_A, RT_V, NB_V, INPLACE, WPS>),
                      dim3((unsigned)(ga > gv ? ga : gv), 2), dim3(kThreads), lds, st, a);
   return mippo::check_launch("mi_policy_bwd_bf16");
 }
@@ -1108,6 +1173,17 @@ extern "C" int mi_policy_bwd_bf16(
   if (M <= 8192) return launch_policy_bwd<1, 4, 1, 4>(a, wa, wc, st);
   MI_REQUIRE(maxw <= 256, "mi_policy_bwd_bf16: trunks wider than 256 take at most 8192 rows "
                           "(use mi_mlp_bwd_dx_bf16 per trunk)");
+  const PolicyShape& ps = policy_shape_override();
+  if (ps.set) {
+#define MI_X(RA, NA, RV, NV, IP, W)                                                       \
+  if (ps.rt_a == RA && ps.nb_a == NA && ps.rt_v == RV && ps.nb_v == NV &&                 \
+      (ps.inplace != 0) == IP && ps.wps == W && (NA == 4 || wa <= 64))                    \
+    return launch_policy_bwd<RA, NA, RV, NV, IP, W>(a, wa, wc, st);
+    MI_POLICY_MENU(MI_X)
+    MI_POLICY_MENU_EXTRA(MI_X)
+#undef MI_X
+    MI_REQUIRE(false, "mi_policy_bwd_bf16: MIPPO_POLICY_SHAPE names no built instantiation");
+  }
   if (wa <= 64 && narrow_trunk_enabled()) return launch_policy_bwd<16, 1, 4, 4>(a, wa, wc, st);
   return launch_policy_bwd<4, 4, 4, 4>(a, wa, wc, st);
 }

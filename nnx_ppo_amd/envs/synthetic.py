@@ -50,19 +50,26 @@ class MockEnv:
     def step(self, state: State, action: torch.Tensor) -> State:
         key = state.data["key"]
         count = state.data["step_count"]
-        if count.is_cuda:
-            # counter + 1 and the `>= max_steps` flag in one launch (the episode
-            # bookkeeping kernel with no inner done)
+        if count.is_cuda and count.dim() == 1 and not rnd._TORCH_ONLY[0]:
+            # the whole step — counter, done flag and the observation draw — in one launch
+            # (csrc/keys.hip: mi_mock_env_step); the same integers and floats as below
             from .. import ops
 
-            step, done, _, _ = ops.episode_step(
-                count, constant(count.shape, torch.bool, 0, count.device), None, self.max_steps)
+            if isinstance(self.obs_size, dict):
+                names = sorted(self.obs_size)
+                step, done, leaves = ops.mock_env_step(key, count, self.max_steps,
+                                                       [self.obs_size[n] for n in names])
+                obs = dict(zip(names, leaves))
+            else:
+                step, done, (obs,) = ops.mock_env_step(key, count, self.max_steps,
+                                                       [self.obs_size])
         else:
             step = count + 1
             done = step >= self.max_steps
+            obs = self._obs(key, step)
         return State(
             data={"key": key, "step_count": step},
-            obs=self._obs(key, step),
+            obs=obs,
             reward=constant(step.shape, torch.float32, 1.0, step.device),
             done=done,
             metrics={}, info={})

@@ -900,6 +900,24 @@ def key_expand(keys: torch.Tensor, m: int, mode: int, minval: int = 0, maxval: i
     return out
 
 
+def mock_env_step(key: torch.Tensor, step_count: torch.Tensor, max_steps: int, widths: list):
+    """MockEnv.step in one launch: returns (step_count + 1, done (bool), [obs leaf [n, w]...])."""
+    _need(key.dtype == i64 and step_count.dtype == i64 and key.shape == step_count.shape
+          and key.dim() == 1, "mock_env_step: key / step_count must be int64 [n]")
+    _need(1 <= len(widths) <= 8, "mock_env_step: 1..8 observation leaves")
+    n = key.shape[0]
+    dev = key.device
+    count_out = torch.empty_like(step_count)
+    done = torch.empty(n, dtype=torch.bool, device=dev)
+    leaves = [torch.empty(n, int(w), dtype=f32, device=dev) for w in widths]
+    nl = len(widths)
+    check(lib().mi_mock_env_step(
+        ptr(key.contiguous(), i64), ptr(step_count.contiguous(), i64), int(max_steps),
+        ptr(count_out, i64), ptr(done.view(u8)), (ctypes.c_void_p * nl)(*[ptr(t) for t in leaves]),
+        (ctypes.c_int64 * nl)(*[int(w) for w in widths]), nl, n, stream()), "mi_mock_env_step")
+    return count_out, done, leaves
+
+
 def key_permutations(key: torch.Tensor, n_perm: int, n: int) -> torch.Tensor:
     """int64 [n_perm, n]: row e = random.permutation(random.fold_in(key, e), n)."""
     _need(key.dtype == i64 and key.numel() == 1, "key_permutations: one int64 key")

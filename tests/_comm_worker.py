@@ -185,13 +185,15 @@ def scenario_timeout(rank, world, dev, comm, out_dir):
     x = torch.ones(1000, device=dev)
     comm.allreduce_(x, 1.0)           # one good collective
     torch.cuda.synchronize()
+    seq0, err0 = comm.status()
+    assert err0 == 0
     if rank == 0:
         t0 = time.perf_counter()
         comm.allreduce_(x, 1.0)       # rank 1 never issues this one
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         seq, err = comm.status()
-        assert err >= 1 and seq == 2, (seq, err)
+        assert err >= 1 and seq == seq0 + 1, (seq0, seq, err)
         assert 1.5 < dt < 15.0, dt
         try:
             comm.check()

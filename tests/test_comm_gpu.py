@@ -71,8 +71,8 @@ def test_sharded_ppo_step_equals_single_process(dev, tmp_path):
     assert np.allclose(cpu(r0["norm_m2"]), cpu(ref["norm_m2"]), rtol=1e-5, atol=1e-4)
     for it in range(2):
         for k, want in ref["metrics"][it].items():
-            if k == "total_steps":
-                continue
+            if not k.startswith("losses/"):
+                continue  # rollout statistics (loglikelihood/...) are per shard by nature
             got0, got1 = r0["metrics"][it][k], r1["metrics"][it][k]
             assert got0 == got1, k                       # logged values agree across ranks
             assert np.isclose(got0, want, rtol=2e-4, atol=2e-6), (it, k, got0, want)

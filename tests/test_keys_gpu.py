@@ -232,3 +232,27 @@ def test_gather_cols_multi_groups(dev):
         for a, b, src in zip(got, want, leaves):
             assert a.shape == (G, src.shape[0], mb, *src.shape[2:]) and a[k].is_contiguous()
             assert torch.equal(a[k], b) and torch.equal(b, src[:, idx[k]])
+
+
+@pytest.mark.parametrize("obs_size", [5, 1, {"position": 8, "velocity": 9}, {"a": 1, "b": 2, "c": 3}])
+def test_mock_env_step_one_launch_equals_host_statement(dev, obs_size):
+    """MockEnv.step on the GPU is ONE launch (mi_mock_env_step); the CPU path is the plain
+    torch statement of the same env (`test_dummies/mock_env.py:25-63` restated): counters,
+    done flags and every observation leaf agree bit for bit over an episode."""
+    from nnx_ppo_amd import _lib
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.tree import tree_leaves
+
+    n = 1000
+    k_cpu = keys.split(keys.key(9), n)
+    k_gpu = k_cpu.to(dev)
+    env = MockEnv(obs_size, 2, max_steps=4)
+    s_cpu, s_gpu = env.reset(k_cpu), env.reset(k_gpu)
+    for _ in range(6):
+        with _lib.profiler as prof:
+            s_gpu = env.step(s_gpu, None)
+        assert [r[0] for r in prof.records] == ["mi_mock_env_step"]
+        s_cpu = env.step(s_cpu, None)
+        for a, b in zip(tree_leaves(s_gpu), tree_leaves(s_cpu)):
+            assert a.dtype == b.dtype and torch.equal(a.cpu(), b), (a.dtype, b.dtype)
+    assert bool(s_gpu.done.all())
