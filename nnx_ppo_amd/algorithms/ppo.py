@@ -39,11 +39,10 @@ from .metrics import compute_metrics, log_weight_stats
 from .types import LoggingLevel, TrainingState, Transition
 
 
-# MIPPO_FUSED_GAE_LOSS=1: GAE + loss as ONE launch (csrc/gae_loss.hip).  Off by default:
-# measured on one box (tools/microbench_gae_loss.py, [30, 1024]) the one-launch form takes
-# 22 us against 15 us for the two launches — one wave per 64 envs walks its 30 loss terms
-# serially where the loss launch spreads them over 30 720 threads.
-FUSED_GAE_LOSS = os.environ.get("MIPPO_FUSED_GAE_LOSS", "0") == "1"
+# GAE + loss as ONE launch (csrc/gae_loss.hip; 12.6 us against 15.1 us for the two launches
+# at [30, 1024], tools/microbench_gae_loss.py).  MIPPO_FUSED_GAE_LOSS=0: two launches (A/B
+# timing; also what a sharded run uses — the advantage statistics are exchanged in between).
+FUSED_GAE_LOSS = os.environ.get("MIPPO_FUSED_GAE_LOSS", "1") != "0"
 
 
 def default_config() -> TrainConfig:

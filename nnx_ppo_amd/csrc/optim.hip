@@ -67,6 +67,7 @@ adam_kernel(mippo_optim::AdamArgs a) {
     if (i >= a.n) break;
     mippo_optim::adam_element(a, st, i, pass_begin, a.g[i]);
   }
+  mippo_optim::adam_end(a, st);
 }
 
 int stream_grid(int64_t n) {

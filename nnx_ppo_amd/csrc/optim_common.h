@@ -40,6 +40,7 @@ struct AdamStep {
   int64_t s0;
   float bc1, bc2, gn;
   bool clip;
+  unsigned int arrival;  // thread 0: this block's position among the "step read" signals
 };
 
 // index of (column c, reduce element r) in a fragment-major image with R reduce elements
@@ -52,8 +53,8 @@ __device__ inline int64_t frag_index(int c, int r, int R) {
 // Every thread: read the step count and derive the bias corrections.  With a ticket the
 // launch counts itself: each block signals (relaxed, agent scope) that all its waves have
 // READ `step`, and the block whose signal arrives last — at which point nobody will read
-// the old value again — publishes step + 1 and re-arms the ticket.  Nothing else is ordered
-// by that counter, so there is no fence and no spin.
+// the old value again — publishes step + 1 and re-arms the ticket (adam_end).  Nothing else
+// is ordered by that counter, so there is no fence and no spin.
 __device__ inline AdamStep adam_begin(const AdamArgs& a) {
   AdamStep st;
   st.s0 = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -66,16 +67,11 @@ __device__ inline AdamStep adam_begin(const AdamArgs& a) {
     st.gn = *a.grad_norm;
     st.clip = !(st.gn < a.max_norm);
   }
+  st.arrival = 0;
   if (a.ticket) {
     __syncthreads();  // every wave of this block has read `step`
-    if (threadIdx.x == 0) {
-      const unsigned int blocks = gridDim.x * gridDim.y * gridDim.z;
-      if (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-          blocks - 1) {
-        __hip_atomic_store(a.step, st.s0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (threadIdx.x == 0)  // the returned position is looked at in adam_end: no wait here
+      st.arrival = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return st;
 }
@@ -115,7 +111,17 @@ __device__ inline void adam_element(const AdamArgs& a, const AdamStep& st, int64
   }
 }
 
-__device__ inline void adam_end(const AdamArgs&, const AdamStep&) {}
+// The block whose signal arrived last publishes step + 1 and re-arms the ticket (every
+// block has read the old value by then; see adam_begin).
+__device__ inline void adam_end(const AdamArgs& a, const AdamStep& st) {
+  if (a.ticket && threadIdx.x == 0) {
+    const unsigned int blocks = gridDim.x * gridDim.y * gridDim.z;
+    if (st.arrival == blocks - 1) {
+      __hip_atomic_store(a.step, st.s0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 // Host: validate and pack the C-ABI arguments.
 inline int fill_adam_args(AdamArgs& a, const char* who, float* params, float* grads, float* m,

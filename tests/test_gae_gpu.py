@@ -183,7 +183,7 @@ def test_fused_gae_loss_in_ppo_step(dev):
                 ts, m = ppo.ppo_step(env, ts, 128, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
             outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()}))
         finally:
-            ppo.FUSED_GAE_LOSS = False
+            ppo.FUSED_GAE_LOSS = True
     assert torch.equal(outs[0][0], outs[1][0])  # same gradients => same parameters
     for k, v in outs[0][1].items():
         assert np.isclose(v, outs[1][1][k], rtol=1e-6, atol=1e-8), k

@@ -78,6 +78,8 @@ if __name__ == "__main__":
                 env.pop("MIPPO_POLICY_SHAPE", None)
             r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True,
                                timeout=300)
-            print(r.stdout.strip() or f"{shape}: FAILED {r.stderr[-400:]}", flush=True)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            err = r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ""
+            print(lines[-1] if lines else f"{shape or 'default'}: FAILED {err}", flush=True)
     else:
         one()
