@@ -522,6 +522,18 @@ int mi_episode_step_select(const int64_t* counter, const void* inner_done, int d
                            const int64_t* row_bytes, int64_t n_leaves, int64_t B,
                            mi_stream_t stream);
 
+/* Weights-stationary form of mi_mlp_fwd_bf16 for training sizes (csrc/trunk_ws.hip): one
+ * workgroup per CU keeps the whole trunk in registers and loops over row tiles.  Shape
+ * class (mi_mlp_ws_supported): dims = [K0 <= 32, H, ..., H, N_out <= 16] with
+ * H in {64, 128, 256} and at most 3 / 2 / 1 H x H layers, relu on every hidden layer, a
+ * linear head.  Same operands as mi_mlp_fwd_bf16 (fragment-major forward images, fp32
+ * biases, fp32 input); y_bf[l] (l < L - 1) and x_bf are the bf16 images kept for the
+ * backward (nullable: inference).  Bit-identical to mi_mlp_fwd_bf16. */
+int mi_mlp_ws_supported(int64_t L, const int64_t* dims, const int64_t* acts);
+int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
+                       const float* const* bias, const int64_t* dims, const int64_t* acts,
+                       float* out, void* const* y_bf, void* x_bf, mi_stream_t stream);
+
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
  * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,
  * done = step' >= max_steps, obs = unit-variance noise from fold(key, step') written to

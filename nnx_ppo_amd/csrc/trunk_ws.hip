@@ -1,0 +1,414 @@
+// a9 (bf16 path, training sizes) — weights-STATIONARY whole-trunk kernels.
+//
+// mlp_bf16.hip gives every 64-row tile its own workgroup: each one fetches the trunk's
+// weight fragments again (134 KB from L2 for the 5-256-256-1 critic), stages biases,
+// warms L2, copies every layer's image out of LDS in a separate pass, and lives ~37 000
+// cycles for ~4 000 cycles of MFMA (profiles/r01_trace_policy_v36.txt).  At training
+// sizes (M = T x minibatch = 30 720 rows) there are ~2 tiles per CU, so all of that is
+// paid twice per CU per launch.
+//
+// Here ONE 8-wave workgroup per CU keeps the whole trunk in REGISTERS — every wave holds
+// the fragments of its own output-column tiles of every layer (the 256 x 256 layer is 64
+// VGPRs per lane when split over 8 waves; two waves per SIMD, <= 256 registers each, so
+// one wave's epilogue / copy-out overlaps its partner's MFMAs) — and walks row tiles in a
+// loop: the input tile of the NEXT row tile is requested before the
+// current one is computed, activations ping-pong through LDS as before (a wave needs every
+// column of the previous layer), each layer's bf16 image is copied out of its LDS buffer in
+// whole 16-byte-per-lane rows while the next layer multiplies, biases sit in registers.
+// Per row tile nothing is loaded but the tile's own input.
+//
+// Shape class (checked on the host, everything else keeps the mlp_bf16.hip kernels):
+//   K0 <= 32 inputs -> H -> (H -> H) x NH -> N_out <= 16, H in {64, 128, 256},
+//   hidden activation relu, linear head, fragments fit the register file.
+// That covers make_mlp_actor_critic's trunks with equal hidden sizes (BASELINE C2:
+// actor 5-64-64-64-64-2 = <64, 3>, critic 5-256-256-1 = <256, 1>).
+//
+// Arithmetic is mlp_bf16.hip's, instruction for instruction where it matters: the same
+// transposed 16x16x32 bf16 MFMA tiles accumulated over k-steps in the same order, the
+// same bias + relu + round-to-bf16 epilogue — results are bit-identical to
+// mi_mlp_fwd_bf16 (tests/test_trunk_ws_gpu.py).
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace {
+
+using namespace mippo_bf16;
+
+constexpr int WS_MAXL = 8;
+
+// -DMIPPO_TRACE (tools/trace_ws.py): thread 0 of every workgroup stamps the shader clock at
+// the phase boundaries of its first two row tiles; compiled out of the product build.
+#ifdef MIPPO_TRACE
+constexpr int WST_EV = 32, WST_WG = 512;
+__device__ unsigned long long g_ws_trace[WST_WG * WST_EV];
+#define WS_TR()                                                                        \
+  do {                                                                                 \
+    if (tid == 0 && ev_ < WST_EV && blockIdx.x < WST_WG)                               \
+      g_ws_trace[blockIdx.x * WST_EV + ev_] = __builtin_amdgcn_s_memtime();            \
+    ++ev_;                                                                             \
+  } while (0)
+#else
+#define WS_TR() do {} while (0)
+#endif
+
+struct WsLayer {
+  const bf16_t* w;    // forward fragment-major image (gemm_bf16.hip: frag_store)
+  const float* bias;  // [N] or null
+  bf16_t* out_bf;     // [M][ldo] bf16 image of this layer's output, or null
+  int64_t ldo;
+};
+
+struct WsChain {
+  WsLayer layer[WS_MAXL];  // layer 0: K0 -> H; 1..NH: H -> H; NH+1: H -> N_out
+  const float* x;          // [M][K0] fp32
+  bf16_t* x_bf;            // [M][ldx] bf16 image of the input, or null
+  int64_t ldx;
+  float* out;              // [M][N_out] fp32
+  int64_t M;
+  int K0, N_out;
+};
+
+// block (ct, ks) of a fragment-major image with KS k-steps per column tile: the 16 bytes of
+// this lane
+__device__ inline bf16x8 ws_frag(const bf16_t* w, unsigned ct, unsigned ks, unsigned KS, int lane) {
+  const char* p = reinterpret_cast<const char*>(w) + (((size_t)ct * KS + ks) << 10) + lane * 16;
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+
+// H: hidden width; NH: number of H x H layers; RT: 16-row tiles per row tile.
+//
+// 512 threads = 8 waves, two per SIMD (<= 256 registers each): while one wave of a SIMD
+// is in an epilogue, a copy-out or the input stage, its partner multiplies.  The waves
+// split a layer's output tile CW column groups x RW row groups (CW * RW = 8): 256 columns
+// -> 8 x 1 with two 16-column tiles per wave, 128 -> 8 x 1, 64 -> 4 x 2.
+template <int H>
+struct WsGeom {
+  static constexpr int CW = H / 16 < 8 ? H / 16 : 8;  // column groups
+  static constexpr int RW = 8 / CW;                   // row groups
+  static constexpr int TPW = (H / 16) / CW;           // column tiles per wave
+};
+constexpr int kWsThreads = 512;
+
+template <int H, int NH, int RT>
+__global__ void __launch_bounds__(kWsThreads, 2)
+trunk_ws_fwd_kernel(WsChain c) {
+  static_assert(H == 64 || H == 128 || H == 256, "hidden width: 64, 128 or 256");
+  using G = WsGeom<H>;
+  constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
+  static_assert(RT % RW == 0 && RT <= 8, "row tiles must split over the row groups");
+  constexpr int RTW = RT / RW;  // row tiles per wave
+  constexpr int ROWS = 16 * RT;
+  constexpr int KSH = H / 32;   // k-steps of an H-deep reduce
+  constexpr int AROW = H + 8;   // LDS row (bf16): 16 bytes of padding
+  constexpr int XROW = 32 + 8;  // input tile row: K0 <= 32 columns
+  __shared__ __attribute__((aligned(16))) bf16_t bufX[ROWS * XROW];
+  __shared__ __attribute__((aligned(16))) bf16_t bufA[ROWS * AROW];
+  __shared__ __attribute__((aligned(16))) bf16_t bufB[ROWS * AROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % CW, wr = wave / CW;
+  const int li = lane & 15, lq = lane >> 4;
+  const int64_t M = c.M;
+  const int K0 = c.K0, N_out = c.N_out;
+  const int64_t ntiles = (M + ROWS - 1) / ROWS;
+#ifdef MIPPO_TRACE
+  int ev_ = 0;
+#endif
+  WS_TR();  // 0: start
+
+  // ---- input tile: fp32 [ROWS][K0] is one contiguous run; element e of it = (row e / K0,
+  // column e % K0) -------------------------------------------------------------------------
+  constexpr int IN_PT = (ROWS * 32 + kWsThreads - 1) / kWsThreads;  // K0 <= 32
+  const int nel = ROWS * K0;
+  const float rcpK0 = 1.0f / (float)K0;
+  float xin[IN_PT];
+  auto request_input = [&](int64_t tile) {
+    const int64_t i0 = tile * ROWS;
+#pragma unroll
+    for (int u = 0; u < IN_PT; ++u) {
+      const int e = tid + u * kWsThreads;
+      const int64_t g = i0 * K0 + e;
+      xin[u] = (e < nel && g < M * K0) ? c.x[g] : 0.0f;
+    }
+  };
+  int64_t tile = blockIdx.x;
+  // the first input tile and layer 0's fragments go out FIRST: the (much larger) rest of the
+  // trunk arrives while the first row tile's input stage and layer 0 run
+  if (tile < ntiles) request_input(tile);
+
+  // ---- the trunk, once: weight fragments and biases of this wave's column tiles --------
+  bf16x8 W0[TPW];
+  bf16x8 WH[NH > 0 ? NH : 1][TPW][KSH];
+  bf16x8 WO[KSH];
+  f32x4 B0[TPW], BH[NH > 0 ? NH : 1][TPW], BO;
+#pragma unroll
+  for (int b = 0; b < TPW; ++b) {
+    const unsigned ct = (unsigned)(wc + CW * b);
+    W0[b] = ws_frag(c.layer[0].w, ct, 0, 1, lane);
+    B0[b] = c.layer[0].bias
+                ? *reinterpret_cast<const f32x4*>(c.layer[0].bias + ct * 16 + 4 * lq)
+                : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int b = 0; b < TPW; ++b) {
+    const unsigned ct = (unsigned)(wc + CW * b);
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) WH[l][b][ks] = ws_frag(c.layer[1 + l].w, ct, ks, KSH, lane);
+      BH[l][b] = c.layer[1 + l].bias
+                     ? *reinterpret_cast<const f32x4*>(c.layer[1 + l].bias + ct * 16 + 4 * lq)
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSH; ++ks) WO[ks] = ws_frag(c.layer[NH + 1].w, 0, ks, KSH, lane);
+  BO = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c.layer[NH + 1].bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * lq + e < N_out) BO[e] = c.layer[NH + 1].bias[4 * lq + e];
+  }
+  // the input buffer's pad columns K0..31 are zero for the whole kernel (nothing else is
+  // ever written there)
+  for (int row = tid >> 5; row < ROWS; row += kWsThreads >> 5)
+    for (int k = K0 + (tid & 31); k < 32; k += 32) bufX[row * XROW + k] = (bf16_t)0.0f;
+  WS_TR();  // 1: trunk and first input requested
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t i0 = tile * ROWS;
+    WS_TR();  // tile + 0
+    // stage 0: the requested input tile -> bf16 in bufX
+#pragma unroll
+    for (int u = 0; u < IN_PT; ++u) {
+      const int e = tid + u * kWsThreads;
+      if (e < nel) {
+        const int row = (int)(((float)e + 0.5f) * rcpK0);
+        bufX[row * XROW + (e - row * K0)] = (bf16_t)xin[u];
+      }
+    }
+    // the next row tile's input is in flight while this one is computed
+    if (tile + gridDim.x < ntiles) request_input(tile + gridDim.x);
+    WS_TR();  // tile + 1: input staged
+    __syncthreads();
+    WS_TR();  // tile + 2
+    if (c.x_bf && tid < ROWS && i0 + tid < M) {  // bf16 image of the input (dW operand)
+      const int64_t ldx = c.ldx;                 // pad8(K0) <= 32 columns: 16-byte chunks
+      for (int k = 0; k < (int)ldx; k += 8)
+        *reinterpret_cast<u32x4*>(c.x_bf + (i0 + tid) * ldx + k) =
+            *reinterpret_cast<const u32x4*>(bufX + tid * XROW + k);
+    }
+
+    f32x4 acc[RTW][TPW];
+    // ---- layer 0: K0 (<= 32, one k-step) -> H ------------------------------------------
+    {
+      bf16x8 af[RTW];
+#pragma unroll
+      for (int r = 0; r < RTW; ++r)
+        af[r] = *reinterpret_cast<const bf16x8*>(bufX + ((wr * RTW + r) * 16 + li) * XROW + 8 * lq);
+#pragma unroll
+      for (int b = 0; b < TPW; ++b)
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+          acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              W0[b], af[r], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    WS_TR();  // tile + 3: layer 0 multiplied
+    // bias + relu + round to bf16 -> the next layer's LDS operand
+    auto epilogue_hidden = [&](const f32x4(&bias)[TPW], bf16_t* nbuf) {
+#pragma unroll
+      for (int b = 0; b < TPW; ++b) {
+        const int col = (wc + CW * b) * 16 + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r) {
+          bf16x4 vo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)fmaxf(acc[r][b][e] + bias[b][e], 0.0f);
+          *reinterpret_cast<bf16x4*>(nbuf + ((wr * RTW + r) * 16 + li) * AROW + col) = vo;
+        }
+      }
+    };
+    // The layer's bf16 image, out of the published LDS buffer in whole rows: 16 bytes per
+    // lane, a wave-instruction covers 1 KiB of consecutive addresses.  All the LDS reads of
+    // a thread first, then its stores; the stores drain while the next layer multiplies.
+    auto copy_out = [&](const bf16_t* buf, const WsLayer& ly) {
+      if (!ly.out_bf) return;
+      constexpr int CPR = H / 8;               // 16-byte chunks per row
+      constexpr int RPP = kWsThreads / CPR;    // rows per pass
+      constexpr int NP = (ROWS + RPP - 1) / RPP;
+      const int cc = tid % CPR, r0 = tid / CPR;
+      u32x4 v[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int row = r0 + p * RPP < ROWS ? r0 + p * RPP : ROWS - 1;
+        v[p] = *reinterpret_cast<const u32x4*>(buf + row * AROW + cc * 8);
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int row = r0 + p * RPP;
+        if (row < ROWS && i0 + row < M)
+          *reinterpret_cast<u32x4*>(ly.out_bf + (i0 + row) * ly.ldo + cc * 8) = v[p];
+      }
+    };
+    epilogue_hidden(B0, bufB);
+    WS_TR();  // tile + 4: layer 0 epilogue
+    __syncthreads();
+    WS_TR();  // tile + 5
+    copy_out(bufB, c.layer[0]);
+    WS_TR();  // tile + 6: copy-out issued
+    // ---- hidden layers: H -> H, activations ping-pong bufB -> bufA -> ... ---------------
+    bf16_t* cur = bufB;
+    bf16_t* nxt = bufA;
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+#pragma unroll
+      for (int r = 0; r < RTW; ++r)
+#pragma unroll
+        for (int b = 0; b < TPW; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) {
+        bf16x8 af[RTW];
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+          af[r] = *reinterpret_cast<const bf16x8*>(cur + ((wr * RTW + r) * 16 + li) * AROW +
+                                                   ks * 32 + 8 * lq);
+#pragma unroll
+        for (int b = 0; b < TPW; ++b)
+#pragma unroll
+          for (int r = 0; r < RTW; ++r)
+            acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[l][b][ks], af[r], acc[r][b],
+                                                                0, 0, 0);
+      }
+      WS_TR();  // hidden: multiplied
+      epilogue_hidden(BH[l], nxt);
+      WS_TR();  // hidden: epilogue
+      __syncthreads();
+      WS_TR();
+      copy_out(nxt, c.layer[1 + l]);
+      WS_TR();  // hidden: copy-out issued
+      bf16_t* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+    // ---- head: H -> N_out (<= 16: one column tile); wave w takes row tile w -------------
+    if (wave < RT) {
+      f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + (wave * 16 + li) * AROW +
+                                                          ks * 32 + 8 * lq);
+        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WO[ks], a, ah, 0, 0, 0);
+      }
+      const int64_t gi = i0 + wave * 16 + li;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gi < M && 4 * lq + e < N_out) c.out[gi * N_out + 4 * lq + e] = ah[e] + BO[e];
+    }
+    WS_TR();  // head done
+    __syncthreads();  // bufA / bufB / bufX are free for the next row tile
+    WS_TR();  // tile end
+  }
+}
+
+int ws_grid(int64_t ntiles) {
+  static const int cus = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cu < 1) {
+      (void)hipGetLastError();
+      cu = mippo::kNumCU;
+    }
+    return cu;
+  }();
+  return (int)(ntiles < cus ? ntiles : cus);
+}
+
+template <int H, int NH, int RT>
+int ws_launch(const WsChain& c, hipStream_t st) {
+  const int64_t ntiles = mippo::ceil_div(c.M, 16 * RT);
+  hipLaunchKernelGGL((trunk_ws_fwd_kernel<H, NH, RT>), dim3((unsigned)ws_grid(ntiles)),
+                     dim3(kWsThreads), 0, st, c);
+  return mippo::check_launch("mi_mlp_ws_fwd_bf16");
+}
+
+}  // namespace
+
+#ifdef MIPPO_TRACE
+extern "C" int mi_debug_ws_trace(unsigned long long* host_out, int64_t n) {
+  int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_trace), (size_t)n * 8);
+  void* p = nullptr;
+  if (rc == 0 && hipGetSymbolAddress(&p, HIP_SYMBOL(g_ws_trace)) == hipSuccess)
+    rc = (int)hipMemset(p, 0, sizeof(g_ws_trace));
+  return rc;
+}
+#endif
+
+// 1 if (dims, acts) is a trunk the weights-stationary kernels take.
+extern "C" int mi_mlp_ws_supported(int64_t L, const int64_t* dims, const int64_t* acts) {
+  if (!dims || !acts || L < 2 || L > WS_MAXL) return 0;
+  const int64_t H = dims[1];
+  if (dims[0] < 1 || dims[0] > 32 || dims[L] < 1 || dims[L] > 16) return 0;
+  for (int64_t l = 1; l < L; ++l)
+    if (dims[l] != H) return 0;
+  for (int64_t l = 0; l + 1 < L; ++l)
+    if (acts[l] != MI_ACT_RELU) return 0;
+  if (acts[L - 1] != MI_ACT_NONE) return 0;
+  const int64_t NH = L - 2;
+  return (H == 256 && NH <= 1) || (H == 128 && NH <= 2) || (H == 64 && NH <= 3);
+}
+
+extern "C" int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
+                                  const float* const* bias, const int64_t* dims,
+                                  const int64_t* acts, float* out, void* const* y_bf,
+                                  void* x_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_mlp_ws_fwd_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(x && wt_bf && dims && acts && out, "mi_mlp_ws_fwd_bf16: null pointer");
+  MI_REQUIRE(mi_mlp_ws_supported(L, dims, acts),
+             "mi_mlp_ws_fwd_bf16: trunk outside the weights-stationary shape class");
+  WsChain c = {};
+  c.x = x;
+  c.x_bf = static_cast<bf16_t*>(x_bf);
+  c.ldx = mippo::ceil_div(dims[0], 8) * 8;
+  c.out = out;
+  c.M = M;
+  c.K0 = (int)dims[0];
+  c.N_out = (int)dims[L];
+  for (int64_t l = 0; l < L; ++l) {
+    MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "mi_mlp_ws_fwd_bf16: weights must be 16-byte aligned");
+    c.layer[l].w = static_cast<const bf16_t*>(wt_bf[l]);
+    c.layer[l].bias = bias ? bias[l] : nullptr;
+    MI_REQUIRE(!c.layer[l].bias || (reinterpret_cast<uintptr_t>(c.layer[l].bias) & 15) == 0 ||
+                   l == L - 1,
+               "mi_mlp_ws_fwd_bf16: hidden biases must be 16-byte aligned");
+    c.layer[l].out_bf = (y_bf && l + 1 < L) ? static_cast<bf16_t*>(y_bf[l]) : nullptr;
+    c.layer[l].ldo = mippo::ceil_div(dims[l + 1], 8) * 8;
+    MI_REQUIRE(al16(c.layer[l].out_bf), "mi_mlp_ws_fwd_bf16: outputs must be 16-byte aligned");
+  }
+  hipStream_t st = mippo::as_stream(stream);
+  const int64_t H = dims[1], NH = L - 2;
+  // RT = 4 (64-row tiles) once every CU has at least one of them, else 32-row tiles
+  // (MIPPO_WS_RT=2|4 overrides: tuning aid)
+  static const int rt_override = [] {
+    const char* e = getenv("MIPPO_WS_RT");
+    return e ? atoi(e) : 0;
+  }();
+  const bool big = rt_override ? rt_override == 4 : M >= 64 * (int64_t)ws_grid(1 << 30);
+#define WS_CASE(h, nh)                                                        \
+  if (H == h && NH == nh)                                                     \
+    return big ? ws_launch<h, nh, 4>(c, st) : ws_launch<h, nh, 2>(c, st);
+  WS_CASE(256, 0)
+  WS_CASE(256, 1)
+  WS_CASE(128, 0)
+  WS_CASE(128, 1)
+  WS_CASE(128, 2)
+  WS_CASE(64, 0)
+  WS_CASE(64, 1)
+  WS_CASE(64, 2)
+  WS_CASE(64, 3)
+#undef WS_CASE
+  MI_REQUIRE(false, "mi_mlp_ws_fwd_bf16: no instantiation");
+}

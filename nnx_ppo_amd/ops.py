@@ -432,6 +432,45 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
     return out, saved
 
 
+def mlp_ws_supported(dims: list, acts: list) -> bool:
+    L = len(acts)
+    return bool(lib().mi_mlp_ws_supported(L, (ctypes.c_int64 * (L + 1))(*[int(d) for d in dims]),
+                                          (ctypes.c_int64 * L)(*[int(a) for a in acts])))
+
+
+def mlp_ws_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
+                    train: bool):
+    """`mlp_fwd_bf16` on the weights-stationary kernel (csrc/trunk_ws.hip): same operands,
+    same results bit for bit; for trunks `mlp_ws_supported` accepts."""
+    M, K0 = x.shape
+    L = len(wts)
+    _need(len(dims) == L + 1 and dims[0] == K0 and len(acts) == L, "mlp_ws_fwd_bf16: dims/acts")
+    dev = x.device
+    out = torch.empty(M, dims[-1], dtype=f32, device=dev)
+    P = ctypes.c_void_p * L
+    I = ctypes.c_int64 * (L + 1)
+    y_bf = [None] * L
+    x_bf = None
+    if train:
+        x_bf = _bf_buf(M, K0, dev)
+        for l in range(L - 1):
+            y_bf[l] = _bf_buf(M, dims[l + 1], dev)
+    arr = lambda ts: P(*[ptr(t) for t in ts])
+    if profiler.active:
+        profiler.next_flops = 2.0 * M * sum(dims[l] * dims[l + 1] for l in range(L))
+        w_bytes = sum(2 * dims[l] * dims[l + 1] + 4 * dims[l + 1] for l in range(L))
+        kept = sum(t.numel() * 2 for t in [x_bf, *y_bf] if t is not None)
+        profiler.next_bytes = 4.0 * M * K0 + w_bytes + 4.0 * M * dims[-1] + kept
+    check(lib().mi_mlp_ws_fwd_bf16(
+        ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
+        (ctypes.c_int64 * L)(*[int(a) for a in acts]), ptr(out, f32),
+        arr(y_bf) if train else None, ptr(x_bf), stream()), "mi_mlp_ws_fwd_bf16")
+    if not train:
+        return out, None
+    saved = [((x_bf if l == 0 else y_bf[l - 1]), y_bf[l]) for l in range(L)]
+    return out, saved
+
+
 def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_add: int, *,
                     min_std: float, std_scale: float, entropy_weight: float,
                     deterministic: bool, extras=None, eps=None, eps2=None, train: bool = False,
