@@ -534,6 +534,24 @@ int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* 
                        const float* const* bias, const int64_t* dims, const int64_t* acts,
                        float* out, void* const* y_bf, void* x_bf, mi_stream_t stream);
 
+/* mi_policy_fwd_bf16 for training sizes on the weights-stationary kernels (two launches:
+ * action trunk + sampler, value trunk + bootstrap tail rows): same arguments (mean_and_std
+ * is required; the pre-activation arrays are unused: relu trunks), same results bit for bit.
+ * mi_policy_ws_supported: both trunks in the shape class of mi_mlp_ws_supported, 2A <= 16. */
+int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
+                           const int64_t* c_dims, const int64_t* c_acts);
+int mi_policy_ws_fwd_bf16(
+    const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
+    const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,
+    const float* const* a_bias, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
+    const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const float* extras, const uint64_t* rng_state, uint64_t offset_add,
+    const float* eps, const float* eps2, float min_std, float std_scale, float entropy_weight,
+    int deterministic, float* mean_and_std, float* raw_out, float* action, float* loglik,
+    float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
+    void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
+    void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream);
+
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
  * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,
  * done = step' >= max_steps, obs = unit-variance noise from fold(key, step') written to

@@ -43,7 +43,12 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 __device__ inline float box_muller(uint32_t a, uint32_t b) {
   const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
   const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+  // cos(2 pi u2) as cospi(2 u2): 2 u2 is exact (u2 is a 24-bit fraction) and cospif reduces
+  // its argument exactly, so the result is within an ulp of the real-valued expression the
+  // oracle evaluates in fp64 — and, unlike cosf, needs no Payne-Hanek fallback: cosf put
+  // 552 bytes of scratch per lane into every kernel that samples, which throttled the
+  // waves per CU of the sampling kernels (rocprofv3: 30 us for a 9 us trunk).
+  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
 }
 
 __device__ inline void philox_normal_pair(uint64_t seed, uint64_t offset, uint64_t elem,

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "sampler_math.h"
 
 namespace {
 
@@ -61,12 +62,21 @@ struct WsLayer {
 
 struct WsChain {
   WsLayer layer[WS_MAXL];  // layer 0: K0 -> H; 1..NH: H -> H; NH+1: H -> N_out
-  const float* x;          // [M][K0] fp32
-  bf16_t* x_bf;            // [M][ldx] bf16 image of the input, or null
+  const float* x;          // [M_head][K0] fp32
+  const float* x_tail;     // rows M_head .. M-1 come from here ([M - M_head][K0]), or null
+  int64_t M_head;          // = M without a tail
+  bf16_t* x_bf;            // [M][ldx] bf16 image of the (normalised) input, or null
   int64_t ldx;
   float* out;              // [M][N_out] fp32
   int64_t M;
   int K0, N_out;
+  // policy step (mi_policy_ws_fwd_bf16): the running-statistics normaliser in the input
+  // stage (normalizer.py:76-96) and, for the action trunk, the sampler on the head's rows
+  const float* norm_mean;  // [K0] or null
+  const float* norm_m2;
+  const float* norm_count;
+  float norm_eps;
+  mippo_sampler::FwdParams samp;  // samp.A == 0: no sampler
 };
 
 // block (ct, ks) of a fragment-major image with KS k-steps per column tile: the 16 bytes of
@@ -90,7 +100,9 @@ struct WsGeom {
 };
 constexpr int kWsThreads = 512;
 
-template <int H, int NH, int RT>
+// SAMP: the trunk ends in the sampler (its own instantiations: the transcendental row
+// function does not belong in the register budget of the plain trunks).
+template <int H, int NH, int RT, bool SAMP>
 __global__ void __launch_bounds__(kWsThreads, 2)
 trunk_ws_fwd_kernel(WsChain c) {
   static_assert(H == 64 || H == 128 || H == 256, "hidden width: 64, 128 or 256");
@@ -124,15 +136,30 @@ trunk_ws_fwd_kernel(WsChain c) {
   const int nel = ROWS * K0;
   const float rcpK0 = 1.0f / (float)K0;
   float xin[IN_PT];
+  const int64_t M_head = c.M_head;
   auto request_input = [&](int64_t tile) {
     const int64_t i0 = tile * ROWS;
 #pragma unroll
     for (int u = 0; u < IN_PT; ++u) {
       const int e = tid + u * kWsThreads;
-      const int64_t g = i0 * K0 + e;
-      xin[u] = (e < nel && g < M * K0) ? c.x[g] : 0.0f;
+      const int row = (int)(((float)e + 0.5f) * rcpK0);
+      const int64_t gi = i0 + row;
+      xin[u] = 0.0f;
+      if (e < nel && gi < M) {
+        const int k = e - row * K0;
+        xin[u] = gi < M_head ? c.x[gi * K0 + k] : c.x_tail[(gi - M_head) * K0 + k];
+      }
     }
   };
+  // normaliser statistics of the K0 input columns, once (same fp32 expressions as
+  // normalize_fwd_kernel / the input stage of mlp_bf16.hip)
+  __shared__ float s_mean[32], s_sd[32];
+  const bool norm = c.norm_mean != nullptr;
+  if (norm && tid < K0) {
+    const float cnt = *c.norm_count;
+    s_mean[tid] = c.norm_mean[tid];
+    s_sd[tid] = cnt > 0.0f ? sqrtf(fmaxf(c.norm_m2[tid] / cnt, c.norm_eps)) : 10.0f;
+  }
   int64_t tile = blockIdx.x;
   // the first input tile and layer 0's fragments go out FIRST: the (much larger) rest of the
   // trunk arrives while the first row tile's input stage and layer 0 run
@@ -175,7 +202,29 @@ trunk_ws_fwd_kernel(WsChain c) {
   // ever written there)
   for (int row = tid >> 5; row < ROWS; row += kWsThreads >> 5)
     for (int k = K0 + (tid & 31); k < 32; k += 32) bufX[row * XROW + k] = (bf16_t)0.0f;
+  __syncthreads();  // s_mean / s_sd
   WS_TR();  // 1: trunk and first input requested
+
+  // sampling_layers.py:82-147 on the action trunk's rows.  One thread per row is a
+  // ~6 000-cycle chain of transcendentals whatever the number of rows, so the head's fp32
+  // rows of several row tiles are stashed in LDS and the sampler runs on all of them at
+  // once (up to 512 rows: every thread busy), not once per 64-row tile.
+  constexpr int kStashFloats = SAMP ? 4096 : 4;         // 16 KB
+  constexpr int kStashTilesMax = kWsThreads / ROWS;     // one row per thread at most
+  __shared__ float ms_s[kStashFloats];
+  constexpr bool has_samp = SAMP;
+  int64_t stash_first = 0;  // row tile of stash slot 0; slot q holds tile + q * gridDim.x
+  int stash_n = 0;
+  int stash_cap = has_samp ? kStashFloats / (ROWS * N_out) : 1;
+  if (stash_cap > kStashTilesMax) stash_cap = kStashTilesMax;
+  auto run_sampler = [&]() {
+    const int slot = tid / ROWS, row = tid % ROWS;
+    if (SAMP && slot < stash_n) {
+      const int64_t gi = (stash_first + (int64_t)slot * gridDim.x) * ROWS + row;
+      if (gi < M) mippo_sampler::fwd_row(ms_s + (slot * ROWS + row) * N_out, gi, c.samp);
+    }
+    __syncthreads();  // the stash is free again
+  };
 
   for (; tile < ntiles; tile += gridDim.x) {
     const int64_t i0 = tile * ROWS;
@@ -186,7 +235,10 @@ trunk_ws_fwd_kernel(WsChain c) {
       const int e = tid + u * kWsThreads;
       if (e < nel) {
         const int row = (int)(((float)e + 0.5f) * rcpK0);
-        bufX[row * XROW + (e - row * K0)] = (bf16_t)xin[u];
+        const int k = e - row * K0;
+        float v = xin[u];
+        if (norm && i0 + row < M) v = (v - s_mean[k]) / s_sd[k];
+        bufX[row * XROW + k] = (bf16_t)v;
       }
     }
     // the next row tile's input is in flight while this one is computed
@@ -301,10 +353,26 @@ trunk_ws_fwd_kernel(WsChain c) {
                                                           ks * 32 + 8 * lq);
         ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WO[ks], a, ah, 0, 0, 0);
       }
-      const int64_t gi = i0 + wave * 16 + li;
+      const int row = wave * 16 + li;
+      const int64_t gi = i0 + row;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (gi < M && 4 * lq + e < N_out) c.out[gi * N_out + 4 * lq + e] = ah[e] + BO[e];
+      for (int e = 0; e < 4; ++e) {
+        if (4 * lq + e < N_out) {
+          const float v = ah[e] + BO[e];
+          if (gi < M) c.out[gi * N_out + 4 * lq + e] = v;
+          // the sampler's input rows wait in LDS until the stash is full (below)
+          if (has_samp) ms_s[(stash_n * ROWS + row) * N_out + 4 * lq + e] = v;
+        }
+      }
+    }
+    if (has_samp) {
+      if (stash_n == 0) stash_first = tile;
+      ++stash_n;
+      if (stash_n == stash_cap || tile + gridDim.x >= ntiles) {
+        __syncthreads();  // the head's rows are in the stash
+        run_sampler();
+        stash_n = 0;
+      }
     }
     WS_TR();  // head done
     __syncthreads();  // bufA / bufB / bufX are free for the next row tile
@@ -329,8 +397,14 @@ int ws_grid(int64_t ntiles) {
 template <int H, int NH, int RT>
 int ws_launch(const WsChain& c, hipStream_t st) {
   const int64_t ntiles = mippo::ceil_div(c.M, 16 * RT);
-  hipLaunchKernelGGL((trunk_ws_fwd_kernel<H, NH, RT>), dim3((unsigned)ws_grid(ntiles)),
-                     dim3(kWsThreads), 0, st, c);
+  const dim3 grid((unsigned)ws_grid(ntiles));
+  if (c.samp.A > 0) {
+    MI_REQUIRE(16 * RT * c.N_out <= 4096, "weights-stationary trunk: 2A = %d is too wide for "
+               "the sampler stash", c.N_out);
+    hipLaunchKernelGGL((trunk_ws_fwd_kernel<H, NH, RT, true>), grid, dim3(kWsThreads), 0, st, c);
+  } else {
+    hipLaunchKernelGGL((trunk_ws_fwd_kernel<H, NH, RT, false>), grid, dim3(kWsThreads), 0, st, c);
+  }
   return mippo::check_launch("mi_mlp_ws_fwd_bf16");
 }
 
@@ -360,17 +434,17 @@ extern "C" int mi_mlp_ws_supported(int64_t L, const int64_t* dims, const int64_t
   return (H == 256 && NH <= 1) || (H == 128 && NH <= 2) || (H == 64 && NH <= 3);
 }
 
-extern "C" int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
-                                  const float* const* bias, const int64_t* dims,
-                                  const int64_t* acts, float* out, void* const* y_bf,
-                                  void* x_bf, mi_stream_t stream) {
-  MI_REQUIRE(M >= 0, "mi_mlp_ws_fwd_bf16: bad M");
-  if (M == 0) return 0;
-  MI_REQUIRE(x && wt_bf && dims && acts && out, "mi_mlp_ws_fwd_bf16: null pointer");
+namespace {
+
+int ws_fill(WsChain& c, const char* who, const float* x, int64_t M, int64_t L,
+            const void* const* wt_bf, const float* const* bias, const int64_t* dims,
+            const int64_t* acts, float* out, void* const* y_bf, void* x_bf) {
+  MI_REQUIRE(x && wt_bf && dims && acts && out, "%s: null pointer", who);
   MI_REQUIRE(mi_mlp_ws_supported(L, dims, acts),
-             "mi_mlp_ws_fwd_bf16: trunk outside the weights-stationary shape class");
-  WsChain c = {};
+             "%s: trunk outside the weights-stationary shape class", who);
+  c = {};
   c.x = x;
+  c.M_head = M;
   c.x_bf = static_cast<bf16_t*>(x_bf);
   c.ldx = mippo::ceil_div(dims[0], 8) * 8;
   c.out = out;
@@ -378,25 +452,27 @@ extern "C" int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const vo
   c.K0 = (int)dims[0];
   c.N_out = (int)dims[L];
   for (int64_t l = 0; l < L; ++l) {
-    MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "mi_mlp_ws_fwd_bf16: weights must be 16-byte aligned");
+    MI_REQUIRE(wt_bf[l] && al16(wt_bf[l]), "%s: weights must be 16-byte aligned", who);
     c.layer[l].w = static_cast<const bf16_t*>(wt_bf[l]);
     c.layer[l].bias = bias ? bias[l] : nullptr;
     MI_REQUIRE(!c.layer[l].bias || (reinterpret_cast<uintptr_t>(c.layer[l].bias) & 15) == 0 ||
                    l == L - 1,
-               "mi_mlp_ws_fwd_bf16: hidden biases must be 16-byte aligned");
+               "%s: hidden biases must be 16-byte aligned", who);
     c.layer[l].out_bf = (y_bf && l + 1 < L) ? static_cast<bf16_t*>(y_bf[l]) : nullptr;
     c.layer[l].ldo = mippo::ceil_div(dims[l + 1], 8) * 8;
-    MI_REQUIRE(al16(c.layer[l].out_bf), "mi_mlp_ws_fwd_bf16: outputs must be 16-byte aligned");
+    MI_REQUIRE(al16(c.layer[l].out_bf), "%s: outputs must be 16-byte aligned", who);
   }
-  hipStream_t st = mippo::as_stream(stream);
-  const int64_t H = dims[1], NH = L - 2;
+  return 0;
+}
+
+int ws_dispatch(const WsChain& c, int64_t H, int64_t NH, hipStream_t st) {
   // RT = 4 (64-row tiles) once every CU has at least one of them, else 32-row tiles
   // (MIPPO_WS_RT=2|4 overrides: tuning aid)
   static const int rt_override = [] {
     const char* e = getenv("MIPPO_WS_RT");
     return e ? atoi(e) : 0;
   }();
-  const bool big = rt_override ? rt_override == 4 : M >= 64 * (int64_t)ws_grid(1 << 30);
+  const bool big = rt_override ? rt_override == 4 : c.M >= 64 * (int64_t)ws_grid(1 << 30);
 #define WS_CASE(h, nh)                                                        \
   if (H == h && NH == nh)                                                     \
     return big ? ws_launch<h, nh, 4>(c, st) : ws_launch<h, nh, 2>(c, st);
@@ -410,5 +486,81 @@ extern "C" int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const vo
   WS_CASE(64, 2)
   WS_CASE(64, 3)
 #undef WS_CASE
-  MI_REQUIRE(false, "mi_mlp_ws_fwd_bf16: no instantiation");
+  MI_REQUIRE(false, "weights-stationary trunk: no instantiation for H=%lld NH=%lld",
+             (long long)H, (long long)NH);
+}
+
+}  // namespace
+
+extern "C" int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
+                                  const float* const* bias, const int64_t* dims,
+                                  const int64_t* acts, float* out, void* const* y_bf,
+                                  void* x_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_mlp_ws_fwd_bf16: bad M");
+  if (M == 0) return 0;
+  WsChain c;
+  int rc = ws_fill(c, "mi_mlp_ws_fwd_bf16", x, M, L, wt_bf, bias, dims, acts, out, y_bf, x_bf);
+  if (rc) return rc;
+  return ws_dispatch(c, dims[1], L - 2, mippo::as_stream(stream));
+}
+
+// 1 if both trunks of a policy step are in the weights-stationary shape class (and the
+// sampler's rows fit the LDS stash: 2A <= 64).
+extern "C" int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts,
+                                      int64_t Lc, const int64_t* c_dims, const int64_t* c_acts) {
+  return mi_mlp_ws_supported(La, a_dims, a_acts) && mi_mlp_ws_supported(Lc, c_dims, c_acts) &&
+         a_dims[0] == c_dims[0] && a_dims[La] % 2 == 0;
+}
+
+// mi_policy_fwd_bf16 on the weights-stationary kernels: the action trunk (normaliser in the
+// input stage, sampler on its head rows) and the value trunk (normaliser, bootstrap tail
+// rows) as two launches of trunk_ws_fwd_kernel.  Same arguments, same results bit for bit.
+extern "C" int mi_policy_ws_fwd_bf16(
+    const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
+    const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,
+    const float* const* a_bias, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
+    const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const float* extras, const uint64_t* rng_state, uint64_t offset_add,
+    const float* eps, const float* eps2, float min_std, float std_scale, float entropy_weight,
+    int deterministic, float* mean_and_std, float* raw_out, float* action, float* loglik,
+    float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
+    void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
+    void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream) {
+  (void)a_pre_bf;
+  (void)c_pre_bf;  // relu trunks keep no pre-activations
+  MI_REQUIRE(M >= 0 && M_tail >= 0 && (M_tail == 0 || value_tail_obs),
+             "mi_policy_ws_fwd_bf16: bad M / tail");
+  if (M == 0) return 0;
+  MI_REQUIRE(obs && value && a_dims && c_dims && mean_and_std,
+             "mi_policy_ws_fwd_bf16: null pointer (mean_and_std is required here)");
+  MI_REQUIRE(mi_policy_ws_supported(La, a_dims, a_acts, Lc, c_dims, c_acts),
+             "mi_policy_ws_fwd_bf16: trunks outside the weights-stationary shape class");
+  MI_REQUIRE(!norm_mean || (norm_m2 && norm_count), "mi_policy_ws_fwd_bf16: incomplete normaliser");
+  MI_REQUIRE(rng_state || (eps && eps2),
+             "mi_policy_ws_fwd_bf16: need rng_state or both injected noises");
+  hipStream_t st = mippo::as_stream(stream);
+  WsChain a;
+  int rc = ws_fill(a, "mi_policy_ws_fwd_bf16(action)", obs, M, La, a_w, a_bias, a_dims, a_acts,
+                   mean_and_std, a_y_bf, a_x_bf);
+  if (rc) return rc;
+  const int64_t A2 = a_dims[La];
+  a.norm_mean = norm_mean;
+  a.norm_m2 = norm_m2;
+  a.norm_count = norm_count;
+  a.norm_eps = norm_eps;
+  a.samp = {extras, {rng_state, offset_add, eps, eps2}, raw_out, action, mu_out, sigma_out,
+            loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
+  rc = ws_dispatch(a, a_dims[1], La - 2, st);
+  if (rc) return rc;
+  WsChain v;
+  rc = ws_fill(v, "mi_policy_ws_fwd_bf16(value)", obs, M + M_tail, Lc, c_w, c_bias, c_dims,
+               c_acts, value, c_y_bf, c_x_bf);
+  if (rc) return rc;
+  v.x_tail = value_tail_obs;
+  v.M_head = M;
+  v.norm_mean = norm_mean;
+  v.norm_m2 = norm_m2;
+  v.norm_count = norm_count;
+  v.norm_eps = norm_eps;
+  return ws_dispatch(v, c_dims[1], Lc - 2, st);
 }

@@ -30,6 +30,11 @@ from .types import PPONetworkOutput, StatefulModuleOutput
 
 # MIPPO_FUSED_POLICY=0 sends everything through the generic containers (A/B timing)
 FUSED = os.environ.get("MIPPO_FUSED_POLICY", "1") != "0"
+# MIPPO_WS_POLICY=0 keeps the loss replay on the per-tile kernels of csrc/mlp_bf16.hip; by
+# default a training-size replay of trunks in their shape class runs on the
+# weights-stationary kernels (csrc/trunk_ws.hip) — same results bit for bit
+WS_POLICY = os.environ.get("MIPPO_WS_POLICY", "1") != "0"
+WS_MIN_ROWS = 8192
 
 
 class MLPActorCritic(Sequential):
@@ -91,10 +96,14 @@ class MLPActorCritic(Sequential):
         A = a_layers[-1].out_features // 2
         eps, eps2 = sampler._noise(M, A, x2.device)
         off = sampler._next_offset()
+        ca, cc = chain(a_layers), chain(c_layers)
+        rows = M + (0 if value_tail is None else value_tail.shape[0])
+        ws = (WS_POLICY and train and rows > WS_MIN_ROWS
+              and ops.policy_ws_supported(ca[2], ca[3], cc[2], cc[3]) and 2 * A <= 64)
         r = ops.policy_fwd_bf16(
-            x2, norm, chain(a_layers), chain(c_layers), sampler._state(x2.device), off,
+            x2, norm, ca, cc, sampler._state(x2.device), off,
             deterministic=sampler.deterministic, extras=extras2, eps=eps, eps2=eps2,
-            train=train, want_stats=not train, value_tail=value_tail, **sampler._kw())
+            train=train, want_stats=not train, value_tail=value_tail, ws=ws, **sampler._kw())
         return r, off, eps2
 
     # ---- rollout / inference (adapter.py:75-117 over the whole stack) -----------------

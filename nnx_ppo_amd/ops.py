@@ -471,17 +471,26 @@ def mlp_ws_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: 
     return out, saved
 
 
+def policy_ws_supported(a_dims: list, a_acts: list, c_dims: list, c_acts: list) -> bool:
+    """Both trunks in the shape class of the weights-stationary kernels (csrc/trunk_ws.hip)."""
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    return bool(lib().mi_policy_ws_supported(len(a_acts), i64s(a_dims), i64s(a_acts),
+                                             len(c_acts), i64s(c_dims), i64s(c_acts)))
+
+
 def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_add: int, *,
                     min_std: float, std_scale: float, entropy_weight: float,
                     deterministic: bool, extras=None, eps=None, eps2=None, train: bool = False,
-                    want_stats: bool = True, value_tail=None):
+                    want_stats: bool = True, value_tail=None, ws: bool = False):
     """Normaliser -> action trunk -> sampler and value trunk in ONE launch
     (`mi_policy_fwd_bf16`).  `norm` = (mean, m2, counter, eps) | None; `actor` / `critic`
     = (frag images, biases, dims, acts).  Returns a dict: raw, action, log_likelihood,
     reg, mu, sigma, value and — training — mean_and_std, actor_saved, critic_saved
     (per-layer (x_bf, aux_bf) as `mlp_fwd_bf16`).  `value_tail` [Mt, K0]: extra rows for
     the value trunk only (the bootstrap observation); `value` and the critic images then
-    have M + Mt rows and `value_tail_out` is the view of the last Mt."""
+    have M + Mt rows and `value_tail_out` is the view of the last Mt.  `ws`: the
+    weights-stationary kernels (`mi_policy_ws_fwd_bf16`; training sizes, trunks that
+    `policy_ws_supported` accepts) — same results bit for bit."""
     M, K0 = obs.shape
     dev = obs.device
     (a_w, a_b, a_dims, a_acts), (c_w, c_b, c_dims, c_acts) = actor, critic
@@ -532,7 +541,11 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
         outs = sum(t.numel() * 4 for t in [raw, action, ll, reg, mu, sigma, value, ms, extras]
                    if t is not None)
         profiler.next_bytes = 4.0 * M * K0 + w_bytes + kept + outs
-    check(lib().mi_policy_fwd_bf16(
+    if ws:
+        _need(train and ms is not None, "policy_fwd_bf16: the weights-stationary form is for "
+              "training launches")
+    entry = lib().mi_policy_ws_fwd_bf16 if ws else lib().mi_policy_fwd_bf16
+    check(entry(
         ptr(obs, f32), M, ptr(n_mean, f32), ptr(n_m2, f32), ptr(n_cnt, f32), float(n_eps),
         La, arr(a_w, La), arr(a_b, La), i64s(a_dims), i64s(a_acts),
         Lc, arr(c_w, Lc), arr(c_b, Lc), i64s(c_dims), i64s(c_acts),
@@ -541,7 +554,8 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
         ptr(ms, f32), ptr(raw, f32), ptr(action, f32), ptr(ll, f32), ptr(reg, f32),
         ptr(mu, f32), ptr(sigma, f32), ptr(value, f32),
         arr(a_y, La), arr(a_pre, La), ptr(a_x), arr(c_y, Lc), arr(c_pre, Lc), ptr(c_x),
-        ptr(value_tail, f32), Mt, stream()), "mi_policy_fwd_bf16")
+        ptr(value_tail, f32), Mt, stream()),
+        "mi_policy_ws_fwd_bf16" if ws else "mi_policy_fwd_bf16")
     out = dict(raw=extras if replay else raw, action=action, log_likelihood=ll, reg=reg, mu=mu,
                sigma=sigma, value=value[:M], value_tail_out=value[M:] if Mt else None,
                mean_and_std=ms)

@@ -67,3 +67,73 @@ def test_ws_shape_class(dev):
     assert not ops.mlp_ws_supported([40, 64, 1], [R, N])                   # K0 <= 32
     assert not ops.mlp_ws_supported([5, 64, 17], [R, N])                   # N_out <= 16
     assert not ops.mlp_ws_supported([5, 512, 1], [R, N])
+
+
+@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [128] * 2, [128] * 3),
+                                   (3, 2, [64], [64] * 2)])
+@pytest.mark.parametrize("M,Mt", [(30720, 1024), (9000, 0), (12345, 77)])
+def test_policy_ws_forward_bit_identical(dev, shape, M, Mt):
+    """mi_policy_ws_fwd_bf16 (normaliser -> action trunk -> sampler; value trunk with the
+    bootstrap tail rows) == mi_policy_fwd_bf16: log-likelihoods, regulariser rows, values,
+    the sampler's input rows and every kept bf16 image, bit for bit."""
+    from nnx_ppo_amd import ops
+
+    O, A, ah, ch = shape
+    a_dims, c_dims = [O] + ah + [2 * A], [O] + ch + [1]
+    a_w, a_b, a_acts = _trunk(dev, a_dims, seed=M)
+    c_w, c_b, c_acts = _trunk(dev, c_dims, seed=M + 1)
+    assert ops.policy_ws_supported(a_dims, a_acts, c_dims, c_acts)
+    rng = np.random.default_rng(M + Mt)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    obs = t(rng.normal(1.0, 2.0, size=(M, O)))
+    tail = t(rng.normal(1.0, 2.0, size=(Mt, O))) if Mt else None
+    extras = t(rng.normal(size=(M, A)))
+    norm = (t(rng.normal(1.0, 0.5, size=O)), t(rng.uniform(50, 500, size=O)),
+            torch.tensor(100.0, device=dev), 1e-6)
+    rng_state = ops.make_rng_state(1234, dev, 7)
+    kw = dict(min_std=0.1, std_scale=1.0, entropy_weight=1e-2, deterministic=False,
+              extras=extras, train=True, want_stats=False, value_tail=tail)
+    actor, critic = (a_w, a_b, a_dims, a_acts), (c_w, c_b, c_dims, c_acts)
+    r0 = ops.policy_fwd_bf16(obs, norm, actor, critic, rng_state, 3, ws=False, **kw)
+    r1 = ops.policy_fwd_bf16(obs, norm, actor, critic, rng_state, 3, ws=True, **kw)
+    for k in ("log_likelihood", "reg", "value", "mean_and_std"):
+        assert torch.equal(r0[k], r1[k]), (k, float((r0[k] - r1[k]).abs().max()))
+    if Mt:
+        assert torch.equal(r0["value_tail_out"], r1["value_tail_out"])
+    for name in ("actor_saved", "critic_saved"):
+        for l, ((xa, ya), (xb, yb)) in enumerate(zip(r0[name], r1[name])):
+            assert torch.equal(xa, xb), (name, "x", l)
+            assert (ya is None) == (yb is None) and (ya is None or torch.equal(ya, yb)), (name, l)
+    # sampling (no stored actions): actions, raw draws and statistics too
+    kw2 = dict(kw, extras=None, want_stats=True)
+    s0 = ops.policy_fwd_bf16(obs, norm, actor, critic, rng_state, 5, ws=False, **kw2)
+    s1 = ops.policy_fwd_bf16(obs, norm, actor, critic, rng_state, 5, ws=True, **kw2)
+    for k in ("raw", "action", "log_likelihood", "reg", "mu", "sigma", "value"):
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_ppo_step_on_ws_kernels_equals_tile_kernels(dev):
+    """A whole iteration at a training size with the loss replay on the weights-stationary
+    kernels == the same iteration on the per-tile kernels."""
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.networks import factories, policy
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    outs = []
+    with config.use_compute_dtype("bf16"):
+        for ws in (True, False):
+            policy.WS_POLICY = ws
+            try:
+                env = EpisodeWrapper(cartpole_shaped(max_steps=9), 30)
+                net = factories.make_mlp_actor_critic(5, 1, [64] * 4, [256] * 2, Rngs(17))
+                ts = ppo.new_training_state(env, net, 2048, 17, 1e-3, device=dev)
+                for _ in range(2):  # M = 10 * 1024 + 1024 rows per gradient step
+                    ts, m = ppo.ppo_step(env, ts, 2048, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
+                outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()}))
+            finally:
+                policy.WS_POLICY = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
