@@ -552,6 +552,22 @@ int mi_policy_ws_fwd_bf16(
     void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
     void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream);
 
+/* Weights-stationary forms of mi_mlp_bwd_dx_bf16 (no input gradient, linear last layer)
+ * and mi_policy_bwd_bf16 for training sizes: same operands (w_bf: the BACKWARD
+ * fragment-major images; aux[l] = y_l, dz_bf[l] = dz_l for l < L - 1; dz_last = dz_{L-1}),
+ * same results bit for bit. */
+int mi_mlp_ws_bwd_dx_bf16(const float* g_out, int64_t M, int64_t L, const void* const* w_bf,
+                          const int64_t* dims, const int64_t* acts, const void* const* aux,
+                          void* dz_last, void* const* dz_bf, mi_stream_t stream);
+int mi_policy_ws_bwd_bf16(
+    const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, const float* g_loglik, float g_reg, float min_std,
+    float std_scale, float entropy_weight, const float* g_value, int64_t M, int64_t La,
+    const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
+    const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
+    const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf, mi_stream_t stream);
+
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
  * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,
  * done = step' >= max_steps, obs = unit-variance noise from fold(key, step') written to

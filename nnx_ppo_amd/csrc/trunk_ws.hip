@@ -380,6 +380,229 @@ trunk_ws_fwd_kernel(WsChain c) {
   }
 }
 
+// ---- backward (dX chain) ------------------------------------------------------------------
+// The same walk over the transposed problem (mlp_bf16.hip: chain_body<.., BWD>):
+//   dz_{L-1} = bf16(g_out)                                  (or the sampler backward's rows)
+//   dz_{l-1} = (dz_l . W_l^T) (.) relu'(y_{l-1}),  l = L-1 .. 1
+// every dz_l is written out (bf16) for the grouped dW launch; no input gradient (the trunk
+// reads observations).  Weights: the BACKWARD fragment-major images (columns = a layer's
+// inputs, reduce = its outputs), stationary in registers as in the forward.
+struct WsBwdLayer {
+  const bf16_t* w;      // backward image of layer l (emits K_l columns, reduces N_l)
+  const bf16_t* aux;    // y_{l-1} [M][ld]: relu' operand of the emitted gradient
+  bf16_t* out_bf;       // dz_{l-1} [M][ld]
+  int64_t ld;
+};
+struct WsBwdChain {
+  WsBwdLayer layer[WS_MAXL];  // [0] = head (reduce N_out), then the H x H layers, last first
+  const float* g_out;         // [M][N_out] fp32, or null with the sampler backward
+  bf16_t* dz_last;            // [M][ldx] bf16 image of the head's output gradient
+  int64_t ldx;
+  int64_t M;
+  int N_out;
+  mippo_sampler::BwdParams sbwd;  // sbwd.A == 0: gradient comes from g_out
+};
+
+template <int H, int NH, int RT, bool SAMP>
+__global__ void __launch_bounds__(kWsThreads, 2)
+trunk_ws_bwd_kernel(WsBwdChain c) {
+  using G = WsGeom<H>;
+  constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
+  constexpr int RTW = RT / RW;
+  constexpr int ROWS = 16 * RT;
+  constexpr int KSH = H / 32;
+  constexpr int AROW = H + 8;
+  constexpr int XROW = 32 + 8;
+  constexpr int kStashTiles = SAMP ? kWsThreads / ROWS : 1;  // one row per thread
+  __shared__ __attribute__((aligned(16))) bf16_t bufX[kStashTiles * ROWS * XROW];
+  __shared__ __attribute__((aligned(16))) bf16_t bufA[ROWS * AROW];
+  __shared__ __attribute__((aligned(16))) bf16_t bufB[ROWS * AROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % CW, wr = wave / CW;
+  const int li = lane & 15, lq = lane >> 4;
+  const int64_t M = c.M;
+  const int N_out = c.N_out;
+  const int64_t ntiles = (M + ROWS - 1) / ROWS;
+
+  // ---- the transposed trunk, once -------------------------------------------------------
+  bf16x8 WO[TPW];
+  bf16x8 WH[NH > 0 ? NH : 1][TPW][KSH];
+#pragma unroll
+  for (int b = 0; b < TPW; ++b) {
+    const unsigned ct = (unsigned)(wc + CW * b);
+    WO[b] = ws_frag(c.layer[0].w, ct, 0, 1, lane);
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) WH[l][b][ks] = ws_frag(c.layer[1 + l].w, ct, ks, KSH, lane);
+  }
+  // pad columns N_out..31 of the head-gradient rows stay zero for the whole kernel
+  for (int i = tid; i < kStashTiles * ROWS * 32; i += kWsThreads) {
+    const int row = i >> 5, k = i & 31;
+    if (k >= N_out) bufX[row * XROW + k] = (bf16_t)0.0f;
+  }
+
+  constexpr int IN_PT = (ROWS * 16 + kWsThreads - 1) / kWsThreads;  // N_out <= 16
+  const int nel = ROWS * N_out;
+  const float rcpN = 1.0f / (float)N_out;
+  float gin[IN_PT];
+  auto request_input = [&](int64_t tile) {
+    if (SAMP) return;
+    const int64_t g0 = tile * ROWS * N_out;
+#pragma unroll
+    for (int u = 0; u < IN_PT; ++u) {
+      const int e = tid + u * kWsThreads;
+      gin[u] = (e < nel && g0 + e < M * N_out) ? c.g_out[g0 + e] : 0.0f;
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  int stash_n = 0, stash_i = 0;  // SAMP: head-gradient rows of `stash_n` row tiles wait in bufX
+  if (tile < ntiles) request_input(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t i0 = tile * ROWS;
+    const bf16_t* xin = bufX;
+    if constexpr (SAMP) {
+      // sampling_layers.py:82-147 differentiated, one thread per row — a long chain of
+      // transcendentals whatever the number of rows, so the rows of up to kStashTiles of
+      // this workgroup's row tiles are produced at once
+      if (stash_i == stash_n) {
+        const int slot = tid / ROWS, row = tid % ROWS;
+        const int64_t t = tile + (int64_t)slot * gridDim.x;
+        if (t < ntiles) {
+          bf16_t* dst = bufX + (slot * ROWS + row) * XROW;
+          const int64_t gi = t * ROWS + row;
+          if (gi < M) {
+            mippo_sampler::bwd_row(gi, c.sbwd, [dst](int j, float v) { dst[j] = (bf16_t)v; });
+          } else {
+            for (int k = 0; k < N_out; ++k) dst[k] = (bf16_t)0.0f;
+          }
+        }
+        stash_n = 0;
+        for (int q = 0; q < kStashTiles; ++q)
+          if (tile + (int64_t)q * gridDim.x < ntiles) ++stash_n;
+        stash_i = 0;
+      }
+      xin = bufX + stash_i * ROWS * XROW;
+      ++stash_i;
+    } else {
+#pragma unroll
+      for (int u = 0; u < IN_PT; ++u) {
+        const int e = tid + u * kWsThreads;
+        if (e < nel) {
+          const int row = (int)(((float)e + 0.5f) * rcpN);
+          bufX[row * XROW + (e - row * N_out)] = (bf16_t)gin[u];
+        }
+      }
+      if (tile + gridDim.x < ntiles) request_input(tile + gridDim.x);
+    }
+    // relu' operands of this row tile: 8 bytes per (row, column tile), requested now
+    s16x4 auxr[NH + 1][RTW][TPW];
+#pragma unroll
+    for (int l = 0; l <= NH; ++l)
+#pragma unroll
+      for (int b = 0; b < TPW; ++b) {
+        const int col = (wc + CW * b) * 16 + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r) {
+          const int64_t gi = i0 + (wr * RTW + r) * 16 + li;
+          s16x4 a = s16x4{0, 0, 0, 0};
+          if (gi < M) a = *reinterpret_cast<const s16x4*>(c.layer[l].aux + gi * c.layer[l].ld + col);
+          auxr[l][r][b] = a;
+        }
+      }
+    __syncthreads();
+    if (c.dz_last && tid < ROWS && i0 + tid < M) {  // bf16 image of the head's gradient
+      const int64_t ldx = c.ldx;
+      for (int k = 0; k < (int)ldx; k += 8)
+        *reinterpret_cast<u32x4*>(c.dz_last + (i0 + tid) * ldx + k) =
+            *reinterpret_cast<const u32x4*>(xin + tid * XROW + k);
+    }
+    f32x4 acc[RTW][TPW];
+    auto epilogue = [&](const s16x4(&aux)[RTW][TPW], bf16_t* nbuf) {
+#pragma unroll
+      for (int b = 0; b < TPW; ++b) {
+        const int col = (wc + CW * b) * 16 + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r) {
+          const bf16x4 a4 = __builtin_bit_cast(bf16x4, aux[r][b]);
+          bf16x4 vo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            vo[e] = (bf16_t)(acc[r][b][e] * ((float)a4[e] > 0.0f ? 1.0f : 0.0f));
+          *reinterpret_cast<bf16x4*>(nbuf + ((wr * RTW + r) * 16 + li) * AROW + col) = vo;
+        }
+      }
+    };
+    auto copy_out = [&](const bf16_t* buf, bf16_t* dst, int64_t ld) {
+      constexpr int CPR = H / 8;
+      constexpr int RPP = kWsThreads / CPR;
+      constexpr int NP = (ROWS + RPP - 1) / RPP;
+      const int cc = tid % CPR, r0 = tid / CPR;
+      u32x4 v[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int row = r0 + p * RPP < ROWS ? r0 + p * RPP : ROWS - 1;
+        v[p] = *reinterpret_cast<const u32x4*>(buf + row * AROW + cc * 8);
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int row = r0 + p * RPP;
+        if (row < ROWS && i0 + row < M)
+          *reinterpret_cast<u32x4*>(dst + (i0 + row) * ld + cc * 8) = v[p];
+      }
+    };
+    // ---- head, transposed: reduce over N_out (one k-step), emit H columns ----------------
+    {
+      bf16x8 af[RTW];
+#pragma unroll
+      for (int r = 0; r < RTW; ++r)
+        af[r] = *reinterpret_cast<const bf16x8*>(xin + ((wr * RTW + r) * 16 + li) * XROW + 8 * lq);
+#pragma unroll
+      for (int b = 0; b < TPW; ++b)
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+          acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              WO[b], af[r], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    epilogue(auxr[0], bufA);
+    __syncthreads();
+    copy_out(bufA, c.layer[0].out_bf, c.layer[0].ld);
+    bf16_t* cur = bufA;
+    bf16_t* nxt = bufB;
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+#pragma unroll
+      for (int r = 0; r < RTW; ++r)
+#pragma unroll
+        for (int b = 0; b < TPW; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) {
+        bf16x8 af[RTW];
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+          af[r] = *reinterpret_cast<const bf16x8*>(cur + ((wr * RTW + r) * 16 + li) * AROW +
+                                                   ks * 32 + 8 * lq);
+#pragma unroll
+        for (int b = 0; b < TPW; ++b)
+#pragma unroll
+          for (int r = 0; r < RTW; ++r)
+            acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[l][b][ks], af[r], acc[r][b],
+                                                                0, 0, 0);
+      }
+      epilogue(auxr[1 + l], nxt);
+      __syncthreads();
+      copy_out(nxt, c.layer[1 + l].out_bf, c.layer[1 + l].ld);
+      bf16_t* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+    __syncthreads();  // the buffers are free for the next row tile
+  }
+}
+
 int ws_grid(int64_t ntiles) {
   static const int cus = [] {
     int dev = 0, cu = 0;
@@ -502,6 +725,123 @@ extern "C" int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const vo
   int rc = ws_fill(c, "mi_mlp_ws_fwd_bf16", x, M, L, wt_bf, bias, dims, acts, out, y_bf, x_bf);
   if (rc) return rc;
   return ws_dispatch(c, dims[1], L - 2, mippo::as_stream(stream));
+}
+
+namespace {
+
+template <int H, int NH, int RT>
+int ws_bwd_launch(const WsBwdChain& c, hipStream_t st) {
+  const int64_t ntiles = mippo::ceil_div(c.M, 16 * RT);
+  const dim3 grid((unsigned)ws_grid(ntiles));
+  if (c.sbwd.A > 0)
+    hipLaunchKernelGGL((trunk_ws_bwd_kernel<H, NH, RT, true>), grid, dim3(kWsThreads), 0, st, c);
+  else
+    hipLaunchKernelGGL((trunk_ws_bwd_kernel<H, NH, RT, false>), grid, dim3(kWsThreads), 0, st, c);
+  return mippo::check_launch("mi_mlp_ws_bwd_dx_bf16");
+}
+
+int ws_bwd_dispatch(const WsBwdChain& c, int64_t H, int64_t NH, hipStream_t st) {
+  static const int rt_override = [] {
+    const char* e = getenv("MIPPO_WS_RT");
+    return e ? atoi(e) : 0;
+  }();
+  const bool big = rt_override ? rt_override == 4 : c.M >= 64 * (int64_t)ws_grid(1 << 30);
+#define WS_CASE(h, nh)                                                        \
+  if (H == h && NH == nh)                                                     \
+    return big ? ws_bwd_launch<h, nh, 4>(c, st) : ws_bwd_launch<h, nh, 2>(c, st);
+  WS_CASE(256, 0)
+  WS_CASE(256, 1)
+  WS_CASE(128, 0)
+  WS_CASE(128, 1)
+  WS_CASE(128, 2)
+  WS_CASE(64, 0)
+  WS_CASE(64, 1)
+  WS_CASE(64, 2)
+  WS_CASE(64, 3)
+#undef WS_CASE
+  MI_REQUIRE(false, "weights-stationary trunk backward: no instantiation for H=%lld NH=%lld",
+             (long long)H, (long long)NH);
+}
+
+// Fills the transposed chain from the C-ABI arrays of mi_mlp_bwd_dx_bf16 (w_bf[l]: backward
+// image of layer l; aux[l] = y_l, dz_bf[l] = dz_l for l < L - 1; dz_last = dz_{L-1}).
+int ws_bwd_fill(WsBwdChain& c, const char* who, const float* g_out, int64_t M, int64_t L,
+                const void* const* w_bf, const int64_t* dims, const int64_t* acts,
+                const void* const* aux, void* dz_last, void* const* dz_bf) {
+  MI_REQUIRE(w_bf && dims && acts && aux && dz_last && dz_bf, "%s: null pointer", who);
+  MI_REQUIRE(mi_mlp_ws_supported(L, dims, acts),
+             "%s: trunk outside the weights-stationary shape class", who);
+  c = {};
+  c.g_out = g_out;
+  c.dz_last = static_cast<bf16_t*>(dz_last);
+  c.ldx = mippo::ceil_div(dims[L], 8) * 8;
+  c.M = M;
+  c.N_out = (int)dims[L];
+  MI_REQUIRE(al16(dz_last), "%s: buffers must be 16-byte aligned", who);
+  // chain position q handles layer l = L-1-q: emits dz_{l-1}, masks by relu'(y_{l-1})
+  for (int64_t q = 0; q + 1 < L; ++q) {
+    const int64_t l = L - 1 - q;
+    MI_REQUIRE(w_bf[l] && al16(w_bf[l]) && aux[l - 1] && dz_bf[l - 1] && al16(aux[l - 1]) &&
+                   al16(dz_bf[l - 1]),
+               "%s: layer %lld operands missing or misaligned", who, (long long)l);
+    c.layer[q].w = static_cast<const bf16_t*>(w_bf[l]);
+    c.layer[q].aux = static_cast<const bf16_t*>(aux[l - 1]);
+    c.layer[q].out_bf = static_cast<bf16_t*>(dz_bf[l - 1]);
+    c.layer[q].ld = mippo::ceil_div(dims[l], 8) * 8;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// Weights-stationary form of mi_mlp_bwd_dx_bf16 without an input gradient (act_last none):
+// same operands, same results bit for bit.
+extern "C" int mi_mlp_ws_bwd_dx_bf16(const float* g_out, int64_t M, int64_t L,
+                                     const void* const* w_bf, const int64_t* dims,
+                                     const int64_t* acts, const void* const* aux,
+                                     void* dz_last, void* const* dz_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_mlp_ws_bwd_dx_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(g_out, "mi_mlp_ws_bwd_dx_bf16: null pointer");
+  WsBwdChain c;
+  int rc = ws_bwd_fill(c, "mi_mlp_ws_bwd_dx_bf16", g_out, M, L, w_bf, dims, acts, aux, dz_last,
+                       dz_bf);
+  if (rc) return rc;
+  return ws_bwd_dispatch(c, dims[1], L - 2, mippo::as_stream(stream));
+}
+
+// mi_policy_bwd_bf16 on the weights-stationary kernels: the action trunk's transposed chain
+// fed by the sampler backward, and the value trunk's fed by g_value — two launches.
+extern "C" int mi_policy_ws_bwd_bf16(
+    const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, const float* g_loglik, float g_reg, float min_std,
+    float std_scale, float entropy_weight, const float* g_value, int64_t M, int64_t La,
+    const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
+    const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
+    const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf, mi_stream_t stream) {
+  MI_REQUIRE(M >= 0, "mi_policy_ws_bwd_bf16: bad M");
+  if (M == 0) return 0;
+  MI_REQUIRE(mean_and_std && extras && g_value && a_dims && c_dims && a_acts && c_acts,
+             "mi_policy_ws_bwd_bf16: null pointer");
+  MI_REQUIRE(rng_state || eps2, "mi_policy_ws_bwd_bf16: need rng_state or injected eps2");
+  MI_REQUIRE(mi_policy_ws_supported(La, a_dims, a_acts, Lc, c_dims, c_acts),
+             "mi_policy_ws_bwd_bf16: trunks outside the weights-stationary shape class");
+  hipStream_t st = mippo::as_stream(stream);
+  WsBwdChain a;
+  int rc = ws_bwd_fill(a, "mi_policy_ws_bwd_bf16(action)", nullptr, M, La, a_w, a_dims, a_acts,
+                       a_aux, a_dz_last, a_dz_bf);
+  if (rc) return rc;
+  const int64_t A2 = a_dims[La];
+  a.sbwd = {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
+            (int)(A2 / 2), min_std, std_scale, entropy_weight};
+  rc = ws_bwd_dispatch(a, a_dims[1], La - 2, st);
+  if (rc) return rc;
+  WsBwdChain v;
+  rc = ws_bwd_fill(v, "mi_policy_ws_bwd_bf16(value)", g_value, M, Lc, c_w, c_dims, c_acts, c_aux,
+                   c_dz_last, c_dz_bf);
+  if (rc) return rc;
+  return ws_bwd_dispatch(v, c_dims[1], Lc - 2, st);
 }
 
 // 1 if both trunks of a policy step are in the weights-stationary shape class (and the

@@ -213,9 +213,12 @@ class MLPActorCritic(Sequential):
         desc = lambda ls, c: ([l._fb for l in ls],
                               [ls[0].in_features] + [l.out_features for l in ls],
                               [l.act_code for l in ls], [sv[1] for sv in c[0]])
+        da, dc = desc(a_layers, a_ctx), desc(c_layers, v_ctx)
+        ws = (WS_POLICY and M > WS_MIN_ROWS and ms2.shape[1] <= 64
+              and ops.policy_ws_supported(da[1], da[2], dc[1], dc[2]))
         a_dz, c_dz = ops.policy_bwd_bf16(
-            ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, g_v,
-            desc(a_layers, a_ctx), desc(c_layers, v_ctx), eps2=eps2, **sampler._kw())
+            ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, g_v, da, dc, eps2=eps2,
+            ws=ws, **sampler._kw())
         # dW / db of every layer of both trunks: one grouped launch per tile class
         problems = []
         for ls, c, dz in ((c_layers, v_ctx, c_dz), (a_layers, a_ctx, a_dz)):

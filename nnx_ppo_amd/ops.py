@@ -573,10 +573,11 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
 
 def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float,
                     g_value, actor, critic, *, min_std: float, std_scale: float,
-                    entropy_weight: float, eps2=None):
+                    entropy_weight: float, eps2=None, ws: bool = False):
     """Sampler backward + both dX chains in ONE launch (`mi_policy_bwd_bf16`).
     `actor` / `critic` = (backward frag images, dims, acts, auxs per layer).  Returns
-    (actor dz list, critic dz list): bf16 [M, pad8(N_l)] per layer."""
+    (actor dz list, critic dz list): bf16 [M, pad8(N_l)] per layer.  `ws`: the
+    weights-stationary kernels (`mi_policy_ws_bwd_bf16`), same results bit for bit."""
     M, A2 = mean_and_std.shape
     dev = mean_and_std.device
     (a_w, a_dims, a_acts, a_aux), (c_w, c_dims, c_acts, c_aux) = actor, critic
@@ -598,15 +599,36 @@ def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_re
         w_bytes = sum(2 * a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
             + sum(2 * c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
         profiler.next_bytes = (4.0 * M * (A2 + A2 // 2 + 1 + c_dims[-1]) + w_bytes + moved)
-    check(lib().mi_policy_bwd_bf16(
+    entry = lib().mi_policy_ws_bwd_bf16 if ws else lib().mi_policy_bwd_bf16
+    check(entry(
         ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
         ptr(eps2, f32), ptr(g_ll, f32), float(g_reg), float(min_std), float(std_scale),
         float(entropy_weight), ptr(g_value, f32), M,
         La, arr(a_w, La), i64s(a_dims), i64s(a_acts), arr(a_aux[:La - 1], La - 1),
         ptr(a_dz[La - 1], bf16), arr(a_dz[:La - 1], La - 1),
         Lc, arr(c_w, Lc), i64s(c_dims), i64s(c_acts), arr(c_aux[:Lc - 1], Lc - 1),
-        ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1), stream()), "mi_policy_bwd_bf16")
+        ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1), stream()),
+        "mi_policy_ws_bwd_bf16" if ws else "mi_policy_bwd_bf16")
     return a_dz, c_dz
+
+
+def mlp_ws_bwd_dx_bf16(g_out: torch.Tensor, w_bfs: list, dims: list, acts: list, auxs: list):
+    """`mlp_bwd_dx_bf16(..., need_input_grad=False)` with a linear last layer on the
+    weights-stationary kernel.  Returns the dz list."""
+    M = g_out.shape[0]
+    L = len(w_bfs)
+    _need(L >= 2 and len(dims) == L + 1 and g_out.shape[1] == dims[-1], "mlp_ws_bwd_dx_bf16: dims")
+    dev = g_out.device
+    dz = [_bf_buf(M, dims[l + 1], dev) for l in range(L)]
+    P = ctypes.c_void_p * L
+    Pm = ctypes.c_void_p * (L - 1)
+    check(lib().mi_mlp_ws_bwd_dx_bf16(
+        ptr(g_out, f32), M, L, P(*[ptr(w, bf16) for w in w_bfs]),
+        (ctypes.c_int64 * (L + 1))(*[int(d) for d in dims]),
+        (ctypes.c_int64 * L)(*[int(a) for a in acts]), Pm(*[ptr(a) for a in auxs[:L - 1]]),
+        ptr(dz[L - 1], bf16), Pm(*[ptr(t, bf16) for t in dz[:L - 1]]), stream()),
+        "mi_mlp_ws_bwd_dx_bf16")
+    return dz
 
 
 def mlp_bwd_dx_bf16(g_out: torch.Tensor, aux_last, act_last: int, w_bfs: list, dims: list,

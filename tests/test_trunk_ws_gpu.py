@@ -137,3 +137,75 @@ def test_ppo_step_on_ws_kernels_equals_tile_kernels(dev):
                 policy.WS_POLICY = True
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
+
+
+def _bwd_images(dev, dims, seed):
+    """Backward fragment-major images of a random trunk (+ the forward ones, biases)."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(seed)
+    L = len(dims) - 1
+    ffs, fbs, bs = [], [], []
+    for l in range(L):
+        K, N = dims[l], dims[l + 1]
+        w = torch.tensor(rng.normal(size=(K, N)) / math.sqrt(K), dtype=torch.float32, device=dev)
+        w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
+        wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
+        nf, nb = ops.frag_sizes(K, N)
+        ff, fb = torch.zeros(nf, dtype=BF, device=dev), torch.zeros(nb, dtype=BF, device=dev)
+        ops.weights_to_bf16_multi([w], [w_bf], [wt_bf], [ff], [fb])
+        ffs.append(ff)
+        fbs.append(fb)
+        bs.append(torch.tensor(rng.normal(0, 0.3, size=N), dtype=torch.float32, device=dev))
+    acts = [ops.ACT_RELU] * (L - 1) + [ops.ACT_NONE]
+    return ffs, fbs, bs, acts
+
+
+@pytest.mark.parametrize("dims", [[5, 256, 256, 1], [5, 64, 64, 64, 64, 2], [17, 128, 128, 3],
+                                  [5, 64, 2], [9, 128, 128, 128, 12]])
+@pytest.mark.parametrize("M", [1, 63, 1000, 16384, 30720])
+def test_ws_backward_bit_identical_to_tile_kernels(dev, dims, M):
+    """mi_mlp_ws_bwd_dx_bf16 == mi_mlp_bwd_dx_bf16 (no input gradient): every dz image."""
+    from nnx_ppo_amd import ops
+
+    ffs, fbs, bs, acts = _bwd_images(dev, dims, seed=M + len(dims))
+    rng = np.random.default_rng(M)
+    x = torch.tensor(rng.normal(size=(M, dims[0])), dtype=torch.float32, device=dev)
+    _, saved = ops.mlp_fwd_bf16(x, ffs, bs, dims, acts, train=True)
+    auxs = [sv[1] for sv in saved]
+    g = torch.tensor(rng.normal(size=(M, dims[-1])), dtype=torch.float32, device=dev)
+    want, _ = ops.mlp_bwd_dx_bf16(g, None, ops.ACT_NONE, fbs, dims, acts, auxs, False)
+    got = ops.mlp_ws_bwd_dx_bf16(g, fbs, dims, acts, auxs)
+    for l, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a, b), (l, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [128] * 2, [128] * 3)])
+@pytest.mark.parametrize("M", [30720, 9000, 12345])
+def test_policy_ws_backward_bit_identical(dev, shape, M):
+    """mi_policy_ws_bwd_bf16 == mi_policy_bwd_bf16: the sampler backward's rows and every
+    dz of both trunks."""
+    from nnx_ppo_amd import ops
+
+    O, A, ah, ch = shape
+    a_dims, c_dims = [O] + ah + [2 * A], [O] + ch + [1]
+    a_ff, a_fb, a_b, a_acts = _bwd_images(dev, a_dims, seed=M)
+    c_ff, c_fb, c_b, c_acts = _bwd_images(dev, c_dims, seed=M + 1)
+    rng = np.random.default_rng(M)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    obs, extras = t(rng.normal(size=(M, O))), t(rng.normal(size=(M, A)))
+    rng_state = ops.make_rng_state(99, dev, 3)
+    kw = dict(min_std=0.1, std_scale=1.0, entropy_weight=1e-2)
+    r = ops.policy_fwd_bf16(obs, None, (a_ff, a_b, a_dims, a_acts), (c_ff, c_b, c_dims, c_acts),
+                            rng_state, 2, deterministic=False, extras=extras, train=True,
+                            want_stats=False, **kw)
+    g_ll, g_v = t(rng.normal(size=M) / M), t(rng.normal(size=(M, 1)) / M)
+    actor = (a_fb, a_dims, a_acts, [sv[1] for sv in r["actor_saved"]])
+    critic = (c_fb, c_dims, c_acts, [sv[1] for sv in r["critic_saved"]])
+    want = ops.policy_bwd_bf16(r["mean_and_std"], extras, rng_state, 2, g_ll, 1.0 / M, g_v,
+                               actor, critic, ws=False, **kw)
+    got = ops.policy_bwd_bf16(r["mean_and_std"], extras, rng_state, 2, g_ll, 1.0 / M, g_v,
+                              actor, critic, ws=True, **kw)
+    for name, wl, gl in (("actor", want[0], got[0]), ("critic", want[1], got[1])):
+        for l, (a, b) in enumerate(zip(wl, gl)):
+            assert torch.equal(a, b), (name, l, float((a.float() - b.float()).abs().max()))
