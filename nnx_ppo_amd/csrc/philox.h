@@ -60,4 +60,12 @@ __device__ inline void philox_normal_pair(uint64_t seed, uint64_t offset, uint64
   eps2 = box_muller(r.z, r.w);
 }
 
+// eps2 alone (same bits as philox_normal_pair's second output)
+__device__ inline float philox_normal_second(uint64_t seed, uint64_t offset, uint64_t elem) {
+  U4 c = {(uint32_t)elem, (uint32_t)(elem >> 32), (uint32_t)offset,
+          (uint32_t)(offset >> 32)};
+  const U4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return box_muller(r.z, r.w);
+}
+
 }  // namespace mippo

@@ -11,12 +11,23 @@ namespace mippo_sampler {
 constexpr float kLog2 = 0.69314718055994530942f;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
+// The row functions below are one-thread-per-row chains of transcendentals (a few
+// thousand cycles whatever the batch size): they sit at the tail of every policy launch.
+// exp / log go through the hardware v_exp_f32 / v_log_f32 (about an ulp each, ~3
+// instructions) instead of the libm expansions (15-40 instructions each); the results feed
+// fp32 sums of O(1) terms, where that is an absolute error of ~1e-7.
+__device__ inline float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ inline float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
 __device__ inline float softplus(float x) {
-  // jax.nn.softplus = logaddexp(x, 0)
-  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+  // jax.nn.softplus = logaddexp(x, 0) = max(x, 0) + log1p(exp(-|x|))
+  return fmaxf(x, 0.0f) + flog(1.0f + fexp(-fabsf(x)));
 }
 
-__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + fexp(-x)); }
+
+// tanh z = 1 - 2 / (exp(2 z) + 1); saturates correctly for |z| large
+__device__ inline float ftanh(float z) { return 1.0f - 2.0f / (fexp(2.0f * z) + 1.0f); }
 
 __device__ inline float log_det_jac(float z) {
   // sampling_layers.py:133: 2 (log 2 - z - softplus(-2 z))
@@ -38,6 +49,11 @@ struct Noise {
     mippo::philox_normal_pair(rng[0], rng[1] + offset_add, (uint64_t)elem, pe, pe2);
     e = eps ? eps[elem] : pe;
     e2 = eps2 ? eps2[elem] : pe2;
+  }
+  // the entropy noise alone (a replay scores stored actions: the action noise is unused)
+  __device__ inline float get_entropy_noise(int64_t elem) const {
+    if (eps2) return eps2[elem];
+    return mippo::philox_normal_second(rng[0], rng[1] + offset_add, (uint64_t)elem);
   }
 };
 
@@ -63,20 +79,24 @@ __device__ inline void fwd_row(const float* row, int64_t b, const FwdParams& p) 
     const int64_t e = b * A + a;
     const float mu = row[a];
     const float sigma = (softplus(row[A + a]) + p.min_std) * p.std_scale;
-    float eps, eps2;
-    p.noise.get(e, eps, eps2);
+    float eps = 0.0f, eps2;
+    if (p.extras || p.deterministic)  // the action noise is not needed: one Box-Muller, not two
+      eps2 = p.noise.get_entropy_noise(e);
+    else
+      p.noise.get(e, eps, eps2);
     const float sampled = p.deterministic ? mu : mu + sigma * eps;
     const float z = p.extras ? p.extras[e] : sampled;
     // _loglikelihood, sampling_layers.py:118-135
     const float q = (z - mu) / sigma;
-    float lp = -0.5f * (q * q) - (kHalfLog2Pi + logf(sigma));
+    const float log_sigma = flog(sigma);
+    float lp = -0.5f * (q * q) - (kHalfLog2Pi + log_sigma);
     lp -= log_det_jac(z);
     ll_acc += lp;
     // _entropy, sampling_layers.py:137-147
     const float z2 = mu + sigma * eps2;
-    h_acc += (0.5f + kHalfLog2Pi + logf(sigma)) + log_det_jac(z2);
+    h_acc += (0.5f + kHalfLog2Pi + log_sigma) + log_det_jac(z2);
     if (p.raw_out) p.raw_out[e] = z;
-    if (p.action) p.action[e] = tanhf(z);
+    if (p.action) p.action[e] = ftanh(z);
     if (p.mu_out) p.mu_out[e] = mu;
     if (p.sigma_out) p.sigma_out[e] = sigma;
   }
@@ -107,8 +127,7 @@ __device__ inline void bwd_row(int64_t b, const BwdParams& p, Store store) {
     const float mu = row[a];
     const float s = row[A + a];
     const float sigma = (softplus(s) + p.min_std) * p.std_scale;
-    float eps, eps2;
-    p.noise.get(e, eps, eps2);
+    const float eps2 = p.noise.get_entropy_noise(e);
     const float z = p.extras[e];
     const float inv = 1.0f / sigma;
     const float q = (z - mu) * inv;
@@ -116,7 +135,7 @@ __device__ inline void bwd_row(int64_t b, const BwdParams& p, Store store) {
     float g_mu = gl * q * inv;
     float g_sigma = gl * (q * q - 1.0f) * inv;
     // H: z2 = mu + sigma*eps2 ; d logdetjac / dz2 = -2 tanh(z2)
-    const float t2 = tanhf(mu + sigma * eps2);
+    const float t2 = ftanh(mu + sigma * eps2);
     g_mu += gh * (-2.0f * t2);
     g_sigma += gh * (inv - 2.0f * t2 * eps2);
     store(a, g_mu);
