@@ -552,6 +552,31 @@ int mi_policy_ws_fwd_bf16(
     void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
     void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream);
 
+/* The two halves of mi_dense_bwd_dw_grouped_bf16 on their own: the dW launch that leaves
+ * the split-M slabs in `workspace` (slab_ptr_out[l] / n_slabs_out[l]: where, how many;
+ * slab s of problem l is [K_l * N_l + N_l] floats: dW then db), and their fixed-order
+ * reduction into the gradients.  mi_adam_step_slabs_f32 is mi_adam_step_f32 that sums the
+ * slabs itself while it reads the gradient arena (gw_offset / gb_offset: arena index of
+ * each problem's kernel / bias gradient, gb < 0: no bias) — bit-identical to reducing
+ * first, one launch fewer per gradient step. */
+int mi_dense_bwd_dw_grouped_slabs_bf16(int64_t n, const void* const* x_bf,
+                                       const void* const* dz_bf, const int64_t* K,
+                                       const int64_t* N, int64_t M, void* workspace,
+                                       const void** slab_ptr_out, int64_t* n_slabs_out,
+                                       mi_stream_t stream);
+int mi_reduce_slabs_grouped_f32(int64_t n, const void* const* slab_ptr, const int64_t* n_slabs,
+                                const int64_t* K, const int64_t* N, float* const* g_w,
+                                float* const* g_b, int accumulate, mi_stream_t stream);
+int mi_adam_step_slabs_f32(
+    float* params, float* grads, float* m, float* v, int64_t n, float lr, float b1, float b2,
+    float eps, float weight_decay, int64_t* step, const float* grad_norm, float max_norm,
+    void* begin_next_ticket, int64_t n_shadows, const int64_t* shadow_begin,
+    const int64_t* shadow_K, const int64_t* shadow_N, void* const* w_bf, void* const* wt_bf,
+    void* const* frag_fwd, void* const* frag_bwd, int64_t n_slab_leaves,
+    const void* const* slab_ptr, const int64_t* n_slabs, const int64_t* slab_K,
+    const int64_t* slab_N, const int64_t* gw_offset, const int64_t* gb_offset,
+    mi_stream_t stream);
+
 /* Weights-stationary forms of mi_mlp_bwd_dx_bf16 (no input gradient, linear last layer)
  * and mi_policy_bwd_bf16 for training sizes: same operands (w_bf: the BACKWARD
  * fragment-major images; aux[l] = y_l, dz_bf[l] = dz_l for l < L - 1; dz_last = dz_{L-1}),

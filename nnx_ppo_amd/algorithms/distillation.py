@@ -196,7 +196,7 @@ def distillation_step(env, teacher: StatefulModule, distillation_state: Distilla
         minibatch = tree_map(lambda x: next(it), loss_view)
         student_state_subset = tree_map(lambda x: next(it).squeeze(0),
                                         distillation_state.student_states)
-        optimizer.begin()
+        optimizer.begin(defer_dw=True)
         _, lm = distillation_loss(student, student_state_subset, minibatch, logging_level)
         for k, v in lm.items():
             per_step.setdefault(k, []).append(v)

@@ -302,7 +302,7 @@ def ppo_step(
         minibatch = tree_map(lambda x: next(it), loss_view)
         net_state_subset = tree_map(lambda x: next(it).squeeze(0),
                                     training_state.network_states)
-        optimizer.begin()
+        optimizer.begin(defer_dw=True)
         _, lm = ppo_loss(networks, net_state_subset, minibatch, clip_range,
                          normalize_advantages, combine_advantages, discounting_factor,
                          gae_lambda, critic_loss_weight, logging_level, loss_out=loss_rows[i],

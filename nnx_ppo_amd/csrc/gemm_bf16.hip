@@ -799,23 +799,19 @@ extern "C" int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const
   return total * (int64_t)sizeof(float);
 }
 
-extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
-                                            const void* const* dz_bf, float* const* g_w,
-                                            float* const* g_b, const int64_t* K,
-                                            const int64_t* N, int64_t M, void* workspace,
-                                            int accumulate, mi_stream_t stream) {
-  MI_REQUIRE(n >= 1 && n <= kMaxDwProblems && M >= 1,
-             "mi_dense_bwd_dw_grouped_bf16: 1 <= n <= %d", kMaxDwProblems);
-  MI_REQUIRE(x_bf && dz_bf && g_w && K && N && workspace,
-             "mi_dense_bwd_dw_grouped_bf16: null pointer");
-  hipStream_t st = mippo::as_stream(stream);
+// The dW launch of a group (all tile classes in one launch); reports where each problem's
+// slabs sit in `workspace` and how many there are.
+static int dw_grouped_launch(const char* who, int64_t n, const void* const* x_bf,
+                             const void* const* dz_bf, const int64_t* K, const int64_t* N,
+                             int64_t M, void* workspace, const float** slab_ptr, int64_t* Sv,
+                             hipStream_t st) {
+  MI_REQUIRE(n >= 1 && n <= kMaxDwProblems && M >= 1, "%s: 1 <= n <= %d", who, kMaxDwProblems);
+  MI_REQUIRE(x_bf && dz_bf && K && N && workspace, "%s: null pointer", who);
   float* ws = static_cast<float*>(workspace);
-  const float* slab_ptr[kMaxDwProblems];
-  int64_t Sv[kMaxDwProblems], KNv[kMaxDwProblems];
+  int64_t KNv[kMaxDwProblems];
   for (int64_t l = 0; l < n; ++l) {
-    MI_REQUIRE(x_bf[l] && dz_bf[l] && g_w[l] && K[l] >= 1 && N[l] >= 1 && al16(x_bf[l]) &&
-                   al16(dz_bf[l]),
-               "mi_dense_bwd_dw_grouped_bf16: bad problem %lld", (long long)l);
+    MI_REQUIRE(x_bf[l] && dz_bf[l] && K[l] >= 1 && N[l] >= 1 && al16(x_bf[l]) && al16(dz_bf[l]),
+               "%s: bad problem %lld", who, (long long)l);
     KNv[l] = K[l] * N[l];
   }
   // one workgroup range per tile class (by output width), problems of a class side by
@@ -861,7 +857,7 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
     tab.gx = (int)gx;
     tab.gy = (int)gy;
     const int64_t blocks = gx * gy * tab.n * S;
-    MI_REQUIRE(next + blocks <= 0x7fffffffLL, "mi_dense_bwd_dw_grouped_bf16: grid too large");
+    MI_REQUIRE(next + blocks <= 0x7fffffffLL, "%s: grid too large", who);
     next += (unsigned)blocks;
     const size_t need = cls == 0 ? dw_lds_bytes<2, 2, 4, 4>()
                                  : (cls == 1 ? dw_lds_bytes<4, 1, 2, 4>() : dw_lds_bytes<4, 1, 2, 1>());
@@ -871,13 +867,69 @@ extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
   static const hipError_t attr = hipFuncSetAttribute(
       reinterpret_cast<const void*>(&tn_gemm_dw_all_kernel),
       hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2, 2, 4, 4>());
-  MI_REQUIRE(attr == hipSuccess, "mi_dense_bwd_dw_grouped_bf16: cannot raise the LDS limit");
+  MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);
   hipLaunchKernelGGL(tn_gemm_dw_all_kernel, dim3(next), dim3(kThreads), lds, st, all);
-  {
-    int rc = mippo::check_launch("mi_dense_bwd_dw_grouped_bf16");
-    if (rc) return rc;
+  return mippo::check_launch(who);
+}
+
+extern "C" int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf,
+                                            const void* const* dz_bf, float* const* g_w,
+                                            float* const* g_b, const int64_t* K,
+                                            const int64_t* N, int64_t M, void* workspace,
+                                            int accumulate, mi_stream_t stream) {
+  MI_REQUIRE(g_w, "mi_dense_bwd_dw_grouped_bf16: null pointer");
+  hipStream_t st = mippo::as_stream(stream);
+  const float* slab_ptr[kMaxDwProblems];
+  int64_t Sv[kMaxDwProblems], KNv[kMaxDwProblems];
+  int rc = dw_grouped_launch("mi_dense_bwd_dw_grouped_bf16", n, x_bf, dz_bf, K, N, M, workspace,
+                             slab_ptr, Sv, st);
+  if (rc) return rc;
+  for (int64_t l = 0; l < n; ++l) {
+    MI_REQUIRE(g_w[l], "mi_dense_bwd_dw_grouped_bf16: null gradient %lld", (long long)l);
+    KNv[l] = K[l] * N[l];
   }
   return mippo::reduce_slabs_grouped((int)n, slab_ptr, Sv, KNv, N, g_w, g_b, accumulate, st);
+}
+
+// The two halves of mi_dense_bwd_dw_grouped_bf16 on their own: the dW launch that leaves
+// the split-M slabs in `workspace` (slab_ptr_out[l], n_slabs_out[l] say where), and their
+// fixed-order reduction into the gradients.  A caller that reduces the slabs elsewhere —
+// mi_adam_step_slabs_f32 sums them while it reads the gradient arena — skips the second.
+extern "C" int mi_dense_bwd_dw_grouped_slabs_bf16(int64_t n, const void* const* x_bf,
+                                                  const void* const* dz_bf, const int64_t* K,
+                                                  const int64_t* N, int64_t M, void* workspace,
+                                                  const void** slab_ptr_out,
+                                                  int64_t* n_slabs_out, mi_stream_t stream) {
+  MI_REQUIRE(slab_ptr_out && n_slabs_out, "mi_dense_bwd_dw_grouped_slabs_bf16: null pointer");
+  const float* slab_ptr[kMaxDwProblems];
+  int64_t Sv[kMaxDwProblems];
+  int rc = dw_grouped_launch("mi_dense_bwd_dw_grouped_slabs_bf16", n, x_bf, dz_bf, K, N, M,
+                             workspace, slab_ptr, Sv, mippo::as_stream(stream));
+  if (rc) return rc;
+  for (int64_t l = 0; l < n; ++l) {
+    slab_ptr_out[l] = slab_ptr[l];
+    n_slabs_out[l] = Sv[l];
+  }
+  return 0;
+}
+
+extern "C" int mi_reduce_slabs_grouped_f32(int64_t n, const void* const* slab_ptr,
+                                           const int64_t* n_slabs, const int64_t* K,
+                                           const int64_t* N, float* const* g_w,
+                                           float* const* g_b, int accumulate,
+                                           mi_stream_t stream) {
+  MI_REQUIRE(n >= 1 && n <= kMaxDwProblems && slab_ptr && n_slabs && K && N && g_w,
+             "mi_reduce_slabs_grouped_f32: bad arguments");
+  const float* sp[kMaxDwProblems];
+  int64_t KNv[kMaxDwProblems];
+  for (int64_t l = 0; l < n; ++l) {
+    MI_REQUIRE(slab_ptr[l] && g_w[l] && n_slabs[l] >= 1 && K[l] >= 1 && N[l] >= 1,
+               "mi_reduce_slabs_grouped_f32: bad problem %lld", (long long)l);
+    sp[l] = static_cast<const float*>(slab_ptr[l]);
+    KNv[l] = K[l] * N[l];
+  }
+  return mippo::reduce_slabs_grouped((int)n, sp, n_slabs, KNv, N, g_w, g_b, accumulate,
+                                     mippo::as_stream(stream));
 }
 
 extern "C" int64_t mi_dense_bwd_dw_bf16_workspace_bytes(int64_t M, int64_t K, int64_t N) {

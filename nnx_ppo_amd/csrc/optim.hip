@@ -65,7 +65,9 @@ adam_kernel(mippo_optim::AdamArgs a) {
        pass_begin += (int64_t)gridDim.x * kThreads) {
     const int64_t i = pass_begin + threadIdx.x;
     if (i >= a.n) break;
-    mippo_optim::adam_element(a, st, i, pass_begin, a.g[i]);
+    float gi = a.g[i];
+    if (a.slabs.n) gi = gi + mippo_optim::slab_sum(a, i, pass_begin);
+    mippo_optim::adam_element(a, st, i, pass_begin, gi);
   }
   mippo_optim::adam_end(a, st);
 }
@@ -142,4 +144,48 @@ extern "C" int mi_adam_step_f32(float* params, float* grads, float* m, float* v,
   if (begin_next_ticket && grid > num_cus()) grid = num_cus();
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0, mippo::as_stream(stream), a);
   return mippo::check_launch("mi_adam_step_f32");
+}
+
+// mi_adam_step_f32 that also reduces the pending split-M slabs of a grouped dW launch
+// (mi_dense_bwd_dw_grouped_slabs_bf16) into the gradients it reads: gradient element i of
+// problem l's kernel / bias is g[i] + sum_s slab_l[s][...], summed exactly as
+// mi_reduce_slabs_grouped_f32 would (bit-identical), without that launch.
+extern "C" int mi_adam_step_slabs_f32(
+    float* params, float* grads, float* m, float* v, int64_t n, float lr, float b1, float b2,
+    float eps, float weight_decay, int64_t* step, const float* grad_norm, float max_norm,
+    void* begin_next_ticket, int64_t n_shadows, const int64_t* shadow_begin,
+    const int64_t* shadow_K, const int64_t* shadow_N, void* const* w_bf, void* const* wt_bf,
+    void* const* frag_fwd, void* const* frag_bwd, int64_t n_slab_leaves,
+    const void* const* slab_ptr, const int64_t* n_slabs, const int64_t* slab_K,
+    const int64_t* slab_N, const int64_t* gw_offset, const int64_t* gb_offset,
+    mi_stream_t stream) {
+  mippo_optim::AdamArgs a;
+  int rc = mippo_optim::fill_adam_args(a, "mi_adam_step_slabs_f32", params, grads, m, v, n, lr, b1,
+                                       b2, eps, weight_decay, step, grad_norm, max_norm,
+                                       begin_next_ticket, n_shadows, shadow_begin, shadow_K,
+                                       shadow_N, w_bf, wt_bf, frag_fwd, frag_bwd);
+  if (rc) return rc;
+  MI_REQUIRE(n_slab_leaves >= 0 && n_slab_leaves <= mippo_optim::kMaxSlabLeaves,
+             "mi_adam_step_slabs_f32: 0 <= n_slab_leaves <= %d", mippo_optim::kMaxSlabLeaves);
+  MI_REQUIRE(begin_next_ticket, "mi_adam_step_slabs_f32: the launch must zero the gradients "
+                                "(the slabs are consumed here)");
+  a.slabs.n = (int)n_slab_leaves;
+  for (int64_t l = 0; l < n_slab_leaves; ++l) {
+    MI_REQUIRE(slab_ptr && n_slabs && slab_K && slab_N && gw_offset && gb_offset && slab_ptr[l] &&
+                   n_slabs[l] >= 1 && slab_K[l] >= 1 && slab_N[l] >= 1 && gw_offset[l] >= 0 &&
+                   gw_offset[l] + slab_K[l] * slab_N[l] <= n &&
+                   (gb_offset[l] < 0 || gb_offset[l] + slab_N[l] <= n),
+               "mi_adam_step_slabs_f32: bad slab leaf %lld", (long long)l);
+    mippo_optim::SlabLeaf& lf = a.slabs.leaf[l];
+    lf.slabs = static_cast<const float*>(slab_ptr[l]);
+    lf.S = (int)n_slabs[l];
+    lf.KN = (int)(slab_K[l] * slab_N[l]);
+    lf.N = (int)slab_N[l];
+    lf.gw_off = gw_offset[l];
+    lf.gb_off = gb_offset[l];
+  }
+  int grid = stream_grid(n);
+  if (grid > num_cus()) grid = num_cus();
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0, mippo::as_stream(stream), a);
+  return mippo::check_launch("mi_adam_step_slabs_f32");
 }

@@ -25,6 +25,20 @@ struct ShadowTable {
   int n;
 };
 
+// Split-M slabs of a grouped dW launch (gemm_bf16.hip) whose reduction rides on the
+// optimiser launch: leaf l adds sum_s slab[s][...] to the gradient of its kernel
+// (arena range [gw_off, gw_off + KN)) and bias ([gb_off, gb_off + N), gb_off < 0: none).
+struct SlabLeaf {
+  const float* slabs;  // [S][KN + N]
+  int64_t gw_off, gb_off;
+  int S, KN, N;
+};
+constexpr int kMaxSlabLeaves = 8;
+struct SlabTable {
+  SlabLeaf leaf[kMaxSlabLeaves];
+  int n;
+};
+
 struct AdamArgs {
   float *p, *g, *m, *v;
   int64_t n;
@@ -34,6 +48,7 @@ struct AdamArgs {
   float max_norm;
   unsigned int* ticket;    // nullable: this launch also opens the next gradient step
   ShadowTable shadows;
+  SlabTable slabs;
 };
 
 struct AdamStep {
@@ -74,6 +89,44 @@ __device__ inline AdamStep adam_begin(const AdamArgs& a) {
       st.arrival = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return st;
+}
+
+// Sum over the pending dW slabs that cover arena element i (0 if none): the fixed
+// summation order of reduce_slabs_grouped_kernel (s = 0 .. S-1), 16 loads in flight.
+__device__ inline float slab_sum(const AdamArgs& a, int64_t i, int64_t pass_begin) {
+  float total = 0.0f;
+  for (int l = 0; l < a.slabs.n; ++l) {
+    const SlabLeaf& lf = a.slabs.leaf[l];
+    const int64_t stride = (int64_t)lf.KN + lf.N;
+    // wave-uniform range tests first (the pass is one contiguous 256-element range)
+    const bool w_hit = lf.gw_off < pass_begin + mippo_bf16::kThreads && lf.gw_off + lf.KN > pass_begin;
+    const bool b_hit = lf.gb_off >= 0 && lf.gb_off < pass_begin + mippo_bf16::kThreads &&
+                       lf.gb_off + lf.N > pass_begin;
+    if (!w_hit && !b_hit) continue;
+    int64_t idx = -1;
+    if (w_hit && i >= lf.gw_off && i < lf.gw_off + lf.KN) idx = i - lf.gw_off;
+    if (b_hit && i >= lf.gb_off && i < lf.gb_off + lf.N) idx = lf.KN + (i - lf.gb_off);
+    if (idx < 0) continue;
+    float v = 0.0f;
+    int s = 0;
+    for (; s + 16 <= lf.S; s += 16) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = lf.slabs[(int64_t)(s + u) * stride + idx];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += t[u];
+    }
+    if (s < lf.S) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = s + u < lf.S ? lf.slabs[(int64_t)(s + u) * stride + idx] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (s + u < lf.S) v += t[u];
+    }
+    total += v;  // one leaf covers an element: this is `g + v` of the reduction kernel
+  }
+  return total;
 }
 
 // Element i with (already reduced) gradient gi.  `pass_begin`: start of the 256-element

@@ -34,6 +34,9 @@ FUSED = os.environ.get("MIPPO_FUSED_POLICY", "1") != "0"
 # default a training-size replay of trunks in their shape class runs on the
 # weights-stationary kernels (csrc/trunk_ws.hip) — same results bit for bit
 WS_POLICY = os.environ.get("MIPPO_WS_POLICY", "1") != "0"
+# the weights-stationary backward measures no faster than policy_bwd_kernel (30.1 vs 29.4 us
+# at C2): off unless MIPPO_WS_POLICY_BWD=1
+WS_POLICY_BWD = os.environ.get("MIPPO_WS_POLICY_BWD", "0") == "1"
 WS_MIN_ROWS = 8192
 
 
@@ -214,7 +217,7 @@ class MLPActorCritic(Sequential):
                               [ls[0].in_features] + [l.out_features for l in ls],
                               [l.act_code for l in ls], [sv[1] for sv in c[0]])
         da, dc = desc(a_layers, a_ctx), desc(c_layers, v_ctx)
-        ws = (WS_POLICY and M > WS_MIN_ROWS and ms2.shape[1] <= 64
+        ws = (WS_POLICY_BWD and M > WS_MIN_ROWS and ms2.shape[1] <= 64
               and ops.policy_ws_supported(da[1], da[2], dc[1], dc[2]))
         a_dz, c_dz = ops.policy_bwd_bf16(
             ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, g_v, da, dc, eps2=eps2,

@@ -357,6 +357,57 @@ def dense_bwd_dw_bf16(x_bf, dz_bf, g_w, g_b, accumulate: bool = True) -> None:
                                      N, int(bool(accumulate)), stream()), "mi_dense_bwd_dw_bf16")
 
 
+class _SlabDefer:
+    """The reduction of a grouped dW launch's split-M slabs can ride on the optimiser
+    launch (`mi_adam_step_slabs_f32`) instead of its own.  `Optimizer.begin(defer_dw=True)`
+    turns it on for one gradient step: the LAST grouped dW call of the step then leaves its
+    slabs pending, and `Optimizer.update` either folds them into the Adam launch or — when
+    something reads the gradients first (norm, all-reduce) — reduces them with
+    `flush_pending_slabs`.  Off by default: `.grad` is complete after every backward.
+    Only gradients that live inside `arena` (the optimiser's gradient arena) defer."""
+    arena = None    # float32 [n] while a deferring gradient step is open
+    pending = None  # (slab_ptrs, S, Ks, Ns, g_w, g_b, gw_off, gb_off, workspace)
+
+    def offsets(self, g_w, g_b, Ks, Ns):
+        """Arena offsets of the gradients, or None if one lies outside the arena."""
+        if self.arena is None:
+            return None
+        base, n = self.arena.data_ptr(), self.arena.numel()
+        gw_off, gb_off = [], []
+        for w, b, K, N in zip(g_w, g_b, Ks, Ns):
+            ow = (w.data_ptr() - base) // 4
+            ob = -1 if b is None else (b.data_ptr() - base) // 4
+            if not (w.is_contiguous() and 0 <= ow and ow + K * N <= n):
+                return None
+            if b is not None and not (b.is_contiguous() and 0 <= ob and ob + N <= n):
+                return None
+            gw_off.append(ow)
+            gb_off.append(ob)
+        return gw_off, gb_off
+
+
+slab_defer = _SlabDefer()
+
+
+def flush_pending_slabs() -> None:
+    """Reduce the pending slabs (if any) into their gradients now."""
+    pend, slab_defer.pending = slab_defer.pending, None
+    if pend is None:
+        return
+    sp, S, Ks, Ns, g_w, g_b = pend[:6]
+    n = len(Ks)
+    P = ctypes.c_void_p * n
+    I = ctypes.c_int64 * n
+    check(lib().mi_reduce_slabs_grouped_f32(
+        n, P(*sp), I(*S), I(*Ks), I(*Ns), P(*[ptr(t, f32) for t in g_w]),
+        P(*[ptr(t, f32) for t in g_b]), 1, stream()), "mi_reduce_slabs_grouped_f32")
+
+
+def take_pending_slabs():
+    pend, slab_defer.pending = slab_defer.pending, None
+    return pend
+
+
 def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
     """dW / db of several layers that share M: `problems` = [(x_bf, dz_bf, g_w, g_b)]."""
     for i in range(0, len(problems), 8):
@@ -373,16 +424,30 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
         Kc, Nc = I(*Ks), I(*Ns)
         nbytes = lib().mi_dense_bwd_dw_grouped_bf16_workspace_bytes(n, Kc, Nc, M)
         _need(nbytes >= 0, "mi_dense_bwd_dw_grouped_bf16_workspace_bytes failed")
+        # the slabs of a pending launch live in the same workspace
+        flush_pending_slabs()
         ws = workspace(grp[0][2].device, "dense_dw_grouped", nbytes)
         if profiler.active:
             profiler.next_flops = 2.0 * M * sum(K * N for K, N in zip(Ks, Ns))
             # operands once + fp32 gradients read-modify-written
             profiler.next_bytes = (sum((g[0].numel() + g[1].numel()) * 2.0 for g in grp)
                                    + sum(8.0 * (K * N + N) for K, N in zip(Ks, Ns)))
+        xs = P(*[ptr(g[0], bf16) for g in grp])
+        dzs = P(*[ptr(g[1], bf16) for g in grp])
+        offs = None
+        if accumulate and i + 8 >= len(problems):
+            offs = slab_defer.offsets([g[2] for g in grp], [g[3] for g in grp], Ks, Ns)
+        if offs is not None:
+            sp, S = P(), I()
+            check(lib().mi_dense_bwd_dw_grouped_slabs_bf16(n, xs, dzs, Kc, Nc, M, ptr(ws), sp, S,
+                                                           stream()),
+                  "mi_dense_bwd_dw_grouped_slabs_bf16")
+            slab_defer.pending = (list(sp), list(S), Ks, Ns, [g[2] for g in grp],
+                                  [g[3] for g in grp], offs[0], offs[1], ws)
+            continue
         check(lib().mi_dense_bwd_dw_grouped_bf16(
-            n, P(*[ptr(g[0], bf16) for g in grp]), P(*[ptr(g[1], bf16) for g in grp]),
-            P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]), Kc, Nc, M,
-            ptr(ws), int(bool(accumulate)), stream()), "mi_dense_bwd_dw_grouped_bf16")
+            n, xs, dzs, P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]),
+            Kc, Nc, M, ptr(ws), int(bool(accumulate)), stream()), "mi_dense_bwd_dw_grouped_bf16")
 
 
 def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
@@ -744,11 +809,14 @@ def global_norm(grads: torch.Tensor, out: torch.Tensor | None = None) -> torch.T
 
 def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: float = 0.999,
               eps: float = 1e-8, weight_decay: float = 0.0, grad_norm=None,
-              max_norm: float = 0.0, begin_next: bool = False, shadows=None) -> None:
+              max_norm: float = 0.0, begin_next: bool = False, shadows=None,
+              slabs=None) -> None:
     """`begin_next`: `step` counts completed steps; this launch advances it and leaves
     `grads` zeroed (it doubles as the next step's `begin_grad_step`).  `shadows`: up to
     16 tuples (begin, K, N, w_bf, wt_bf, frag_fwd, frag_bwd) of Dense kernels stored in
-    `params` whose bf16 images are written by the same launch."""
+    `params` whose bf16 images are written by the same launch.  `slabs`: pending dW slabs
+    (slab_ptrs, S, Ks, Ns, gw_offsets, gb_offsets) summed into the gradient as it is read
+    (`mi_adam_step_slabs_f32`)."""
     n = params.numel()
     for t in (grads, m, v):
         _need(t.numel() == n, "adam_step: arena sizes differ")
@@ -758,17 +826,27 @@ def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: floa
     I = ctypes.c_int64 * max(ns, 1)
     P = ctypes.c_void_p * max(ns, 1)
     col = lambda j: [t[j] for t in sh]
-    check(lib().mi_adam_step_f32(ptr(params, f32), ptr(grads, f32), ptr(m, f32), ptr(v, f32), n,
-                                 float(lr), float(b1), float(b2), float(eps),
-                                 float(weight_decay), ptr(step, i64), ptr(grad_norm, f32),
-                                 float(max_norm), ptr(ticket), ns,
-                                 I(*col(0)) if ns else None, I(*col(1)) if ns else None,
-                                 I(*col(2)) if ns else None,
-                                 P(*[ptr(t, bf16) for t in col(3)]) if ns else None,
-                                 P(*[ptr(t, bf16) for t in col(4)]) if ns else None,
-                                 P(*[ptr(t, bf16) for t in col(5)]) if ns else None,
-                                 P(*[ptr(t, bf16) for t in col(6)]) if ns else None,
-                                 stream()), "mi_adam_step_f32")
+    args = (ptr(params, f32), ptr(grads, f32), ptr(m, f32), ptr(v, f32), n,
+            float(lr), float(b1), float(b2), float(eps),
+            float(weight_decay), ptr(step, i64), ptr(grad_norm, f32),
+            float(max_norm), ptr(ticket), ns,
+            I(*col(0)) if ns else None, I(*col(1)) if ns else None,
+            I(*col(2)) if ns else None,
+            P(*[ptr(t, bf16) for t in col(3)]) if ns else None,
+            P(*[ptr(t, bf16) for t in col(4)]) if ns else None,
+            P(*[ptr(t, bf16) for t in col(5)]) if ns else None,
+            P(*[ptr(t, bf16) for t in col(6)]) if ns else None)
+    if slabs is None:
+        check(lib().mi_adam_step_f32(*args, stream()), "mi_adam_step_f32")
+        return
+    _need(begin_next, "adam_step: pending slabs need begin_next (the launch consumes them)")
+    sp, S, Ks, Ns, gw_off, gb_off = slabs
+    nl = len(Ks)
+    Pl = ctypes.c_void_p * nl
+    Il = ctypes.c_int64 * nl
+    check(lib().mi_adam_step_slabs_f32(*args, nl, Pl(*sp), Il(*S), Il(*Ks), Il(*Ns),
+                                       Il(*gw_off), Il(*gb_off), stream()),
+          "mi_adam_step_slabs_f32")
 
 
 # ------------------------------------------------------ a5 / a7: movement

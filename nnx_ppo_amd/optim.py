@@ -12,6 +12,7 @@ their gradients / Adam moments into three more), each parameter starting on a
 unchanged.  The step counter and gradient norm stay on the device."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -20,6 +21,8 @@ from . import ops, parallel
 from .networks.types import StatefulModule, bump_param_epoch
 
 _ALIGN = 64  # floats (256 B)
+# MIPPO_DEFER_DW=0: always reduce the dW slabs in their own launch (A/B switch)
+DEFER_DW = os.environ.get("MIPPO_DEFER_DW", "1") != "0"
 
 
 class Optimizer:
@@ -65,16 +68,33 @@ class Optimizer:
         bump_param_epoch()
 
     # ---- one gradient step = begin() ... backward ... update() --------------------
-    def begin(self) -> None:
+    def begin(self, defer_dw: bool = False) -> None:
         """Start a gradient step with a zeroed gradient arena.  `update()` leaves the
         arena zeroed (and counts the step) in the Adam launch itself, so in the
         training loop this is free; it only launches when gradients were accumulated
-        since the last update (e.g. two loss evaluations without an update)."""
+        since the last update (e.g. two loss evaluations without an update).
+
+        `defer_dw`: the caller promises to read the gradients only through this
+        optimiser until `update()`; the split-M slabs of the step's last grouped dW
+        launch then stay unreduced and `update()` sums them inside the Adam launch (same
+        summation order, one launch fewer).  Without it `.grad` is complete after every
+        backward."""
+        ops.flush_pending_slabs()
         if not self._clean:
             ops.begin_grad_step(self.grads, None)
         self._clean = False
+        ops.slab_defer.arena = self.grads if (defer_dw and DEFER_DW) else None
+
+    def _pending_slabs(self):
+        """The pending dW slabs in `adam_step`'s form (None: nothing pending)."""
+        pend = ops.take_pending_slabs()
+        if pend is None:
+            return None
+        sp, S, Ks, Ns, _, _, gw_off, gb_off, _ = pend
+        return (sp, S, Ks, Ns, gw_off, gb_off)
 
     def compute_grad_norm(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        ops.flush_pending_slabs()
         return ops.global_norm(self.grads, out=self.grad_norm if out is None else out)
 
     def update(self, have_norm: bool = False, norm_out: Optional[torch.Tensor] = None) -> None:
@@ -87,6 +107,10 @@ class Optimizer:
         shadowed = dense_chain.shadows_in(self.params)[:16]
         table = [(off, l.kernel.shape[0], l.kernel.shape[1], l._w_bf, l._wt_bf, l._ff, l._fb)
                  for l, off in shadowed]
+        ops.slab_defer.arena = None
+        if parallel.is_distributed() or norm_out is not None or \
+                (self.gradient_clipping is not None and not have_norm):
+            ops.flush_pending_slabs()  # somebody reads the whole gradient before Adam
         if parallel.is_distributed():
             comm = parallel.peer_comm()
             if comm is not None and norm_out is None and self.gradient_clipping is None and \
@@ -114,7 +138,7 @@ class Optimizer:
                       lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
                       weight_decay=self.weight_decay, grad_norm=gn,
                       max_norm=float(self.gradient_clipping or 0.0), begin_next=True,
-                      shadows=table)
+                      shadows=table, slabs=self._pending_slabs())
         self._clean = True
         bump_param_epoch()
         dense_chain.mark_fresh([l for l, _ in shadowed])

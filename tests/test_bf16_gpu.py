@@ -295,6 +295,57 @@ def test_grouped_dw_matches_per_layer(dev):
             assert torch.allclose(gb, gb1, rtol=1e-4, atol=2e-3), (K, N)
 
 
+@pytest.mark.parametrize("M", [40, 3000, 61440])
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_dw_slabs_reduced_inside_adam_are_bit_identical(dev, M, clip):
+    """`mi_adam_step_slabs_f32` sums the split-M slabs of a grouped dW launch while it reads
+    the gradient arena; parameters, moments, bf16 images and the zeroed gradient must equal
+    `mi_reduce_slabs_grouped_f32` followed by `mi_adam_step_f32` bit for bit (same
+    summation order).  Through the optimiser: `begin(defer_dw=True)` vs `begin()`."""
+    from nnx_ppo_amd import ops, optim
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+
+    results = []
+    for defer in (False, True):
+        net = factories.make_mlp_actor_critic(5, 2, [64, 64], [256], Rngs(3)).to(dev)
+        opt = optim.Optimizer(net, 1e-3, gradient_clipping=clip, weight_decay=True)
+        named = dict(net.named_parameters())
+        layers = [(p, named.get(k[:-len("kernel")] + "bias")) for k, p in named.items()
+                  if k.endswith("kernel") and len(p.shape) == 2]
+        assert len(layers) == 5
+        g = np.random.default_rng(7)
+        opt.begin(defer_dw=defer)
+        # something already in the gradient (the reduction ADDS to it)
+        opt.grads.copy_(torch.as_tensor(g.normal(size=opt.n).astype(np.float32)).to(dev) * 1e-2)
+        problems = []
+        for w, bias in layers:
+            K, N = w.shape
+            x = ops.cast_pad_bf16(torch.as_tensor(g.normal(size=(M, K)).astype(np.float32)).to(dev))
+            dz = ops.cast_pad_bf16(torch.as_tensor(g.normal(size=(M, N)).astype(np.float32)).to(dev) * 1e-2)
+            problems.append((x, dz, w.grad, bias.grad if bias is not None else None))
+        ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
+        assert (ops.slab_defer.pending is not None) == defer
+        if clip is not None:
+            opt.compute_grad_norm()  # flushes: a whole-gradient reader
+            assert ops.slab_defer.pending is None
+            opt.update(have_norm=True)
+        else:
+            opt.update()
+        assert ops.slab_defer.pending is None and ops.slab_defer.arena is None
+        torch.cuda.synchronize()
+        assert float(opt.grads.abs().max()) == 0.0
+        from nnx_ppo_amd.networks import dense_chain
+        results.append((opt.params.clone(), opt.m.clone(), opt.v.clone(),
+                        [l._w_bf.clone() for l, _ in dense_chain.shadows_in(opt.params)]))
+    a, b = results
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[3], b[3]):
+        assert torch.equal(x, y)
+    assert float((a[1] != 0).float().mean()) > 0.5
+
+
 @pytest.mark.parametrize("dims", [[5, 64, 64, 64, 64, 2], [5, 256, 256, 1], [17, 512, 512, 1],
                                   [33, 40, 129, 7], [17, 256, 256, 256, 256, 12]])
 @pytest.mark.parametrize("M", [7, 1000, 9000])

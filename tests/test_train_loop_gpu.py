@@ -50,6 +50,40 @@ def _run(dev, **kw):
     return res, net, logs, ckpts
 
 
+def test_train_ppo_dw_slabs_in_adam_equal_separate_reduction(dev, monkeypatch):
+    """Without clipping / GRAD_NORM the dW slab reduction rides on the Adam launch
+    (`Optimizer.begin(defer_dw=True)`); the run must be bit-identical to the one that
+    reduces the slabs in their own launch (MIPPO_DEFER_DW=0)."""
+    from nnx_ppo_amd import ops, optim
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.types import LoggingLevel
+
+    out = []
+    for defer in (True, False):
+        monkeypatch.setattr(optim, "DEFER_DW", defer)
+        env, net = _setup()
+        logs = []
+        res = ppo.train_ppo(env, net, _cfg(level=LoggingLevel.LOSSES), compute_dtype="bf16",
+                            log_fn=lambda m, s: logs.append(dict(m)), hip_graph=True)
+        out.append((res.training_state.optimizer.params.clone(),
+                    res.training_state.optimizer.m.clone(), logs))
+        assert ops.slab_defer.pending is None and ops.slab_defer.arena is None
+        # which entries an eager iteration goes through
+        from nnx_ppo_amd import _lib, config
+        ts = res.training_state
+        with config.use_compute_dtype("bf16"), _lib.profiler as prof:
+            ppo.ppo_step(env, ts, 64, 8, 0.95, 0.99, 0.2, True, False, 2, 2)
+        used = {name for name, *_ in prof.records}
+        assert ("mi_adam_step_slabs_f32" in used) == defer, used
+        assert ("mi_dense_bwd_dw_grouped_slabs_bf16" in used) == defer, used
+    (pa, ma, la), (pb, mb, lb) = out
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
+    for x, y in zip(la, lb):
+        for k in x:
+            if not k.startswith("throughput/"):
+                assert float(x[k]) == float(y[k]), k
+
+
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
 def test_train_ppo_graph_equals_eager(dev, compute):
     """Iteration 1 eager, 2 recorded, 3+ replayed == every iteration launched from Python:

@@ -125,7 +125,7 @@ def test_ppo_step_on_ws_kernels_equals_tile_kernels(dev):
     outs = []
     with config.use_compute_dtype("bf16"):
         for ws in (True, False):
-            policy.WS_POLICY = ws
+            policy.WS_POLICY = policy.WS_POLICY_BWD = ws
             try:
                 env = EpisodeWrapper(cartpole_shaped(max_steps=9), 30)
                 net = factories.make_mlp_actor_critic(5, 1, [64] * 4, [256] * 2, Rngs(17))
@@ -134,7 +134,7 @@ def test_ppo_step_on_ws_kernels_equals_tile_kernels(dev):
                     ts, m = ppo.ppo_step(env, ts, 2048, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
                 outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()}))
             finally:
-                policy.WS_POLICY = True
+                policy.WS_POLICY, policy.WS_POLICY_BWD = True, False
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
 
