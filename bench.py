@@ -51,6 +51,7 @@ FWD_FLOP_PER_SAMPLE = 2 * (OBS * 64 + 3 * 64 * 64 + 64 * 2 * ACT + OBS * 256 + 2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16
 PEAK_HBM_GBPS = 8000.0          # HBM3E, MI355X_MICROARCH.md
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"  # HBM bytes per launch from the PMC passes
 
 
 # symbol -> (M, K, N) from the integer arguments of a recorded call (in call order;
@@ -66,7 +67,10 @@ GEMM_SYMBOLS = {
     "mi_mlp_bwd_dx_bf16": None,
     "mi_policy_fwd_bf16": None,
     "mi_policy_bwd_bf16": None,
+    "mi_policy_ws_fwd_bf16": None,
+    "mi_policy_ws_bwd_bf16": None,
     "mi_dense_bwd_dw_grouped_bf16": None,
+    "mi_dense_bwd_dw_grouped_slabs_bf16": None,
 }
 
 
@@ -156,10 +160,19 @@ def roofline_of_dominant_kernel(env, ts):
                 M = ints[0] if name == "mi_policy_fwd_bf16" else ints[1]  # (offset_add, M, ..)
                 shape = "1, 4, 1, 4" if M <= 8192 else ("16, 1, 4, 4" if narrow else "4, 4, 4, 4")
                 add(f"{kern}<{shape}>", t_ms, work)
+        if name in ("mi_policy_ws_fwd_bf16", "mi_policy_ws_bwd_bf16"):
+            # csrc/trunk_ws.hip: one C call = TWO launches of the weights-stationary kernel
+            # (action trunk + sampler, value trunk + bootstrap rows); bracketed as a pair
+            kern = "trunk_ws_fwd_kernel" if name == "mi_policy_ws_fwd_bf16" else "trunk_ws_bwd_kernel"
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                add(f"{kern} pair (action<64,3,.> + value<256,1,.>)", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",
                     t_ms, work)
+        if name == "mi_dense_bwd_dw_grouped_slabs_bf16":
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                add("tn_gemm_dw_all_kernel (slabs reduced by adam_kernel)", t_ms, work)
         if name in GEMM_SYMBOLS:
             if GEMM_SYMBOLS[name] is None:
                 flops += d["flops"]
@@ -183,11 +196,12 @@ def roofline_of_dominant_kernel(env, ts):
         "note": "every dense launch (trunk fwd, dX chain, dW): SURVEY 8(d)'s 2*M*K*N count",
     }
     traffic_db = {}
-    pmc = Path(__file__).resolve().parent / "profiles" / "r01_pmc_traffic.json"
+    pmc = Path(__file__).resolve().parent / "profiles" / PMC_TRAFFIC_FILE
     if pmc.exists():
         traffic_db = json.loads(pmc.read_text()).get("kernels", {})
     trunk = {k: v for k, v in classes.items()
-             if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel"))}
+             if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel",
+                              "trunk_ws_"))}
     if trunk:
         # Dominant kernel = the trunk class with the most device time.  Its arithmetic
         # intensity (~100-150 flop/B with the activations kept for the backward) is below
@@ -202,7 +216,7 @@ def roofline_of_dominant_kernel(env, ts):
             "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5),
             "traffic": None if t is None else t["hbm_bytes_per_launch"],
             "traffic_source": None if t is None else
-            "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+            f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
             "this command; FETCH_SIZE x2 on gfx950)",
             "launches_per_iter": c["launches"],
             "avg_launch_us": round(c["ms"] / c["launches"] * 1e3, 2),

@@ -60,14 +60,27 @@ __global__ void norm_finalize_kernel(const double* partials, int G, float* norm_
 // shared with the launch that carries the one-shot gradient exchange (comm.hip).
 __global__ void __launch_bounds__(kThreads)
 adam_kernel(mippo_optim::AdamArgs a) {
+  // Every load of a pass is issued before anything waits: gradient, moments, parameter,
+  // then the slab sums; the first pass's are in flight while adam_begin reads the step.
+  int64_t pass_begin = (int64_t)blockIdx.x * kThreads;
+  int64_t i = pass_begin + threadIdx.x;
+  float gi = 0.0f, m0 = 0.0f, v0 = 0.0f, p0 = 0.0f;
+  auto fetch = [&] {
+    if (i < a.n) {
+      gi = a.g[i];
+      m0 = a.m[i];
+      v0 = a.v[i];
+      p0 = a.p[i];
+      if (a.slabs.n) gi = gi + mippo_optim::slab_sum(a, i, pass_begin);
+    }
+  };
+  fetch();
   const mippo_optim::AdamStep st = mippo_optim::adam_begin(a);
-  for (int64_t pass_begin = (int64_t)blockIdx.x * kThreads; pass_begin < a.n;
-       pass_begin += (int64_t)gridDim.x * kThreads) {
-    const int64_t i = pass_begin + threadIdx.x;
-    if (i >= a.n) break;
-    float gi = a.g[i];
-    if (a.slabs.n) gi = gi + mippo_optim::slab_sum(a, i, pass_begin);
-    mippo_optim::adam_element(a, st, i, pass_begin, gi);
+  while (pass_begin < a.n) {
+    if (i < a.n) mippo_optim::adam_element(a, st, i, pass_begin, gi, m0, v0, p0);
+    pass_begin += (int64_t)gridDim.x * kThreads;
+    i = pass_begin + threadIdx.x;
+    if (pass_begin < a.n) fetch();
   }
   mippo_optim::adam_end(a, st);
 }
@@ -109,6 +122,10 @@ extern "C" int mi_global_norm_f32(const float* grads, int64_t n, float* norm_out
   return mippo::check_launch("mi_global_norm_f32(finalize)");
 }
 
+// Adam grid cap: two 256-thread blocks per CU keep the arenas of the reference networks (80 K -
+// 700 K floats) to one or two passes, and 512 ticket increments still cost nothing
+constexpr int kAdamBlocksPerCU = 2;
+
 // CUs of the device the library runs on (queried once; 256 on MI355X)
 static int num_cus() {
   static const int n = [] {
@@ -141,7 +158,7 @@ extern "C" int mi_adam_step_f32(float* params, float* grads, float* m, float* v,
   // every block takes a ticket when this launch also opens the next step: keep the
   // grid at one block per CU so the tickets do not serialise on the counter's L2 line
   int grid = stream_grid(n);
-  if (begin_next_ticket && grid > num_cus()) grid = num_cus();
+  if (begin_next_ticket && grid > kAdamBlocksPerCU * num_cus()) grid = kAdamBlocksPerCU * num_cus();
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0, mippo::as_stream(stream), a);
   return mippo::check_launch("mi_adam_step_f32");
 }
@@ -185,7 +202,7 @@ extern "C" int mi_adam_step_slabs_f32(
     lf.gb_off = gb_offset[l];
   }
   int grid = stream_grid(n);
-  if (grid > num_cus()) grid = num_cus();
+  if (grid > kAdamBlocksPerCU * num_cus()) grid = kAdamBlocksPerCU * num_cus();
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0, mippo::as_stream(stream), a);
   return mippo::check_launch("mi_adam_step_slabs_f32");
 }

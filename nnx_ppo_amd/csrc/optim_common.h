@@ -133,15 +133,18 @@ __device__ inline float slab_sum(const AdamArgs& a, int64_t i, int64_t pass_begi
 // contiguous arena range this wave group is working on (i - threadIdx.x), so the shadow
 // leaves that overlap it are found with wave-uniform (scalar) tests; inside a leaf the
 // index arithmetic is 32-bit.
+// `m0`, `v0`, `p0`: the element's moments and parameter, loaded by the caller (early, so
+// the loads overlap whatever produces gi).
 __device__ inline void adam_element(const AdamArgs& a, const AdamStep& st, int64_t i,
-                                    int64_t pass_begin, float gi) {
+                                    int64_t pass_begin, float gi, float m0, float v0,
+                                    float p0) {
   if (st.clip) gi = gi / st.gn * a.max_norm;
-  const float mi = a.b1 * a.m[i] + (1.0f - a.b1) * gi;
-  const float vi = a.b2 * a.v[i] + (1.0f - a.b2) * (gi * gi);
+  const float mi = a.b1 * m0 + (1.0f - a.b1) * gi;
+  const float vi = a.b2 * v0 + (1.0f - a.b2) * (gi * gi);
   a.m[i] = mi;
   a.v[i] = vi;
   float u = (mi / st.bc1) / (sqrtf(vi / st.bc2) + a.eps);
-  const float pi = a.p[i];
+  const float pi = p0;
   if (a.weight_decay != 0.0f) u += a.weight_decay * pi;
   const float pn = pi - a.lr * u;
   a.p[i] = pn;
@@ -162,6 +165,11 @@ __device__ inline void adam_element(const AdamArgs& a, const AdamStep& st, int64
       if (lf.fb) lf.fb[frag_index((int)k, (int)c, lf.N)] = b;  // columns = inputs,  reduce = N
     }
   }
+}
+
+__device__ inline void adam_element(const AdamArgs& a, const AdamStep& st, int64_t i,
+                                    int64_t pass_begin, float gi) {
+  adam_element(a, st, i, pass_begin, gi, a.m[i], a.v[i], a.p[i]);
 }
 
 // The block whose signal arrived last publishes step + 1 and re-arms the ticket (every
