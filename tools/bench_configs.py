@@ -41,10 +41,14 @@ def build(name, n_envs, device):
         net = Sequential([Normalizer({"position": 8, "velocity": 9}), Flattener(),
                           PPOAdapter(action=Sequential([*actor, sampler]), value=critic)])
         desc = "CheetahRun-shaped dict obs {position 8, velocity 9}, MLP 4x256 / 2x512"
-    elif name == "c4":
-        env = EpisodeWrapper(cartpole_shaped(max_steps=1000), 1000)
+    elif name in ("c4", "c4r"):
+        # c4r: the reset-heavy env of SURVEY 8(d) (an episode ends every 5 steps, so the
+        # carry reset inside the BPTT kernels is exercised on every replay)
+        inner = 5 if name == "c4r" else 1000
+        env = EpisodeWrapper(cartpole_shaped(max_steps=inner), 1000)
         net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], rngs)
-        desc = "CartpoleBalance-shaped, actor Dense-GRU(64)-Dense / critic 2x256"
+        desc = ("CartpoleBalance-shaped" + (", max_steps=5 (reset-heavy)" if name == "c4r" else "")
+                + ", actor Dense-GRU(64)-Dense / critic 2x256")
     else:
         raise SystemExit(f"unknown config {name}")
     ts = ppo.new_training_state(env, net, n_envs, SEED, 1e-4, device=device)
@@ -57,7 +61,7 @@ def main():
 
     mi_config.set_compute_dtype("bf16")
     device = torch.device("cuda", 0)
-    default_n = {"c2": 4096, "c3": 8192, "c4": 4096}
+    default_n = {"c2": 4096, "c3": 8192, "c4": 4096, "c4r": 4096}
     for spec in sys.argv[1:] or ["c2", "c3", "c4"]:
         name, _, n = spec.partition(":")
         n_envs = int(n) if n else default_n[name]
