@@ -522,6 +522,22 @@ int mi_episode_step_select(const int64_t* counter, const void* inner_done, int d
                            const int64_t* row_bytes, int64_t n_leaves, int64_t B,
                            mi_stream_t stream);
 
+/* mi_episode_step_select with the synthetic env's own step (mi_mock_env_step) inside the
+ * launch: inner done = mock_count + 1 >= mock_max_steps, and leaves marked in `produced`
+ * (1: float32 observation columns from produced_col0[l] of the env's flat draw; 2: the
+ * int64 step counter) are computed — stored to on_false[l] as the stepped state and
+ * selected against on_true[l] — instead of read.  envs/synthetic.py MockEnv under
+ * wrappers/episode_wrapper.py; bit-identical to the two launches it replaces. */
+int mi_mock_episode_step_select(
+    const int64_t* mock_key, const int64_t* mock_count, int64_t mock_max_steps,
+    const int64_t* produced, const int64_t* produced_col0, const int64_t* counter,
+    const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
+    uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out,
+    const int64_t* reset_counter, const uint8_t* reset_truncated, const float* reset_done,
+    int64_t* counter_sel, uint8_t* truncated_sel, float* done_sel, const void* const* on_true,
+    const int64_t* true_row_stride_bytes, const void* const* on_false, void* const* out,
+    const int64_t* row_bytes, int64_t n_leaves, int64_t B, mi_stream_t stream);
+
 /* Weights-stationary form of mi_mlp_fwd_bf16 for training sizes (csrc/trunk_ws.hip): one
  * workgroup per CU keeps the whole trunk in registers and loops over row tiles.  Shape
  * class (mi_mlp_ws_supported): dims = [K0 <= 32, H, ..., H, N_out <= 16] with

@@ -10,19 +10,14 @@
 // workload's size the iteration is launch-bound, not arithmetic-bound.
 // Integer work: bit-exact by construction (tests/test_keys_gpu.py).
 #include "common.h"
+#include "keys_common.h"
 
 namespace {
 
+using mippo_keys::kGolden;
+using mippo_keys::kM2;
+using mippo_keys::mix;
 constexpr int kThreads = 256;
-constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
-constexpr uint64_t kM1 = 0xBF58476D1CE4E5B9ull;
-constexpr uint64_t kM2 = 0x94D049BB133111EBull;
-
-__device__ inline uint64_t mix(uint64_t z) {
-  z = (z ^ (z >> 30)) * kM1;
-  z = (z ^ (z >> 27)) * kM2;
-  return z ^ (z >> 31);
-}
 
 enum { OUT_SPLIT = 0, OUT_BITS = 1, OUT_RANDINT = 2, OUT_UNIFORM = 3, OUT_UNIT_UNIFORM = 4 };
 
@@ -117,10 +112,7 @@ mock_env_step_kernel(const int64_t* __restrict__ key, const int64_t* __restrict_
       count_out[i] = step;
       done_out[i] = step >= max_steps ? 1 : 0;
     }
-    const uint64_t k = mix((uint64_t)key[i] ^ mix((uint64_t)step + kGolden));
-    const uint64_t b = mix(mix(k) ^ ((uint64_t)(j + 1) * kM2));
-    const float u = (float)(int64_t)(b >> 40) * (1.0f / 16777216.0f);
-    const float v = (u - 0.5f) * 3.4641016151377544f;
+    const float v = mippo_keys::mock_obs(key[i], step, j);
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       if (l < o.n_leaves) {

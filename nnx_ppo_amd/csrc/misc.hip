@@ -7,6 +7,7 @@
 // Both are dtype-agnostic (rows are moved as 4-byte words when the row size
 // allows, bytes otherwise) and therefore bit-exact by construction.
 #include "common.h"
+#include "keys_common.h"
 
 namespace {
 
@@ -50,6 +51,12 @@ struct SelectLeaf {
   int64_t true_stride;  // in words; 0 = broadcast one on_true row
   int64_t words;        // words per row
   int word_bytes;       // 4 or 1
+  // mi_episode_step_select with a producer: this leaf's on_false values are COMPUTED by the
+  // launch (and stored to on_false as the stepped state) instead of read.
+  //   1: float32 observation columns col0 .. col0 + words - 1 of the MockEnv draw
+  //   2: the int64 inner step counter (two 4-byte words per row)
+  int produced;
+  int col0;
 };
 constexpr int kMaxSelectLeaves = 16;
 struct SelectTable {
@@ -96,12 +103,18 @@ struct EpisodeArgs {
   int64_t* counter_sel;
   uint8_t* trunc_sel;
   float* done_sel;
+  // producer (MockEnv.step inside this launch; mock_key == nullptr: none): the inner env's
+  // step' = mock_count + 1, done = step' >= mock_max_steps, obs = mock_obs(key, step', j)
+  const int64_t* mock_key;
+  const int64_t* mock_count;
+  int64_t mock_max_steps;
 };
 
 __device__ inline void episode_row(const EpisodeArgs& e, int64_t b, int64_t& c, bool& t, bool& m) {
   c = e.counter[b] + 1;
-  const bool d = e.done_is_float ? static_cast<const float*>(e.inner_done)[b] != 0.0f
-                                 : static_cast<const uint8_t*>(e.inner_done)[b] != 0;
+  const bool d = e.mock_key ? e.mock_count[b] + 1 >= e.mock_max_steps
+                 : e.done_is_float ? static_cast<const float*>(e.inner_done)[b] != 0.0f
+                                   : static_cast<const uint8_t*>(e.inner_done)[b] != 0;
   t = (e.inner_trunc ? e.inner_trunc[b] != 0 : false) || c >= e.max_len;
   m = d || t;
 }
@@ -134,8 +147,18 @@ episode_select_kernel(EpisodeArgs e, SelectTable tab, int n_leaves, int64_t B) {
     episode_row(e, b, c, t, m);
     if (lf.word_bytes == 4) {
       const uint32_t* tt = static_cast<const uint32_t*>(lf.on_true);
-      const uint32_t* ff = static_cast<const uint32_t*>(lf.on_false);
-      static_cast<uint32_t*>(lf.out)[i] = m ? tt[b * lf.true_stride + w] : ff[i];
+      uint32_t fv;
+      if (lf.produced) {  // the inner env's own step: compute, keep as the stepped state
+        const int64_t step = e.mock_count[b] + 1;
+        if (lf.produced == 1)
+          fv = __float_as_uint(mippo_keys::mock_obs(e.mock_key[b], step, lf.col0 + (int)w));
+        else
+          fv = (uint32_t)((uint64_t)step >> (32 * (int)w));
+        static_cast<uint32_t*>(const_cast<void*>(lf.on_false))[i] = fv;
+      } else {
+        fv = static_cast<const uint32_t*>(lf.on_false)[i];
+      }
+      static_cast<uint32_t*>(lf.out)[i] = m ? tt[b * lf.true_stride + w] : fv;
     } else {
       const uint8_t* tt = static_cast<const uint8_t*>(lf.on_true);
       const uint8_t* ff = static_cast<const uint8_t*>(lf.on_false);
@@ -371,33 +394,38 @@ extern "C" int mi_copy_multi(const void* const* src, void* const* dst, const int
   return mippo::check_launch("mi_copy_multi");
 }
 
-extern "C" int mi_episode_step_select(
-    const int64_t* counter, const void* inner_done, int done_is_float,
+static int episode_step_select_launch(
+    const char* who, const int64_t* counter, const void* inner_done, int done_is_float,
     const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
     uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out,
     const int64_t* reset_counter, const uint8_t* reset_truncated, const float* reset_done,
     int64_t* counter_sel, uint8_t* truncated_sel, float* done_sel, const void* const* on_true,
     const int64_t* true_row_stride_bytes, const void* const* on_false, void* const* out,
-    const int64_t* row_bytes, int64_t n_leaves, int64_t B, mi_stream_t stream) {
+    const int64_t* row_bytes, int64_t n_leaves, int64_t B, const int64_t* mock_key,
+    const int64_t* mock_count, int64_t mock_max_steps, const int64_t* produced,
+    const int64_t* produced_col0, mi_stream_t stream) {
   MI_REQUIRE(n_leaves >= 0 && n_leaves <= kMaxSelectLeaves && B >= 0,
-             "mi_episode_step_select: 0 <= n_leaves <= %d", kMaxSelectLeaves);
+             "%s: 0 <= n_leaves <= %d", who, kMaxSelectLeaves);
   if (B == 0) return 0;
-  MI_REQUIRE(counter && inner_done && counter_out && truncated_out && done_out &&
+  MI_REQUIRE(counter && (inner_done || mock_key) && counter_out && truncated_out && done_out &&
                  reset_counter && reset_truncated && reset_done && counter_sel &&
                  truncated_sel && done_sel,
-             "mi_episode_step_select: null pointer");
+             "%s: null pointer", who);
+  MI_REQUIRE(!mock_key || (mock_count && produced && produced_col0),
+             "%s: the producer needs its step counter and the leaf kinds", who);
   MI_REQUIRE(n_leaves == 0 || (on_true && on_false && out && row_bytes && true_row_stride_bytes),
-             "mi_episode_step_select: null leaf table");
+             "%s: null leaf table", who);
   EpisodeArgs e = {counter,       inner_done,    inner_truncated, max_len,       done_is_float,
                    counter_out,   truncated_out, done_out,        done_flag_out, reset_counter,
-                   reset_truncated, reset_done,  counter_sel,     truncated_sel, done_sel};
+                   reset_truncated, reset_done,  counter_sel,     truncated_sel, done_sel,
+                   mock_key,      mock_count,    mock_max_steps};
   SelectTable tab = {};
   int64_t max_words = 1;
   for (int64_t l = 0; l < n_leaves; ++l) {
-    MI_REQUIRE(on_true[l] && on_false[l] && out[l] && row_bytes[l] >= 1,
-               "mi_episode_step_select: bad leaf %lld", (long long)l);
+    MI_REQUIRE(on_true[l] && on_false[l] && out[l] && row_bytes[l] >= 1, "%s: bad leaf %lld", who,
+               (long long)l);
     MI_REQUIRE(true_row_stride_bytes[l] == 0 || true_row_stride_bytes[l] == row_bytes[l],
-               "mi_episode_step_select: on_true stride must be 0 or row_bytes");
+               "%s: on_true stride must be 0 or row_bytes", who);
     const bool w4 = row_bytes[l] % 4 == 0 && aligned4(on_true[l]) && aligned4(on_false[l]) &&
                     aligned4(out[l]);
     SelectLeaf& lf = tab.leaf[l];
@@ -407,12 +435,59 @@ extern "C" int mi_episode_step_select(
     lf.word_bytes = w4 ? 4 : 1;
     lf.words = row_bytes[l] / lf.word_bytes;
     lf.true_stride = true_row_stride_bytes[l] / lf.word_bytes;
+    if (mock_key && produced[l]) {
+      MI_REQUIRE(w4 && (produced[l] == 1 || (produced[l] == 2 && row_bytes[l] == 8)) &&
+                     produced_col0[l] >= 0,
+                 "%s: produced leaf %lld must be float32 columns (1) or the int64 counter (2)",
+                 who, (long long)l);
+      lf.produced = (int)produced[l];
+      lf.col0 = (int)produced_col0[l];
+    }
     if (lf.words > max_words) max_words = lf.words;
   }
   dim3 grid((unsigned)stream_grid(B * max_words), (unsigned)n_leaves + 1);
   hipLaunchKernelGGL(episode_select_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream), e,
                      tab, (int)n_leaves, B);
-  return mippo::check_launch("mi_episode_step_select");
+  return mippo::check_launch(who);
+}
+
+extern "C" int mi_episode_step_select(
+    const int64_t* counter, const void* inner_done, int done_is_float,
+    const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
+    uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out,
+    const int64_t* reset_counter, const uint8_t* reset_truncated, const float* reset_done,
+    int64_t* counter_sel, uint8_t* truncated_sel, float* done_sel, const void* const* on_true,
+    const int64_t* true_row_stride_bytes, const void* const* on_false, void* const* out,
+    const int64_t* row_bytes, int64_t n_leaves, int64_t B, mi_stream_t stream) {
+  return episode_step_select_launch(
+      "mi_episode_step_select", counter, inner_done, done_is_float, inner_truncated, max_len,
+      counter_out, truncated_out, done_out, done_flag_out, reset_counter, reset_truncated,
+      reset_done, counter_sel, truncated_sel, done_sel, on_true, true_row_stride_bytes, on_false,
+      out, row_bytes, n_leaves, B, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// mi_episode_step_select with the synthetic env's own step (mi_mock_env_step) inside the
+// launch: the inner done flag is step' >= mock_max_steps with step' = mock_count + 1, and the
+// leaves marked in `produced` (1: float32 observation columns starting at produced_col0[l]
+// of the env's flat draw; 2: the int64 step counter) are computed — stored to on_false[l]
+// as the stepped state AND selected against on_true[l] — instead of read.  Bit-identical to
+// mi_mock_env_step followed by mi_episode_step_select.
+extern "C" int mi_mock_episode_step_select(
+    const int64_t* mock_key, const int64_t* mock_count, int64_t mock_max_steps,
+    const int64_t* produced, const int64_t* produced_col0, const int64_t* counter,
+    const uint8_t* inner_truncated, int64_t max_len, int64_t* counter_out,
+    uint8_t* truncated_out, float* done_out, uint8_t* done_flag_out,
+    const int64_t* reset_counter, const uint8_t* reset_truncated, const float* reset_done,
+    int64_t* counter_sel, uint8_t* truncated_sel, float* done_sel, const void* const* on_true,
+    const int64_t* true_row_stride_bytes, const void* const* on_false, void* const* out,
+    const int64_t* row_bytes, int64_t n_leaves, int64_t B, mi_stream_t stream) {
+  MI_REQUIRE(mock_key && mock_count, "mi_mock_episode_step_select: null producer");
+  return episode_step_select_launch(
+      "mi_mock_episode_step_select", counter, nullptr, 0, inner_truncated, max_len, counter_out,
+      truncated_out, done_out, done_flag_out, reset_counter, reset_truncated, reset_done,
+      counter_sel, truncated_sel, done_sel, on_true, true_row_stride_bytes, on_false, out,
+      row_bytes, n_leaves, B, mock_key, mock_count, mock_max_steps, produced, produced_col0,
+      stream);
 }
 
 extern "C" int mi_stack_multi(const void* const* src, void* const* dst, const int64_t* nbytes,

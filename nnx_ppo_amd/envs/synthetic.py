@@ -74,6 +74,40 @@ class MockEnv:
             done=done,
             metrics={}, info={})
 
+    def step_deferred(self, state: State, action: torch.Tensor):
+        """`step` for a wrapper that can run it inside its own launch
+        (`EpisodeWrapper.step_and_reset` -> `mi_mock_episode_step_select`).  Returns
+        (state, producer): with a producer the state's `step_count` / `obs` leaves are
+        allocated but NOT yet written and `done` is None — the wrapper's launch fills them
+        (`producer["leaves"]`: id(tensor) -> (kind, first column)); producer None: an
+        ordinary finished step."""
+        key = state.data["key"]
+        count = state.data["step_count"]
+        if not (count.is_cuda and count.dim() == 1 and not rnd._TORCH_ONLY[0]
+                and key.is_contiguous() and count.is_contiguous()):
+            return self.step(state, action), None
+        n, dev = count.shape[0], count.device
+        step = torch.empty_like(count)
+        leaves = {id(step): (2, 0)}
+        keep = [step]
+        if isinstance(self.obs_size, dict):
+            obs, col = {}, 0
+            for name in sorted(self.obs_size):
+                w = int(self.obs_size[name])
+                obs[name] = torch.empty(n, w, dtype=torch.float32, device=dev)
+                leaves[id(obs[name])] = (1, col)
+                keep.append(obs[name])
+                col += w
+        else:
+            obs = torch.empty(n, int(self.obs_size), dtype=torch.float32, device=dev)
+            leaves[id(obs)] = (1, 0)
+            keep.append(obs)
+        st = State(data={"key": key, "step_count": step}, obs=obs,
+                   reward=constant(step.shape, torch.float32, 1.0, dev), done=None,
+                   metrics={}, info={})
+        return st, {"key": key, "count": count, "max_steps": int(self.max_steps),
+                    "leaves": leaves, "keep": keep}
+
 
 def cartpole_shaped(max_steps: int = 1000) -> MockEnv:
     """CartpoleBalance-shaped workload: obs 5, action 1 (BASELINE configs 1/2/4/5)."""

@@ -1111,20 +1111,22 @@ def episode_step(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc, m
 
 def episode_step_select(counter: torch.Tensor, inner_done: torch.Tensor, inner_trunc,
                         max_len: int, reset_counter: torch.Tensor, reset_trunc: torch.Tensor,
-                        reset_done: torch.Tensor, pairs: list):
+                        reset_done: torch.Tensor, pairs: list, producer=None):
     """`episode_step` and the reset-on-done select of every (on_true, on_false) leaf of
     `pairs` (<= 16) in ONE launch (`mi_episode_step_select`).  Returns
-    (counter', truncated, done, done flag, selected counter / truncated / done, outs)."""
+    (counter', truncated, done, done flag, selected counter / truncated / done, outs).
+    `producer` (envs/synthetic.py: MockEnv.step_deferred): the inner env's step runs inside
+    the same launch (`mi_mock_episode_step_select`); `inner_done` is then unused."""
     B = counter.numel()
-    _need(counter.dtype == i64 and counter.dim() == 1 and inner_done.numel() == B,
-          "episode_step_select: shapes")
+    _need(counter.dtype == i64 and counter.dim() == 1
+          and (producer is not None or inner_done.numel() == B), "episode_step_select: shapes")
     _need(reset_counter.dtype == i64 and reset_trunc.dtype == torch.bool
           and reset_done.dtype == f32 and reset_counter.shape == counter.shape
           and reset_trunc.shape == counter.shape and reset_done.shape == counter.shape,
           "episode_step_select: reset leaves must be int64 / bool / float32 [B]")
     _need(len(pairs) <= 16, "episode_step_select: at most 16 leaves")
-    is_float = inner_done.dtype == f32
-    d_in = inner_done if is_float else _as_u8(inner_done)
+    is_float = producer is None and inner_done.dtype == f32
+    d_in = None if producer is not None else (inner_done if is_float else _as_u8(inner_done))
     t_in = None if inner_trunc is None else _as_u8(inner_trunc)
     dev = counter.device
     mk = lambda dt: torch.empty(counter.shape, dtype=dt, device=dev)
@@ -1148,12 +1150,28 @@ def episode_step_select(counter: torch.Tensor, inner_done: torch.Tensor, inner_t
             raise MippoError("episode_step_select: on_true must match on_false or be one row")
         out = torch.empty_like(on_false)
         outs.append(out)
+        kind, col0 = (0, 0) if producer is None else producer["leaves"].get(id(on_false), (0, 0))
         if row_bytes:
-            tab.append((ptr(v(on_true)), stride, ptr(v(on_false)), ptr(v(out)), row_bytes))
+            tab.append((ptr(v(on_true)), stride, ptr(v(on_false)), ptr(v(out)), row_bytes,
+                        kind, col0))
+        else:
+            _need(kind == 0, "episode_step_select: empty produced leaf")
     n = len(tab)
     P = ctypes.c_void_p * max(n, 1)
     L = ctypes.c_int64 * max(n, 1)
     col = lambda k: [r[k] for r in tab] or [None if k in (0, 2, 3) else 0]
+    if producer is not None:
+        _need(sum(1 for r in tab if r[5]) == len(producer["leaves"]),
+              "episode_step_select: a produced leaf is not among the selected leaves")
+        check(lib().mi_mock_episode_step_select(
+            ptr(producer["key"], i64), ptr(producer["count"], i64), int(producer["max_steps"]),
+            L(*col(5)), L(*col(6)), ptr(counter, i64), ptr(t_in), int(max_len), ptr(c_out, i64),
+            ptr(t_out.view(torch.uint8)), ptr(d_out, f32), ptr(f_out.view(torch.uint8)),
+            ptr(reset_counter, i64), ptr(reset_trunc.view(torch.uint8)), ptr(reset_done, f32),
+            ptr(c_sel, i64), ptr(t_sel.view(torch.uint8)), ptr(d_sel, f32),
+            P(*col(0)), L(*col(1)), P(*col(2)), P(*col(3)), L(*col(4)), n, B, stream()),
+            "mi_mock_episode_step_select")
+        return c_out, t_out, d_out, f_out, c_sel, t_sel, d_sel, outs
     check(lib().mi_episode_step_select(
         ptr(counter, i64), ptr(d_in), int(is_float), ptr(t_in), int(max_len), ptr(c_out, i64),
         ptr(t_out.view(torch.uint8)), ptr(d_out, f32), ptr(f_out.view(torch.uint8)),

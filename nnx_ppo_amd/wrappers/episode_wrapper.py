@@ -68,7 +68,11 @@ class EpisodeWrapper:
         from .. import ops
         from ..algorithms.rollout import collect_pairs, fill_slots
 
-        inner = self.env.step(state, action)
+        # an env that can hand its own step to this launch (MockEnv.step_deferred): no
+        # launch of its own
+        deferred = getattr(self.env, "step_deferred", None)
+        inner, producer = deferred(state, action) if deferred is not None \
+            else (self.env.step(state, action), None)
         prev = inner.info.get("truncated", None)
         prev = prev if isinstance(prev, torch.Tensor) else None
         marked_info = dict(inner.info)
@@ -78,10 +82,18 @@ class EpisodeWrapper:
         pairs, skeleton = collect_pairs(
             counter.shape[0], reset_states, marked,
             special=lambda x, y: y if isinstance(y, _Produced) else None)
+        if producer is not None and (len(pairs) > 16 or not all(
+                any(y is leaf for _, y in pairs) for leaf in producer["keep"])):
+            # the fused launch does not apply after all: the env steps by itself
+            inner, producer = self.env.step(state, action), None
+            marked = inner.replace(done=_DONE, info=marked_info)
+            pairs, skeleton = collect_pairs(
+                counter.shape[0], reset_states, marked,
+                special=lambda x, y: y if isinstance(y, _Produced) else None)
         if len(pairs) > 16:
             return self._finish_step(inner, state, prev), None
         c, t, d, flag, c_sel, t_sel, d_sel, outs = ops.episode_step_select(
-            counter, inner.done, prev, self.max_len, rc, rt, rd, pairs)
+            counter, inner.done, prev, self.max_len, rc, rt, rd, pairs, producer=producer)
         d.done_flag = flag
         info = dict(inner.info)
         info["step_counter"] = c

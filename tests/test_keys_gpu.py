@@ -256,3 +256,40 @@ def test_mock_env_step_one_launch_equals_host_statement(dev, obs_size):
         for a, b in zip(tree_leaves(s_gpu), tree_leaves(s_cpu)):
             assert a.dtype == b.dtype and torch.equal(a.cpu(), b), (a.dtype, b.dtype)
     assert bool(s_gpu.done.all())
+
+
+@pytest.mark.parametrize("obs_size", [5, {"position": 8, "velocity": 9}])
+def test_mock_env_step_inside_the_episode_launch(dev, obs_size):
+    """EpisodeWrapper(MockEnv).step_and_reset runs the env's own step inside the wrapper's
+    launch (mi_mock_episode_step_select): stepped state and state after the reset select
+    equal the two-launch path (mi_mock_env_step, then mi_episode_step_select) bit for bit,
+    across inner-env dones and wrapper truncations."""
+    from nnx_ppo_amd import _lib
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.tree import tree_leaves
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    n = 777
+    fused = EpisodeWrapper(MockEnv(obs_size, 2, max_steps=5), 7)
+    plain = EpisodeWrapper(MockEnv(obs_size, 2, max_steps=5), 7)
+    plain.env.step_deferred = None  # the env steps by itself
+    k = keys.split(keys.key(3, dev), n)
+    sa, sb = fused.reset(k), plain.reset(k)
+    seen_done = seen_trunc = False
+    for i in range(12):
+        ra, rb = fused.reset(keys.fold_in(k, i + 100)), plain.reset(keys.fold_in(k, i + 100))
+        with _lib.profiler as prof:
+            stepped_a, after_a = fused.step_and_reset(sa, None, ra)
+        assert [r[0] for r in prof.records] == ["mi_mock_episode_step_select"]
+        with _lib.profiler as prof:
+            stepped_b, after_b = plain.step_and_reset(sb, None, rb)
+        assert [r[0] for r in prof.records] == ["mi_mock_env_step", "mi_episode_step_select"]
+        for x, y in ((stepped_a, stepped_b), (after_a, after_b)):
+            la, lb = tree_leaves(x), tree_leaves(y)
+            assert len(la) == len(lb)
+            for a, b in zip(la, lb):
+                assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+        seen_done |= bool((stepped_a.done != 0).any())
+        seen_trunc |= bool(stepped_a.info["truncated"].any())
+        sa, sb = after_a, after_b
+    assert seen_done and seen_trunc
