@@ -9,6 +9,8 @@
 // expressions in ONE launch each instead of ~10 elementwise launches — at this
 // workload's size the iteration is launch-bound, not arithmetic-bound.
 // Integer work: bit-exact by construction (tests/test_keys_gpu.py).
+#include <stdlib.h>
+
 #include "common.h"
 #include "keys_common.h"
 
@@ -180,6 +182,64 @@ key_permutations_kernel(const int64_t* __restrict__ key, int64_t* __restrict__ o
   for (int i = threadIdx.x; i < n; i += kSortThreads) o[i] = hi[i];
 }
 
+// The same argsort by RANK: workgroup (x, e) recomputes permutation e's n hashes into LDS
+// and counts, for each of its 64 elements (one per lane), the (hash, index) pairs below it
+// — that count is the element's position.  The four waves take a quarter of the n
+// candidates each.  n^2 compares instead of n log^2 n exchanges, but every CU works
+// (n / 64 workgroups per permutation instead of one) and nothing waits on a barrier.
+// 64-bit integer compares are slow on the vector unit, so the loop compares the signed
+// high words only (one v_cmp + add-with-carry per candidate) and falls to the exact
+// (hash, index) order only when some lane sees equal high words.  Same total order, same
+// result as the bitonic network.
+constexpr int kRankElems = 64;
+__global__ void __launch_bounds__(kThreads)
+key_permutations_rank_kernel(const int64_t* __restrict__ key, int64_t* __restrict__ out, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sort_raw[];
+  int64_t* hk = reinterpret_cast<int64_t*>(sort_raw);  // [n rounded up to 64], pads = max
+  __shared__ int part[kThreads / 64][kRankElems];
+  const uint64_t ke = mix((uint64_t)key[0] ^ mix((uint64_t)blockIdx.y + kGolden));  // fold_in
+  const uint64_t mk = mix(ke);
+  const int n2 = (n + 63) & ~63;
+  for (int i = threadIdx.x; i < n2; i += kThreads)
+    hk[i] = i < n ? (int64_t)mix(mk ^ ((uint64_t)(i + 1) * kM2)) : INT64_MAX;  // random.bits
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * kRankElems + lane;
+  const int64_t h = hk[i < n2 ? i : 0];
+  const int hhi = (int)(h >> 32);
+  // this wave's candidates: chunks of 16, interleaved over the four waves
+  int rank = 0;
+  for (int j = wave * 16; j < n2; j += 16 * (kThreads / 64)) {
+    int64_t t[16];  // requested together (wave-broadcast LDS reads), then compared
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = hk[j + u];
+    unsigned nearest = 0xffffffffu;  // min over the candidates of (high word XOR mine)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int thi = (int)(t[u] >> 32);
+      rank += thi < hhi ? 1 : 0;
+      nearest = min(nearest, (unsigned)(thi ^ hhi));
+    }
+    if (__any(nearest == 0u)) {  // rare (and once per lane for the element itself): the exact order
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int thi = (int)(t[u] >> 32);
+        if (thi == hhi)
+          rank += ((uint32_t)t[u] < (uint32_t)h || ((uint32_t)t[u] == (uint32_t)h && j + u < i))
+                      ? 1 : 0;
+      }
+    }
+  }
+  part[wave][lane] = rank;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) r += part[w][lane];
+    out[(int64_t)blockIdx.y * n + r] = i;
+  }
+}
+
 int stream_grid(int64_t n) {
   int64_t g = mippo::ceil_div(n, kThreads);
   if (g > mippo::kMaxStreamBlocks) g = mippo::kMaxStreamBlocks;
@@ -255,6 +315,17 @@ extern "C" int mi_key_permutations(const int64_t* key, int64_t* out, int64_t n_p
              "mi_key_permutations: 0 <= n <= 8192 (n=%lld)", (long long)n);
   if (n_perm == 0 || n == 0) return 0;
   MI_REQUIRE(key && out, "mi_key_permutations: null pointer");
+  static const bool bitonic = [] {  // MIPPO_PERM_BITONIC=1: the one-workgroup network (A/B)
+    const char* e = getenv("MIPPO_PERM_BITONIC");
+    return e && e[0] == '1';
+  }();
+  if (!bitonic) {
+    const size_t bytes = (size_t)((n + 63) & ~(int64_t)63) * sizeof(int64_t);  // <= 64 KiB
+    hipLaunchKernelGGL(key_permutations_rank_kernel,
+                       dim3((unsigned)mippo::ceil_div(n, kRankElems), (unsigned)n_perm),
+                       dim3(kThreads), bytes, mippo::as_stream(stream), key, out, (int)n);
+    return mippo::check_launch("mi_key_permutations");
+  }
   int P = 2;
   while (P < n) P <<= 1;
   const size_t lds = (size_t)P * (sizeof(int64_t) + sizeof(int));
