@@ -210,7 +210,11 @@ def roofline_of_dominant_kernel(env, ts):
         c = trunk[dom]
         gbps = c["bytes"] / (c["ms"] * 1e-3) / 1e9
         tf = c["flops"] / (c["ms"] * 1e-3) / 1e12
-        t = traffic_db.get(dom)
+        # rocprofv3 names carry every template argument; the class names above only the
+        # tile shape: match on the common prefix
+        stem = dom.split(" pair")[0].rstrip(">")
+        t = traffic_db.get(dom) or next(
+            (v for k, v in traffic_db.items() if k.startswith(stem)), None)
         roof = {
             "bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
             "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5),
