@@ -556,6 +556,12 @@ int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* 
  * mi_policy_ws_supported: both trunks in the shape class of mi_mlp_ws_supported, 2A <= 16. */
 int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
                            const int64_t* c_dims, const int64_t* c_acts);
+/* At rollout / evaluation sizes (M + M_tail <= 8192 rows) mi_policy_ws_fwd_bf16 runs both
+ * trunks in ONE launch (value-trunk workgroups beside action-trunk workgroups, one 32-row
+ * tile each when the launch fits the chip) for the trunk pairs it is instantiated for;
+ * mi_policy_ws_dual_supported says whether a pair is one of them. */
+int mi_policy_ws_dual_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts,
+                                int64_t Lc, const int64_t* c_dims, const int64_t* c_acts);
 int mi_policy_ws_fwd_bf16(
     const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
     const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,

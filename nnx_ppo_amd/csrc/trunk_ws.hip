@@ -43,10 +43,11 @@ constexpr int WS_MAXL = 8;
 #ifdef MIPPO_TRACE
 constexpr int WST_EV = 32, WST_WG = 512;
 __device__ unsigned long long g_ws_trace[WST_WG * WST_EV];
+#define WS_TR_BLOCK blockIdx.x
 #define WS_TR()                                                                        \
   do {                                                                                 \
-    if (tid == 0 && ev_ < WST_EV && blockIdx.x < WST_WG)                               \
-      g_ws_trace[blockIdx.x * WST_EV + ev_] = __builtin_amdgcn_s_memtime();            \
+    if (tid == 0 && ev_ < WST_EV && WS_TR_BLOCK < WST_WG)                              \
+      g_ws_trace[WS_TR_BLOCK * WST_EV + ev_] = __builtin_amdgcn_s_memtime();           \
     ++ev_;                                                                             \
   } while (0)
 #else
@@ -102,9 +103,11 @@ constexpr int kWsThreads = 512;
 
 // SAMP: the trunk ends in the sampler (its own instantiations: the transcendental row
 // function does not belong in the register budget of the plain trunks).
+// The body is a device function of (chain, workgroup index, workgroup count) so that one
+// launch can run two trunks side by side (policy_ws_dual_kernel below); its LDS is
+// function-scope, i.e. allocated per kernel that reaches it.
 template <int H, int NH, int RT, bool SAMP>
-__global__ void __launch_bounds__(kWsThreads, 2)
-trunk_ws_fwd_kernel(WsChain c) {
+__device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, const int nblk) {
   static_assert(H == 64 || H == 128 || H == 256, "hidden width: 64, 128 or 256");
   using G = WsGeom<H>;
   constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
@@ -160,7 +163,7 @@ trunk_ws_fwd_kernel(WsChain c) {
     s_mean[tid] = c.norm_mean[tid];
     s_sd[tid] = cnt > 0.0f ? sqrtf(fmaxf(c.norm_m2[tid] / cnt, c.norm_eps)) : 10.0f;
   }
-  int64_t tile = blockIdx.x;
+  int64_t tile = bid;
   // the first input tile and layer 0's fragments go out FIRST: the (much larger) rest of the
   // trunk arrives while the first row tile's input stage and layer 0 run
   if (tile < ntiles) request_input(tile);
@@ -213,20 +216,20 @@ trunk_ws_fwd_kernel(WsChain c) {
   constexpr int kStashTilesMax = kWsThreads / ROWS;     // one row per thread at most
   __shared__ float ms_s[kStashFloats];
   constexpr bool has_samp = SAMP;
-  int64_t stash_first = 0;  // row tile of stash slot 0; slot q holds tile + q * gridDim.x
+  int64_t stash_first = 0;  // row tile of stash slot 0; slot q holds tile + q * nblk
   int stash_n = 0;
   int stash_cap = has_samp ? kStashFloats / (ROWS * N_out) : 1;
   if (stash_cap > kStashTilesMax) stash_cap = kStashTilesMax;
   auto run_sampler = [&]() {
     const int slot = tid / ROWS, row = tid % ROWS;
     if (SAMP && slot < stash_n) {
-      const int64_t gi = (stash_first + (int64_t)slot * gridDim.x) * ROWS + row;
+      const int64_t gi = (stash_first + (int64_t)slot * nblk) * ROWS + row;
       if (gi < M) mippo_sampler::fwd_row(ms_s + (slot * ROWS + row) * N_out, gi, c.samp);
     }
     __syncthreads();  // the stash is free again
   };
 
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += nblk) {
     const int64_t i0 = tile * ROWS;
     WS_TR();  // tile + 0
     // stage 0: the requested input tile -> bf16 in bufX
@@ -242,7 +245,7 @@ trunk_ws_fwd_kernel(WsChain c) {
       }
     }
     // the next row tile's input is in flight while this one is computed
-    if (tile + gridDim.x < ntiles) request_input(tile + gridDim.x);
+    if (tile + nblk < ntiles) request_input(tile + nblk);
     WS_TR();  // tile + 1: input staged
     __syncthreads();
     WS_TR();  // tile + 2
@@ -368,7 +371,7 @@ trunk_ws_fwd_kernel(WsChain c) {
     if (has_samp) {
       if (stash_n == 0) stash_first = tile;
       ++stash_n;
-      if (stash_n == stash_cap || tile + gridDim.x >= ntiles) {
+      if (stash_n == stash_cap || tile + nblk >= ntiles) {
         __syncthreads();  // the head's rows are in the stash
         run_sampler();
         stash_n = 0;
@@ -378,6 +381,28 @@ trunk_ws_fwd_kernel(WsChain c) {
     __syncthreads();  // bufA / bufB / bufX are free for the next row tile
     WS_TR();  // tile end
   }
+}
+
+template <int H, int NH, int RT, bool SAMP>
+__global__ void __launch_bounds__(kWsThreads, 2)
+trunk_ws_fwd_kernel(WsChain c) {
+  ws_fwd_body<H, NH, RT, SAMP>(c, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The policy step at rollout / evaluation sizes (M <= 8192 rows): BOTH trunks in one
+// launch, workgroups 0 .. n_value-1 the value trunk, the rest the action trunk + sampler,
+// one 16*RT-row tile each when the launch fits the chip.  The tile kernels
+// (mlp_bf16.hip) walk a trunk layer by layer with the weight fragments fetched from L2 one
+// 64-deep step ahead — at 16 rows per workgroup that is a chain of dependent L2 round
+// trips (~27 000 cycles for ~300 of MFMA); here all of a trunk's fragments are requested
+// at once, up front, and the layers run out of registers.
+template <int HV, int NHV, int HA, int NHA, int RT>
+__global__ void __launch_bounds__(kWsThreads, 2)
+policy_ws_dual_kernel(WsChain a, WsChain v, int n_value) {
+  if ((int)blockIdx.x < n_value)
+    ws_fwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value);
+  else
+    ws_fwd_body<HA, NHA, RT, true>(a, (int)blockIdx.x - n_value, (int)gridDim.x - n_value);
 }
 
 // ---- backward (dX chain) ------------------------------------------------------------------
@@ -852,6 +877,62 @@ extern "C" int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const i
          a_dims[0] == c_dims[0] && a_dims[La] % 2 == 0;
 }
 
+namespace {
+
+// (value trunk, action trunk) pairs the one-launch form is instantiated for: the equal-width
+// trunks `make_mlp_actor_critic` is usually called with, and BASELINE C2's 2x256 / 4x64.
+#define WS_DUAL_MENU(X) \
+  X(256, 1, 64, 3) X(256, 1, 64, 2) X(256, 1, 64, 1) X(256, 1, 256, 1) X(256, 0, 256, 0) \
+  X(128, 1, 128, 1) X(128, 2, 128, 2) X(128, 1, 64, 1) X(64, 1, 64, 1) X(64, 2, 64, 2)    \
+  X(64, 3, 64, 3)
+
+bool ws_dual_has(int64_t hv, int64_t nhv, int64_t ha, int64_t nha) {
+#define X(a, b, c, d) if (hv == a && nhv == b && ha == c && nha == d) return true;
+  WS_DUAL_MENU(X)
+#undef X
+  return false;
+}
+
+// Both trunks in one launch: 32-row tiles; when the tiles of both fit the chip every
+// workgroup has exactly one, otherwise the CUs are split in proportion to the tile counts.
+int ws_dual_launch(const WsChain& a, const WsChain& v, int64_t hv, int64_t nhv, int64_t ha,
+                   int64_t nha, hipStream_t st) {
+  constexpr int RT = 2;
+  MI_REQUIRE(16 * RT * a.N_out <= 4096, "mi_policy_ws_fwd_bf16: 2A = %d is too wide for the "
+             "sampler stash", a.N_out);
+  const int64_t tv = mippo::ceil_div(v.M, 16 * RT), ta = mippo::ceil_div(a.M, 16 * RT);
+  const int64_t cus = ws_grid(1 << 30);
+  int64_t nv = tv, na = ta;
+  if (tv + ta > cus) {
+    nv = cus * tv / (tv + ta);
+    if (nv < 1) nv = 1;
+    if (nv > cus - 1) nv = cus - 1;
+    na = cus - nv;
+    if (nv > tv) nv = tv;
+    if (na > ta) na = ta;
+  }
+#define X(p, q, r, s_)                                                                      \
+  if (hv == p && nhv == q && ha == r && nha == s_) {                                        \
+    hipLaunchKernelGGL((policy_ws_dual_kernel<p, q, r, s_, RT>), dim3((unsigned)(nv + na)), \
+                       dim3(kWsThreads), 0, st, a, v, (int)nv);                             \
+    return mippo::check_launch("mi_policy_ws_fwd_bf16(one launch)");                        \
+  }
+  WS_DUAL_MENU(X)
+#undef X
+  MI_REQUIRE(false, "mi_policy_ws_fwd_bf16: no one-launch instantiation for these trunks");
+}
+
+}  // namespace
+
+// 1 if mi_policy_ws_fwd_bf16 runs these two trunks as ONE launch at rollout sizes
+// (M + M_tail <= 8192 rows).
+extern "C" int mi_policy_ws_dual_supported(int64_t La, const int64_t* a_dims,
+                                           const int64_t* a_acts, int64_t Lc,
+                                           const int64_t* c_dims, const int64_t* c_acts) {
+  if (!mi_policy_ws_supported(La, a_dims, a_acts, Lc, c_dims, c_acts)) return 0;
+  return ws_dual_has(c_dims[1], Lc - 2, a_dims[1], La - 2) ? 1 : 0;
+}
+
 // mi_policy_fwd_bf16 on the weights-stationary kernels: the action trunk (normaliser in the
 // input stage, sampler on its head rows) and the value trunk (normaliser, bootstrap tail
 // rows) as two launches of trunk_ws_fwd_kernel.  Same arguments, same results bit for bit.
@@ -890,8 +971,6 @@ extern "C" int mi_policy_ws_fwd_bf16(
   a.norm_eps = norm_eps;
   a.samp = {extras, {rng_state, offset_add, eps, eps2}, raw_out, action, mu_out, sigma_out,
             loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
-  rc = ws_dispatch(a, a_dims[1], La - 2, st);
-  if (rc) return rc;
   WsChain v;
   rc = ws_fill(v, "mi_policy_ws_fwd_bf16(value)", obs, M + M_tail, Lc, c_w, c_bias, c_dims,
                c_acts, value, c_y_bf, c_x_bf);
@@ -902,5 +981,10 @@ extern "C" int mi_policy_ws_fwd_bf16(
   v.norm_m2 = norm_m2;
   v.norm_count = norm_count;
   v.norm_eps = norm_eps;
+  // rollout / evaluation sizes: one launch for both trunks; training sizes: one each
+  if (M + M_tail <= 8192 && ws_dual_has(c_dims[1], Lc - 2, a_dims[1], La - 2))
+    return ws_dual_launch(a, v, c_dims[1], Lc - 2, a_dims[1], La - 2, st);
+  rc = ws_dispatch(a, a_dims[1], La - 2, st);
+  if (rc) return rc;
   return ws_dispatch(v, c_dims[1], Lc - 2, st);
 }

@@ -37,6 +37,8 @@ WS_POLICY = os.environ.get("MIPPO_WS_POLICY", "1") != "0"
 # the weights-stationary backward measures no faster than policy_bwd_kernel (30.1 vs 29.4 us
 # at C2): off unless MIPPO_WS_POLICY_BWD=1
 WS_POLICY_BWD = os.environ.get("MIPPO_WS_POLICY_BWD", "0") == "1"
+# MIPPO_WS_ROLLOUT=0 keeps rollout / evaluation steps (<= 8192 rows) on the tile kernel
+WS_POLICY_ROLLOUT = os.environ.get("MIPPO_WS_ROLLOUT", "1") != "0"
 WS_MIN_ROWS = 8192
 
 
@@ -47,6 +49,13 @@ class MLPActorCritic(Sequential):
         assert isinstance(adapter, PPOAdapter) and len(self.layers) == 2
         self._norm = self.layers[0]
         self._adapter = adapter
+
+    def _ws_dual(self, a_dims, a_acts, c_dims, c_acts) -> bool:
+        key = (tuple(a_dims), tuple(a_acts), tuple(c_dims), tuple(c_acts))
+        cache = self.__dict__.setdefault("_ws_dual_cache", {})
+        if key not in cache:
+            cache[key] = ops.policy_ws_dual_supported(a_dims, a_acts, c_dims, c_acts)
+        return cache[key]
 
     # ---- pattern ---------------------------------------------------------------------
     def _parts(self):
@@ -101,8 +110,12 @@ class MLPActorCritic(Sequential):
         off = sampler._next_offset()
         ca, cc = chain(a_layers), chain(c_layers)
         rows = M + (0 if value_tail is None else value_tail.shape[0])
-        ws = (WS_POLICY and train and rows > WS_MIN_ROWS
-              and ops.policy_ws_supported(ca[2], ca[3], cc[2], cc[3]) and 2 * A <= 64)
+        if rows > WS_MIN_ROWS:  # training sizes: one weights-stationary launch per trunk
+            ws = (WS_POLICY and train and 2 * A <= 64
+                  and ops.policy_ws_supported(ca[2], ca[3], cc[2], cc[3]))
+        else:                   # rollout / evaluation sizes: both trunks in one such launch
+            ws = (WS_POLICY_ROLLOUT and 2 * A <= 64
+                  and self._ws_dual(ca[2], ca[3], cc[2], cc[3]))
         r = ops.policy_fwd_bf16(
             x2, norm, ca, cc, sampler._state(x2.device), off,
             deterministic=sampler.deterministic, extras=extras2, eps=eps, eps2=eps2,

@@ -543,6 +543,14 @@ def policy_ws_supported(a_dims: list, a_acts: list, c_dims: list, c_acts: list) 
                                              len(c_acts), i64s(c_dims), i64s(c_acts)))
 
 
+def policy_ws_dual_supported(a_dims: list, a_acts: list, c_dims: list, c_acts: list) -> bool:
+    """The weights-stationary policy step takes these two trunks as ONE launch at rollout
+    sizes (<= 8192 rows)."""
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    return bool(lib().mi_policy_ws_dual_supported(len(a_acts), i64s(a_dims), i64s(a_acts),
+                                                  len(c_acts), i64s(c_dims), i64s(c_acts)))
+
+
 def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_add: int, *,
                     min_std: float, std_scale: float, entropy_weight: float,
                     deterministic: bool, extras=None, eps=None, eps2=None, train: bool = False,
@@ -554,8 +562,10 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
     (per-layer (x_bf, aux_bf) as `mlp_fwd_bf16`).  `value_tail` [Mt, K0]: extra rows for
     the value trunk only (the bootstrap observation); `value` and the critic images then
     have M + Mt rows and `value_tail_out` is the view of the last Mt.  `ws`: the
-    weights-stationary kernels (`mi_policy_ws_fwd_bf16`; training sizes, trunks that
-    `policy_ws_supported` accepts) — same results bit for bit."""
+    weights-stationary kernels (`mi_policy_ws_fwd_bf16`: training sizes for trunks that
+    `policy_ws_supported` accepts — one launch per trunk; up to 8192 rows for pairs that
+    `policy_ws_dual_supported` accepts — both trunks in one launch) — same results bit for
+    bit."""
     M, K0 = obs.shape
     dev = obs.device
     (a_w, a_b, a_dims, a_acts), (c_w, c_b, c_dims, c_acts) = actor, critic
@@ -577,7 +587,7 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
         _need(value_tail.shape == (Mt, K0) and value_tail.is_contiguous(),
               "policy_fwd_bf16: value_tail must be a contiguous [Mt, K0]")
     value = mk(M + Mt, c_dims[-1])
-    ms = mk(M, A2) if train else None
+    ms = mk(M, A2) if (train or ws) else None  # the ws kernels always write the head's rows
 
     def images(L, dims, acts, rows):
         if not train:
@@ -607,8 +617,8 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
                    if t is not None)
         profiler.next_bytes = 4.0 * M * K0 + w_bytes + kept + outs
     if ws:
-        _need(train and ms is not None, "policy_fwd_bf16: the weights-stationary form is for "
-              "training launches")
+        _need(train or M + Mt <= 8192, "policy_fwd_bf16: without `train` the weights-stationary "
+              "form is the one-launch rollout step (<= 8192 rows)")
     entry = lib().mi_policy_ws_fwd_bf16 if ws else lib().mi_policy_fwd_bf16
     check(entry(
         ptr(obs, f32), M, ptr(n_mean, f32), ptr(n_m2, f32), ptr(n_cnt, f32), float(n_eps),

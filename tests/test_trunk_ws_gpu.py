@@ -112,6 +112,65 @@ def test_policy_ws_forward_bit_identical(dev, shape, M, Mt):
         assert torch.equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [128] * 2, [128] * 2),
+                                   (3, 2, [64] * 2, [64] * 2), (9, 3, [256] * 2, [256] * 2)])
+@pytest.mark.parametrize("M,Mt", [(4096, 0), (1, 0), (33, 5), (8000, 192), (2048, 0)])
+@pytest.mark.parametrize("train", [False, True])
+def test_policy_ws_one_launch_at_rollout_sizes(dev, shape, M, Mt, train):
+    """Up to 8192 rows mi_policy_ws_fwd_bf16 runs both trunks in ONE launch
+    (policy_ws_dual_kernel): sampled actions, raw draws, log-likelihoods, statistics and
+    values == mi_policy_fwd_bf16, bit for bit — sampling and replay, with and without the
+    kept images."""
+    from nnx_ppo_amd import _lib, ops
+
+    O, A, ah, ch = shape
+    a_dims, c_dims = [O] + ah + [2 * A], [O] + ch + [1]
+    a_w, a_b, a_acts = _trunk(dev, a_dims, seed=M)
+    c_w, c_b, c_acts = _trunk(dev, c_dims, seed=M + 1)
+    assert ops.policy_ws_dual_supported(a_dims, a_acts, c_dims, c_acts)
+    rng = np.random.default_rng(M + Mt)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    obs = t(rng.normal(1.0, 2.0, size=(M, O)))
+    tail = t(rng.normal(1.0, 2.0, size=(Mt, O))) if Mt else None
+    norm = (t(rng.normal(1.0, 0.5, size=O)), t(rng.uniform(50, 500, size=O)),
+            torch.tensor(100.0, device=dev), 1e-6)
+    rng_state = ops.make_rng_state(99, dev, 11)
+    actor, critic = (a_w, a_b, a_dims, a_acts), (c_w, c_b, c_dims, c_acts)
+    for extras in (None, t(rng.normal(size=(M, A)))):
+        for det in (False, True):
+            kw = dict(min_std=0.1, std_scale=1.0, entropy_weight=1e-2, deterministic=det,
+                      extras=extras, train=train, want_stats=True, value_tail=tail)
+            r0 = ops.policy_fwd_bf16(obs, norm, actor, critic, rng_state, 5, ws=False, **kw)
+            with _lib.profiler as prof:
+                r1 = ops.policy_fwd_bf16(obs, norm, actor, critic, rng_state, 5, ws=True, **kw)
+            assert [r[0] for r in prof.records] == ["mi_policy_ws_fwd_bf16"]
+            for k in ("raw", "action", "log_likelihood", "reg", "mu", "sigma", "value"):
+                if r0[k] is None:
+                    assert r1[k] is None or k == "action"
+                    continue
+                assert torch.equal(r0[k], r1[k]), (k, det, extras is None)
+            if Mt:
+                assert torch.equal(r0["value_tail_out"], r1["value_tail_out"])
+            if train:
+                assert torch.equal(r0["mean_and_std"], r1["mean_and_std"])
+                for name in ("actor_saved", "critic_saved"):
+                    for (xa, ya), (xb, yb) in zip(r0[name], r1[name]):
+                        assert torch.equal(xa, xb)
+                        assert (ya is None) == (yb is None) and (ya is None or torch.equal(ya, yb))
+
+
+def test_policy_ws_dual_menu(dev):
+    from nnx_ppo_amd import ops
+
+    R, N = ops.ACT_RELU, ops.ACT_NONE
+    ok = lambda a, c: ops.policy_ws_dual_supported(a, [R] * (len(a) - 2) + [N],
+                                                   c, [R] * (len(c) - 2) + [N])
+    assert ok([5, 64, 64, 64, 64, 2], [5, 256, 256, 1])       # BASELINE C2
+    assert ok([5, 128, 128, 4], [5, 128, 128, 1])
+    assert not ok([5, 64, 64, 64, 64, 2], [5, 128, 128, 1])   # not instantiated: tile kernel
+    assert not ok([5, 512, 2], [5, 256, 256, 1])              # outside the shape class
+
+
 def test_ppo_step_on_ws_kernels_equals_tile_kernels(dev):
     """A whole iteration at a training size with the loss replay on the weights-stationary
     kernels == the same iteration on the per-tile kernels."""
