@@ -160,12 +160,16 @@ def roofline_of_dominant_kernel(env, ts):
                 M = ints[0] if name == "mi_policy_fwd_bf16" else ints[1]  # (offset_add, M, ..)
                 shape = "1, 4, 1, 4" if M <= 8192 else ("16, 1, 4, 4" if narrow else "4, 4, 4, 4")
                 add(f"{kern}<{shape}>", t_ms, work)
-        if name in ("mi_policy_ws_fwd_bf16", "mi_policy_ws_bwd_bf16"):
-            # csrc/trunk_ws.hip: one C call = TWO launches of the weights-stationary kernel
-            # (action trunk + sampler, value trunk + bootstrap rows); bracketed as a pair
-            kern = "trunk_ws_fwd_kernel" if name == "mi_policy_ws_fwd_bf16" else "trunk_ws_bwd_kernel"
+        if name == "mi_policy_ws_fwd_bf16":
+            # csrc/trunk_ws.hip: both trunks in ONE launch (policy_ws_dual_kernel<HV, NHV, HA,
+            # NHA, RT>): 32-row tiles, one per workgroup, at rollout sizes; 64-row tiles with
+            # the CUs split between the trunks at replay sizes
             for (ints, t_ms), work in zip(d["args"], d["work"]):
-                add(f"{kern} pair (action<64,3,.> + value<256,1,.>)", t_ms, work)
+                rt = 2 if ints[0] <= 8192 else 4
+                add(f"policy_ws_dual_kernel<256, 1, 64, 3, {rt}>", t_ms, work)
+        if name == "mi_policy_ws_bwd_bf16":
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                add("trunk_ws_bwd_kernel pair (action<64,3,.> + value<256,1,.>)", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",
@@ -201,7 +205,7 @@ def roofline_of_dominant_kernel(env, ts):
         traffic_db = json.loads(pmc.read_text()).get("kernels", {})
     trunk = {k: v for k, v in classes.items()
              if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel",
-                              "trunk_ws_"))}
+                              "trunk_ws_", "policy_ws_"))}
     if trunk:
         # Dominant kernel = the trunk class with the most device time.  Its arithmetic
         # intensity (~100-150 flop/B with the activations kept for the backward) is below

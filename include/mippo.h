@@ -550,16 +550,17 @@ int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* 
                        const float* const* bias, const int64_t* dims, const int64_t* acts,
                        float* out, void* const* y_bf, void* x_bf, mi_stream_t stream);
 
-/* mi_policy_fwd_bf16 for training sizes on the weights-stationary kernels (two launches:
- * action trunk + sampler, value trunk + bootstrap tail rows): same arguments (mean_and_std
+/* mi_policy_fwd_bf16 on the weights-stationary kernels (action trunk + sampler, value
+ * trunk + bootstrap tail rows; one launch or two, see below): same arguments (mean_and_std
  * is required; the pre-activation arrays are unused: relu trunks), same results bit for bit.
  * mi_policy_ws_supported: both trunks in the shape class of mi_mlp_ws_supported, 2A <= 16. */
 int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
                            const int64_t* c_dims, const int64_t* c_acts);
-/* At rollout / evaluation sizes (M + M_tail <= 8192 rows) mi_policy_ws_fwd_bf16 runs both
- * trunks in ONE launch (value-trunk workgroups beside action-trunk workgroups, one 32-row
- * tile each when the launch fits the chip) for the trunk pairs it is instantiated for;
- * mi_policy_ws_dual_supported says whether a pair is one of them. */
+/* For the trunk pairs it is instantiated for, mi_policy_ws_fwd_bf16 runs both trunks in ONE
+ * launch (value-trunk workgroups beside action-trunk workgroups: one 32-row tile each when
+ * the launch fits the chip — rollout sizes — else the CUs are split between the trunks);
+ * mi_policy_ws_dual_supported says whether a pair is one of them.  Below 8192 rows only
+ * this form is used (the per-trunk launches pay off from ~2 tiles per CU). */
 int mi_policy_ws_dual_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts,
                                 int64_t Lc, const int64_t* c_dims, const int64_t* c_acts);
 int mi_policy_ws_fwd_bf16(

@@ -893,18 +893,24 @@ bool ws_dual_has(int64_t hv, int64_t nhv, int64_t ha, int64_t nha) {
   return false;
 }
 
-// Both trunks in one launch: 32-row tiles; when the tiles of both fit the chip every
-// workgroup has exactly one, otherwise the CUs are split in proportion to the tile counts.
-int ws_dual_launch(const WsChain& a, const WsChain& v, int64_t hv, int64_t nhv, int64_t ha,
-                   int64_t nha, hipStream_t st) {
-  constexpr int RT = 2;
+// Both trunks in one launch.  When the tiles of both fit the chip every workgroup has
+// exactly one (32-row tiles: rollout sizes); otherwise the CUs are split in proportion to
+// the tile counts (MIPPO_WS_DUAL_SPLIT = percent of the CUs for the value trunk: tuning aid)
+// and a workgroup walks its trunk's tiles (64-row tiles unless MIPPO_WS_DUAL_RT says 2).
+template <int RT>
+int ws_dual_launch_rt(const WsChain& a, const WsChain& v, int64_t hv, int64_t nhv, int64_t ha,
+                      int64_t nha, hipStream_t st) {
   MI_REQUIRE(16 * RT * a.N_out <= 4096, "mi_policy_ws_fwd_bf16: 2A = %d is too wide for the "
              "sampler stash", a.N_out);
   const int64_t tv = mippo::ceil_div(v.M, 16 * RT), ta = mippo::ceil_div(a.M, 16 * RT);
   const int64_t cus = ws_grid(1 << 30);
+  static const int split_pct = [] {
+    const char* e = getenv("MIPPO_WS_DUAL_SPLIT");
+    return e ? atoi(e) : 0;
+  }();
   int64_t nv = tv, na = ta;
   if (tv + ta > cus) {
-    nv = cus * tv / (tv + ta);
+    nv = split_pct > 0 ? cus * split_pct / 100 : cus * tv / (tv + ta);
     if (nv < 1) nv = 1;
     if (nv > cus - 1) nv = cus - 1;
     na = cus - nv;
@@ -922,10 +928,23 @@ int ws_dual_launch(const WsChain& a, const WsChain& v, int64_t hv, int64_t nhv, 
   MI_REQUIRE(false, "mi_policy_ws_fwd_bf16: no one-launch instantiation for these trunks");
 }
 
+int ws_dual_launch(const WsChain& a, const WsChain& v, int64_t hv, int64_t nhv, int64_t ha,
+                   int64_t nha, hipStream_t st) {
+  static const int rt_override = [] {
+    const char* e = getenv("MIPPO_WS_DUAL_RT");
+    return e ? atoi(e) : 0;
+  }();
+  const int64_t cus = ws_grid(1 << 30);
+  const bool one_each = mippo::ceil_div(v.M, 32) + mippo::ceil_div(a.M, 32) <= cus;
+  const int rt = rt_override == 2 || rt_override == 4 ? rt_override : (one_each ? 2 : 4);
+  if (rt == 2 || 64 * a.N_out > 4096) return ws_dual_launch_rt<2>(a, v, hv, nhv, ha, nha, st);
+  return ws_dual_launch_rt<4>(a, v, hv, nhv, ha, nha, st);
+}
+
 }  // namespace
 
-// 1 if mi_policy_ws_fwd_bf16 runs these two trunks as ONE launch at rollout sizes
-// (M + M_tail <= 8192 rows).
+// 1 if mi_policy_ws_fwd_bf16 runs these two trunks as ONE launch (at any size; required
+// below 8192 rows, where the one-launch-per-trunk form is not used).
 extern "C" int mi_policy_ws_dual_supported(int64_t La, const int64_t* a_dims,
                                            const int64_t* a_acts, int64_t Lc,
                                            const int64_t* c_dims, const int64_t* c_acts) {
@@ -935,7 +954,9 @@ extern "C" int mi_policy_ws_dual_supported(int64_t La, const int64_t* a_dims,
 
 // mi_policy_fwd_bf16 on the weights-stationary kernels: the action trunk (normaliser in the
 // input stage, sampler on its head rows) and the value trunk (normaliser, bootstrap tail
-// rows) as two launches of trunk_ws_fwd_kernel.  Same arguments, same results bit for bit.
+// rows) — one launch with the CUs shared between the trunks for the instantiated pairs
+// (policy_ws_dual_kernel), else two launches of trunk_ws_fwd_kernel.  Same arguments, same
+// results bit for bit.
 extern "C" int mi_policy_ws_fwd_bf16(
     const float* obs, int64_t M, const float* norm_mean, const float* norm_m2,
     const float* norm_count, float norm_eps, int64_t La, const void* const* a_w,
@@ -981,8 +1002,15 @@ extern "C" int mi_policy_ws_fwd_bf16(
   v.norm_m2 = norm_m2;
   v.norm_count = norm_count;
   v.norm_eps = norm_eps;
-  // rollout / evaluation sizes: one launch for both trunks; training sizes: one each
-  if (M + M_tail <= 8192 && ws_dual_has(c_dims[1], Lc - 2, a_dims[1], La - 2))
+  // one launch for both trunks whenever the pair is instantiated (measured at C2's replay,
+  // 31 744 + 30 720 rows: 2.24 -> 2.15 ms per iteration against one launch per trunk — the
+  // second prologue, launch and tail run beside the other trunk's tiles);
+  // MIPPO_WS_DUAL_MAX_ROWS caps it (A/B)
+  static const int64_t dual_max_rows = [] {
+    const char* e = getenv("MIPPO_WS_DUAL_MAX_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)1 << 40;
+  }();
+  if (M + M_tail <= dual_max_rows && ws_dual_has(c_dims[1], Lc - 2, a_dims[1], La - 2))
     return ws_dual_launch(a, v, c_dims[1], Lc - 2, a_dims[1], La - 2, st);
   rc = ws_dispatch(a, a_dims[1], La - 2, st);
   if (rc) return rc;
