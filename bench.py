@@ -169,7 +169,7 @@ def roofline_of_dominant_kernel(env, ts):
                 add(f"policy_ws_dual_kernel<256, 1, 64, 3, {rt}>", t_ms, work)
         if name == "mi_policy_ws_bwd_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
-                add("trunk_ws_bwd_kernel pair (action<64,3,.> + value<256,1,.>)", t_ms, work)
+                add("policy_ws_bwd_dual_kernel<256, 1, 64, 3, 4>", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",

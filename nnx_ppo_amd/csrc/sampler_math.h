@@ -72,7 +72,7 @@ struct FwdParams {
 };
 
 // `row`: the 2A floats (mean | pre-softplus std) of batch row b.
-__device__ inline void fwd_row(const float* row, int64_t b, const FwdParams& p) {
+__device__ __forceinline__ void fwd_row(const float* row, int64_t b, const FwdParams& p) {
   const int A = p.A;
   float ll_acc = 0.0f, h_acc = 0.0f;
   for (int a = 0; a < A; ++a) {
@@ -117,7 +117,7 @@ struct BwdParams {
 // Gradient w.r.t. the 2A inputs of row b, written to grow[0..2A) through `store`
 // (fp32 global row in the stand-alone kernel, bf16 LDS row in the fused backward).
 template <typename Store>
-__device__ inline void bwd_row(int64_t b, const BwdParams& p, Store store) {
+__device__ __forceinline__ void bwd_row(int64_t b, const BwdParams& p, Store store) {
   const int A = p.A;
   const float* row = p.ms + b * 2 * A;
   const float gl = p.g_ll ? p.g_ll[b] : 0.0f;

@@ -106,8 +106,23 @@ constexpr int kWsThreads = 512;
 // The body is a device function of (chain, workgroup index, workgroup count) so that one
 // launch can run two trunks side by side (policy_ws_dual_kernel below); its LDS is
 // function-scope, i.e. allocated per kernel that reaches it.
+// LDS of one forward body (carved out of the kernel's one array, so a two-trunk launch
+// needs the larger of the two, not their sum)
+template <int H, int RT, bool SAMP>
+struct WsFwdLds {
+  static constexpr size_t kRows = 16 * RT;
+  static constexpr size_t bufX = 0;
+  static constexpr size_t bufA = bufX + kRows * (32 + 8) * 2;
+  static constexpr size_t bufB = bufA + kRows * (H + 8) * 2;
+  static constexpr size_t mean = bufB + kRows * (H + 8) * 2;
+  static constexpr size_t sd = mean + 32 * 4;
+  static constexpr size_t stash = sd + 32 * 4;
+  static constexpr size_t bytes = stash + (SAMP ? 4096 : 4) * 4;
+};
+
 template <int H, int NH, int RT, bool SAMP>
-__device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, const int nblk) {
+__device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, const int nblk,
+                                            unsigned char* smem) {
   static_assert(H == 64 || H == 128 || H == 256, "hidden width: 64, 128 or 256");
   using G = WsGeom<H>;
   constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
@@ -117,9 +132,10 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
   constexpr int KSH = H / 32;   // k-steps of an H-deep reduce
   constexpr int AROW = H + 8;   // LDS row (bf16): 16 bytes of padding
   constexpr int XROW = 32 + 8;  // input tile row: K0 <= 32 columns
-  __shared__ __attribute__((aligned(16))) bf16_t bufX[ROWS * XROW];
-  __shared__ __attribute__((aligned(16))) bf16_t bufA[ROWS * AROW];
-  __shared__ __attribute__((aligned(16))) bf16_t bufB[ROWS * AROW];
+  using Lds = WsFwdLds<H, RT, SAMP>;
+  bf16_t* const bufX = reinterpret_cast<bf16_t*>(smem + Lds::bufX);  // [ROWS][XROW]
+  bf16_t* const bufA = reinterpret_cast<bf16_t*>(smem + Lds::bufA);  // [ROWS][AROW]
+  bf16_t* const bufB = reinterpret_cast<bf16_t*>(smem + Lds::bufB);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,7 +172,8 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
   };
   // normaliser statistics of the K0 input columns, once (same fp32 expressions as
   // normalize_fwd_kernel / the input stage of mlp_bf16.hip)
-  __shared__ float s_mean[32], s_sd[32];
+  float* const s_mean = reinterpret_cast<float*>(smem + Lds::mean);  // [32]
+  float* const s_sd = reinterpret_cast<float*>(smem + Lds::sd);
   const bool norm = c.norm_mean != nullptr;
   if (norm && tid < K0) {
     const float cnt = *c.norm_count;
@@ -214,7 +231,7 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
   // once (up to 512 rows: every thread busy), not once per 64-row tile.
   constexpr int kStashFloats = SAMP ? 4096 : 4;         // 16 KB
   constexpr int kStashTilesMax = kWsThreads / ROWS;     // one row per thread at most
-  __shared__ float ms_s[kStashFloats];
+  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);  // [kStashFloats]
   constexpr bool has_samp = SAMP;
   int64_t stash_first = 0;  // row tile of stash slot 0; slot q holds tile + q * nblk
   int stash_n = 0;
@@ -386,7 +403,8 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
 template <int H, int NH, int RT, bool SAMP>
 __global__ void __launch_bounds__(kWsThreads, 2)
 trunk_ws_fwd_kernel(WsChain c) {
-  ws_fwd_body<H, NH, RT, SAMP>(c, (int)blockIdx.x, (int)gridDim.x);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WsFwdLds<H, RT, SAMP>::bytes];
+  ws_fwd_body<H, NH, RT, SAMP>(c, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // The policy step at rollout / evaluation sizes (M <= 8192 rows): BOTH trunks in one
@@ -399,10 +417,13 @@ trunk_ws_fwd_kernel(WsChain c) {
 template <int HV, int NHV, int HA, int NHA, int RT>
 __global__ void __launch_bounds__(kWsThreads, 2)
 policy_ws_dual_kernel(WsChain a, WsChain v, int n_value) {
+  constexpr size_t nv = WsFwdLds<HV, RT, false>::bytes, na = WsFwdLds<HA, RT, true>::bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[nv > na ? nv : na];
   if ((int)blockIdx.x < n_value)
-    ws_fwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value);
+    ws_fwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value, smem);
   else
-    ws_fwd_body<HA, NHA, RT, true>(a, (int)blockIdx.x - n_value, (int)gridDim.x - n_value);
+    ws_fwd_body<HA, NHA, RT, true>(a, (int)blockIdx.x - n_value, (int)gridDim.x - n_value,
+                                   smem);
 }
 
 // ---- backward (dX chain) ------------------------------------------------------------------
@@ -428,9 +449,19 @@ struct WsBwdChain {
   mippo_sampler::BwdParams sbwd;  // sbwd.A == 0: gradient comes from g_out
 };
 
+template <int H, int RT, bool SAMP>
+struct WsBwdLds {
+  static constexpr size_t kRows = 16 * RT;
+  static constexpr size_t kStashTiles = SAMP ? kWsThreads / kRows : 1;
+  static constexpr size_t bufX = 0;
+  static constexpr size_t bufA = bufX + kStashTiles * kRows * (32 + 8) * 2;
+  static constexpr size_t bufB = bufA + kRows * (H + 8) * 2;
+  static constexpr size_t bytes = bufB + kRows * (H + 8) * 2;
+};
+
 template <int H, int NH, int RT, bool SAMP>
-__global__ void __launch_bounds__(kWsThreads, 2)
-trunk_ws_bwd_kernel(WsBwdChain c) {
+__device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, const int nblk,
+                                            unsigned char* smem) {
   using G = WsGeom<H>;
   constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
   constexpr int RTW = RT / RW;
@@ -439,9 +470,10 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
   constexpr int AROW = H + 8;
   constexpr int XROW = 32 + 8;
   constexpr int kStashTiles = SAMP ? kWsThreads / ROWS : 1;  // one row per thread
-  __shared__ __attribute__((aligned(16))) bf16_t bufX[kStashTiles * ROWS * XROW];
-  __shared__ __attribute__((aligned(16))) bf16_t bufA[ROWS * AROW];
-  __shared__ __attribute__((aligned(16))) bf16_t bufB[ROWS * AROW];
+  using Lds = WsBwdLds<H, RT, SAMP>;
+  bf16_t* const bufX = reinterpret_cast<bf16_t*>(smem + Lds::bufX);  // [kStashTiles][ROWS][XROW]
+  bf16_t* const bufA = reinterpret_cast<bf16_t*>(smem + Lds::bufA);  // [ROWS][AROW]
+  bf16_t* const bufB = reinterpret_cast<bf16_t*>(smem + Lds::bufB);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -483,10 +515,10 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
     }
   };
 
-  int64_t tile = blockIdx.x;
+  int64_t tile = bid;
   int stash_n = 0, stash_i = 0;  // SAMP: head-gradient rows of `stash_n` row tiles wait in bufX
   if (tile < ntiles) request_input(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += nblk) {
     const int64_t i0 = tile * ROWS;
     const bf16_t* xin = bufX;
     if constexpr (SAMP) {
@@ -495,7 +527,7 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
       // this workgroup's row tiles are produced at once
       if (stash_i == stash_n) {
         const int slot = tid / ROWS, row = tid % ROWS;
-        const int64_t t = tile + (int64_t)slot * gridDim.x;
+        const int64_t t = tile + (int64_t)slot * nblk;
         if (t < ntiles) {
           bf16_t* dst = bufX + (slot * ROWS + row) * XROW;
           const int64_t gi = t * ROWS + row;
@@ -507,7 +539,7 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
         }
         stash_n = 0;
         for (int q = 0; q < kStashTiles; ++q)
-          if (tile + (int64_t)q * gridDim.x < ntiles) ++stash_n;
+          if (tile + (int64_t)q * nblk < ntiles) ++stash_n;
         stash_i = 0;
       }
       xin = bufX + stash_i * ROWS * XROW;
@@ -521,7 +553,7 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
           bufX[row * XROW + (e - row * N_out)] = (bf16_t)gin[u];
         }
       }
-      if (tile + gridDim.x < ntiles) request_input(tile + gridDim.x);
+      if (tile + nblk < ntiles) request_input(tile + nblk);
     }
     // relu' operands of this row tile: 8 bytes per (row, column tile), requested now
     s16x4 auxr[NH + 1][RTW][TPW];
@@ -628,6 +660,27 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
   }
 }
 
+template <int H, int NH, int RT, bool SAMP>
+__global__ void __launch_bounds__(kWsThreads, 2)
+trunk_ws_bwd_kernel(WsBwdChain c) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WsBwdLds<H, RT, SAMP>::bytes];
+  ws_bwd_body<H, NH, RT, SAMP>(c, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+// Sampler backward + both dX chains in one launch: workgroups 0 .. n_value-1 the value
+// trunk, the rest the action trunk (the CUs split between them as in policy_ws_dual_kernel).
+template <int HV, int NHV, int HA, int NHA, int RT>
+__global__ void __launch_bounds__(kWsThreads, 2)
+policy_ws_bwd_dual_kernel(WsBwdChain a, WsBwdChain v, int n_value) {
+  constexpr size_t nv = WsBwdLds<HV, RT, false>::bytes, na = WsBwdLds<HA, RT, true>::bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[nv > na ? nv : na];
+  if ((int)blockIdx.x < n_value)
+    ws_bwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value, smem);
+  else
+    ws_bwd_body<HA, NHA, RT, true>(a, (int)blockIdx.x - n_value, (int)gridDim.x - n_value,
+                                   smem);
+}
+
 int ws_grid(int64_t ntiles) {
   static const int cus = [] {
     int dev = 0, cu = 0;
@@ -640,6 +693,20 @@ int ws_grid(int64_t ntiles) {
     return cu;
   }();
   return (int)(ntiles < cus ? ntiles : cus);
+}
+
+// (value trunk, action trunk) pairs the one-launch form is instantiated for: the equal-width
+// trunks `make_mlp_actor_critic` is usually called with, and BASELINE C2's 2x256 / 4x64.
+#define WS_DUAL_MENU(X) \
+  X(256, 1, 64, 3) X(256, 1, 64, 2) X(256, 1, 64, 1) X(256, 1, 256, 1) X(256, 0, 256, 0) \
+  X(128, 1, 128, 1) X(128, 2, 128, 2) X(128, 1, 64, 1) X(64, 1, 64, 1) X(64, 2, 64, 2)    \
+  X(64, 3, 64, 3)
+
+bool ws_dual_has(int64_t hv, int64_t nhv, int64_t ha, int64_t nha) {
+#define X(a, b, c, d) if (hv == a && nhv == b && ha == c && nha == d) return true;
+  WS_DUAL_MENU(X)
+#undef X
+  return false;
 }
 
 template <int H, int NH, int RT>
@@ -837,6 +904,46 @@ extern "C" int mi_mlp_ws_bwd_dx_bf16(const float* g_out, int64_t M, int64_t L,
 
 // mi_policy_bwd_bf16 on the weights-stationary kernels: the action trunk's transposed chain
 // fed by the sampler backward, and the value trunk's fed by g_value — two launches.
+namespace {
+
+// The CUs of a two-trunk launch, split in proportion to the tile counts (all of them when
+// both trunks' tiles fit the chip).  MIPPO_WS_DUAL_SPLIT = percent for the value trunk.
+void ws_dual_split(int64_t tv, int64_t ta, int64_t* nv, int64_t* na) {
+  static const int split_pct = [] {
+    const char* e = getenv("MIPPO_WS_DUAL_SPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  const int64_t cus = ws_grid(1 << 30);
+  *nv = tv;
+  *na = ta;
+  if (tv + ta > cus) {
+    *nv = split_pct > 0 ? cus * split_pct / 100 : cus * tv / (tv + ta);
+    if (*nv < 1) *nv = 1;
+    if (*nv > cus - 1) *nv = cus - 1;
+    *na = cus - *nv;
+    if (*nv > tv) *nv = tv;
+    if (*na > ta) *na = ta;
+  }
+}
+
+template <int RT>
+int ws_bwd_dual_launch_rt(const WsBwdChain& a, const WsBwdChain& v, int64_t hv, int64_t nhv,
+                          int64_t ha, int64_t nha, hipStream_t st) {
+  int64_t nv, na;
+  ws_dual_split(mippo::ceil_div(v.M, 16 * RT), mippo::ceil_div(a.M, 16 * RT), &nv, &na);
+#define X(p, q, r, s_)                                                                       \
+  if (hv == p && nhv == q && ha == r && nha == s_) {                                         \
+    hipLaunchKernelGGL((policy_ws_bwd_dual_kernel<p, q, r, s_, RT>),                         \
+                       dim3((unsigned)(nv + na)), dim3(kWsThreads), 0, st, a, v, (int)nv);   \
+    return mippo::check_launch("mi_policy_ws_bwd_bf16(one launch)");                         \
+  }
+  WS_DUAL_MENU(X)
+#undef X
+  MI_REQUIRE(false, "mi_policy_ws_bwd_bf16: no one-launch instantiation for these trunks");
+}
+
+}  // namespace
+
 extern "C" int mi_policy_ws_bwd_bf16(
     const float* mean_and_std, const float* extras, const uint64_t* rng_state,
     uint64_t offset_add, const float* eps2, const float* g_loglik, float g_reg, float min_std,
@@ -860,11 +967,20 @@ extern "C" int mi_policy_ws_bwd_bf16(
   const int64_t A2 = a_dims[La];
   a.sbwd = {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
             (int)(A2 / 2), min_std, std_scale, entropy_weight};
-  rc = ws_bwd_dispatch(a, a_dims[1], La - 2, st);
-  if (rc) return rc;
   WsBwdChain v;
   rc = ws_bwd_fill(v, "mi_policy_ws_bwd_bf16(value)", g_value, M, Lc, c_w, c_dims, c_acts, c_aux,
                    c_dz_last, c_dz_bf);
+  if (rc) return rc;
+  static const bool two_launches = [] {  // MIPPO_WS_BWD_DUAL=0: one launch per trunk (A/B)
+    const char* e = getenv("MIPPO_WS_BWD_DUAL");
+    return e && e[0] == '0';
+  }();
+  if (!two_launches && ws_dual_has(c_dims[1], Lc - 2, a_dims[1], La - 2)) {
+    const bool one_each = 2 * mippo::ceil_div(M, 32) <= ws_grid(1 << 30);
+    return one_each ? ws_bwd_dual_launch_rt<2>(a, v, c_dims[1], Lc - 2, a_dims[1], La - 2, st)
+                    : ws_bwd_dual_launch_rt<4>(a, v, c_dims[1], Lc - 2, a_dims[1], La - 2, st);
+  }
+  rc = ws_bwd_dispatch(a, a_dims[1], La - 2, st);
   if (rc) return rc;
   return ws_bwd_dispatch(v, c_dims[1], Lc - 2, st);
 }
@@ -879,20 +995,6 @@ extern "C" int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const i
 
 namespace {
 
-// (value trunk, action trunk) pairs the one-launch form is instantiated for: the equal-width
-// trunks `make_mlp_actor_critic` is usually called with, and BASELINE C2's 2x256 / 4x64.
-#define WS_DUAL_MENU(X) \
-  X(256, 1, 64, 3) X(256, 1, 64, 2) X(256, 1, 64, 1) X(256, 1, 256, 1) X(256, 0, 256, 0) \
-  X(128, 1, 128, 1) X(128, 2, 128, 2) X(128, 1, 64, 1) X(64, 1, 64, 1) X(64, 2, 64, 2)    \
-  X(64, 3, 64, 3)
-
-bool ws_dual_has(int64_t hv, int64_t nhv, int64_t ha, int64_t nha) {
-#define X(a, b, c, d) if (hv == a && nhv == b && ha == c && nha == d) return true;
-  WS_DUAL_MENU(X)
-#undef X
-  return false;
-}
-
 // Both trunks in one launch.  When the tiles of both fit the chip every workgroup has
 // exactly one (32-row tiles: rollout sizes); otherwise the CUs are split in proportion to
 // the tile counts (MIPPO_WS_DUAL_SPLIT = percent of the CUs for the value trunk: tuning aid)
@@ -902,21 +1004,8 @@ int ws_dual_launch_rt(const WsChain& a, const WsChain& v, int64_t hv, int64_t nh
                       int64_t nha, hipStream_t st) {
   MI_REQUIRE(16 * RT * a.N_out <= 4096, "mi_policy_ws_fwd_bf16: 2A = %d is too wide for the "
              "sampler stash", a.N_out);
-  const int64_t tv = mippo::ceil_div(v.M, 16 * RT), ta = mippo::ceil_div(a.M, 16 * RT);
-  const int64_t cus = ws_grid(1 << 30);
-  static const int split_pct = [] {
-    const char* e = getenv("MIPPO_WS_DUAL_SPLIT");
-    return e ? atoi(e) : 0;
-  }();
-  int64_t nv = tv, na = ta;
-  if (tv + ta > cus) {
-    nv = split_pct > 0 ? cus * split_pct / 100 : cus * tv / (tv + ta);
-    if (nv < 1) nv = 1;
-    if (nv > cus - 1) nv = cus - 1;
-    na = cus - nv;
-    if (nv > tv) nv = tv;
-    if (na > ta) na = ta;
-  }
+  int64_t nv, na;
+  ws_dual_split(mippo::ceil_div(v.M, 16 * RT), mippo::ceil_div(a.M, 16 * RT), &nv, &na);
 #define X(p, q, r, s_)                                                                      \
   if (hv == p && nhv == q && ha == r && nha == s_) {                                        \
     hipLaunchKernelGGL((policy_ws_dual_kernel<p, q, r, s_, RT>), dim3((unsigned)(nv + na)), \

@@ -34,9 +34,9 @@ FUSED = os.environ.get("MIPPO_FUSED_POLICY", "1") != "0"
 # default a training-size replay of trunks in their shape class runs on the
 # weights-stationary kernels (csrc/trunk_ws.hip) — same results bit for bit
 WS_POLICY = os.environ.get("MIPPO_WS_POLICY", "1") != "0"
-# the weights-stationary backward measures no faster than policy_bwd_kernel (30.1 vs 29.4 us
-# at C2): off unless MIPPO_WS_POLICY_BWD=1
-WS_POLICY_BWD = os.environ.get("MIPPO_WS_POLICY_BWD", "0") == "1"
+# the weights-stationary backward (both trunks in one launch) measures ~1 % of an iteration
+# better than policy_bwd_kernel at C2 (2.105 vs 2.125 ms); MIPPO_WS_POLICY_BWD=0 for the latter
+WS_POLICY_BWD = os.environ.get("MIPPO_WS_POLICY_BWD", "1") != "0"
 # MIPPO_WS_ROLLOUT=0 keeps rollout / evaluation steps (<= 8192 rows) on the tile kernel
 WS_POLICY_ROLLOUT = os.environ.get("MIPPO_WS_ROLLOUT", "1") != "0"
 WS_MIN_ROWS = 8192

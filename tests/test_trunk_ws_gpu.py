@@ -193,7 +193,7 @@ def test_ppo_step_on_ws_kernels_equals_tile_kernels(dev):
                     ts, m = ppo.ppo_step(env, ts, 2048, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
                 outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()}))
             finally:
-                policy.WS_POLICY, policy.WS_POLICY_BWD = True, False
+                policy.WS_POLICY, policy.WS_POLICY_BWD = True, True
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
 
