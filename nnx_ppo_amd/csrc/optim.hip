@@ -74,8 +74,9 @@ adam_kernel(mippo_optim::AdamArgs a) {
       if (a.slabs.n) gi = gi + mippo_optim::slab_sum(a, i, pass_begin);
     }
   };
+  const mippo_optim::AdamScalars sc = mippo_optim::adam_read_scalars(a);  // in flight too
   fetch();
-  const mippo_optim::AdamStep st = mippo_optim::adam_begin(a);
+  const mippo_optim::AdamStep st = mippo_optim::adam_begin(a, sc);
   while (pass_begin < a.n) {
     if (i < a.n) mippo_optim::adam_element(a, st, i, pass_begin, gi, m0, v0, p0);
     pass_begin += (int64_t)gridDim.x * kThreads;

@@ -70,16 +70,29 @@ __device__ inline int64_t frag_index(int c, int r, int R) {
 // READ `step`, and the block whose signal arrives last — at which point nobody will read
 // the old value again — publishes step + 1 and re-arms the ticket (adam_end).  Nothing else
 // is ordered by that counter, so there is no fence and no spin.
-__device__ inline AdamStep adam_begin(const AdamArgs& a) {
+// The two scalar reads of adam_begin on their own, so that a kernel can issue them before
+// its element loads (they are one more memory round trip otherwise).
+struct AdamScalars {
+  int64_t s0;
+  float gn;
+};
+__device__ inline AdamScalars adam_read_scalars(const AdamArgs& a) {
+  AdamScalars r;
+  r.s0 = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r.gn = a.grad_norm ? *a.grad_norm : 1.0f;
+  return r;
+}
+
+__device__ inline AdamStep adam_begin(const AdamArgs& a, const AdamScalars& sc) {
   AdamStep st;
-  st.s0 = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  st.s0 = sc.s0;
   const float t = (float)(a.ticket ? st.s0 + 1 : st.s0);
   st.bc1 = 1.0f - powf(a.b1, t);
   st.bc2 = 1.0f - powf(a.b2, t);
   st.clip = false;
   st.gn = 1.0f;
   if (a.grad_norm) {
-    st.gn = *a.grad_norm;
+    st.gn = sc.gn;
     st.clip = !(st.gn < a.max_norm);
   }
   st.arrival = 0;
@@ -89,6 +102,10 @@ __device__ inline AdamStep adam_begin(const AdamArgs& a) {
       st.arrival = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return st;
+}
+
+__device__ inline AdamStep adam_begin(const AdamArgs& a) {
+  return adam_begin(a, adam_read_scalars(a));
 }
 
 // Sum over the pending dW slabs that cover arena element i (0 if none): the fixed

@@ -358,39 +358,77 @@ def dense_bwd_dw_bf16(x_bf, dz_bf, g_w, g_b, accumulate: bool = True) -> None:
 
 
 class _SlabDefer:
-    """The reduction of a grouped dW launch's split-M slabs can ride on the optimiser
-    launch (`mi_adam_step_slabs_f32`) instead of its own.  `Optimizer.begin(defer_dw=True)`
-    turns it on for one gradient step: the LAST grouped dW call of the step then leaves its
-    slabs pending, and `Optimizer.update` either folds them into the Adam launch or — when
-    something reads the gradients first (norm, all-reduce) — reduces them with
-    `flush_pending_slabs`.  Off by default: `.grad` is complete after every backward.
-    Only gradients that live inside `arena` (the optimiser's gradient arena) defer."""
+    """Deferred weight gradients of one gradient step.  `Optimizer.begin(defer_dw=True)`
+    opens it (the training loops): every grouped dW request whose gradients live in the
+    optimiser's arena is QUEUED instead of launched, so that at `Optimizer.update` the dW /
+    db of every layer of the network — whatever module asked for them — go out as ONE
+    grouped launch per 8 problems (a Dense-GRU-Dense actor beside an MLP critic is five
+    requests of 1-3 layers), and the split-M slabs of the last one are summed inside the
+    Adam launch (`mi_adam_step_slabs_f32`) instead of by their own reduction launch.
+    Anything that reads the gradients first (norm, all-reduce) calls
+    `flush_pending_slabs`, which launches and reduces everything.  Off by default:
+    `.grad` is complete after every backward."""
     arena = None    # float32 [n] while a deferring gradient step is open
-    pending = None  # (slab_ptrs, S, Ks, Ns, g_w, g_b, gw_off, gb_off, workspace)
+    queue: list = []   # (x_bf, dz_bf, g_w, g_b, gw_off, gb_off) not yet launched
+    pending = None  # (slab_ptrs, S, Ks, Ns, g_w, g_b, gw_off, gb_off, workspace): launched,
+    #                 slabs not yet reduced
 
-    def offsets(self, g_w, g_b, Ks, Ns):
-        """Arena offsets of the gradients, or None if one lies outside the arena."""
+    def offsets(self, g_w, g_b, K, N):
+        """Arena offsets of a problem's gradients, or None if one lies outside the arena."""
         if self.arena is None:
             return None
         base, n = self.arena.data_ptr(), self.arena.numel()
-        gw_off, gb_off = [], []
-        for w, b, K, N in zip(g_w, g_b, Ks, Ns):
-            ow = (w.data_ptr() - base) // 4
-            ob = -1 if b is None else (b.data_ptr() - base) // 4
-            if not (w.is_contiguous() and 0 <= ow and ow + K * N <= n):
-                return None
-            if b is not None and not (b.is_contiguous() and 0 <= ob and ob + N <= n):
-                return None
-            gw_off.append(ow)
-            gb_off.append(ob)
-        return gw_off, gb_off
+        ow = (g_w.data_ptr() - base) // 4
+        ob = -1 if g_b is None else (g_b.data_ptr() - base) // 4
+        if not (g_w.is_contiguous() and 0 <= ow and ow + K * N <= n):
+            return None
+        if g_b is not None and not (g_b.is_contiguous() and 0 <= ob and ob + N <= n):
+            return None
+        return ow, ob
 
 
 slab_defer = _SlabDefer()
 
 
-def flush_pending_slabs() -> None:
-    """Reduce the pending slabs (if any) into their gradients now."""
+def _dw_group(grp: list, accumulate: bool, fold) -> None:
+    """One grouped dW launch of <= 8 problems sharing M.  `fold` = [(gw_off, gb_off)] per
+    problem: leave the slabs pending for the optimiser launch instead of reducing them."""
+    n = len(grp)
+    M = grp[0][0].shape[0]
+    Ks = [g[2].shape[0] for g in grp]
+    Ns = [g[2].shape[1] for g in grp]
+    for (x_bf, dz_bf, g_w, g_b), K, N in zip(grp, Ks, Ns):
+        _need(x_bf.shape == (M, pad8(K)) and dz_bf.shape == (M, pad8(N)),
+              "dense_bwd_dw_grouped_bf16: operands must be [M, pad8(K)] / [M, pad8(N)]")
+    P = ctypes.c_void_p * n
+    I = ctypes.c_int64 * n
+    Kc, Nc = I(*Ks), I(*Ns)
+    nbytes = lib().mi_dense_bwd_dw_grouped_bf16_workspace_bytes(n, Kc, Nc, M)
+    _need(nbytes >= 0, "mi_dense_bwd_dw_grouped_bf16_workspace_bytes failed")
+    _reduce_pending()  # the slabs of a pending launch live in the same workspace
+    ws = workspace(grp[0][2].device, "dense_dw_grouped", nbytes)
+    if profiler.active:
+        profiler.next_flops = 2.0 * M * sum(K * N for K, N in zip(Ks, Ns))
+        # operands once + fp32 gradients read-modify-written
+        profiler.next_bytes = (sum((g[0].numel() + g[1].numel()) * 2.0 for g in grp)
+                               + sum(8.0 * (K * N + N) for K, N in zip(Ks, Ns)))
+    xs = P(*[ptr(g[0], bf16) for g in grp])
+    dzs = P(*[ptr(g[1], bf16) for g in grp])
+    if fold is not None:
+        sp, S = P(), I()
+        check(lib().mi_dense_bwd_dw_grouped_slabs_bf16(n, xs, dzs, Kc, Nc, M, ptr(ws), sp, S,
+                                                       stream()),
+              "mi_dense_bwd_dw_grouped_slabs_bf16")
+        slab_defer.pending = (list(sp), list(S), Ks, Ns, [g[2] for g in grp],
+                              [g[3] for g in grp], [o[0] for o in fold],
+                              [o[1] for o in fold], ws)
+        return
+    check(lib().mi_dense_bwd_dw_grouped_bf16(
+        n, xs, dzs, P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]),
+        Kc, Nc, M, ptr(ws), int(bool(accumulate)), stream()), "mi_dense_bwd_dw_grouped_bf16")
+
+
+def _reduce_pending() -> None:
     pend, slab_defer.pending = slab_defer.pending, None
     if pend is None:
         return
@@ -403,51 +441,77 @@ def flush_pending_slabs() -> None:
         P(*[ptr(t, f32) for t in g_b]), 1, stream()), "mi_reduce_slabs_grouped_f32")
 
 
+def _run_queue(fold_last: bool) -> None:
+    """Launch the queued problems: grouped by M (request order kept), 8 per launch; with
+    `fold_last` the final launch leaves its slabs pending."""
+    q, slab_defer.queue = slab_defer.queue, []
+    if not q:
+        return
+    by_m: dict = {}
+    for pr in q:
+        by_m.setdefault(pr[0].shape[0], []).append(pr)
+    groups = [g[i:i + 8] for g in by_m.values() for i in range(0, len(g), 8)]
+    for gi, grp in enumerate(groups):
+        last = fold_last and gi == len(groups) - 1
+        _dw_group([pr[:4] for pr in grp], True, [pr[4:6] for pr in grp] if last else None)
+
+
+def flush_pending_slabs() -> None:
+    """Launch every queued dW request and reduce every pending slab now: after this the
+    gradients are complete."""
+    _run_queue(fold_last=False)
+    _reduce_pending()
+
+
 def take_pending_slabs():
+    """The optimiser is about to run: launch the queue, the last launch's slabs (if any)
+    are handed to it unreduced."""
+    _run_queue(fold_last=True)
     pend, slab_defer.pending = slab_defer.pending, None
     return pend
 
 
+def _dw_tiles(K: int, N: int) -> int:
+    """Output tiles of one dW problem (csrc/gemm_bf16.hip: 128 x {128, 64, 16})."""
+    tn = 128 if N > 64 else (64 if N > 16 else 16)
+    return -(-K // 128) * -(-N // tn)
+
+
+# A grouped launch splits M so that (tiles x splits) fills one resident wave of workgroups
+# (~416).  Small requests (a few tiles: launch-bound) gain from sharing a launch; past ~26
+# tiles the shared launch has too few splits to keep the chip busy (measured at C3:
+# 4x256 + 2x512 trunks in one launch 14.5 ms / iteration against 12.6 ms as two), so
+# requests are queued only while the queue stays under this many tiles — and only requests of
+# at most half that: a big request launched at once overlaps the other branch of a
+# two-stream backward (networks/adapter.py), which the queue would serialise.
+_DW_QUEUE_TILES = 26
+_DW_REQUEST_TILES = 13
+
+
 def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
     """dW / db of several layers that share M: `problems` = [(x_bf, dz_bf, g_w, g_b)]."""
+    tiles = sum(_dw_tiles(g_w.shape[0], g_w.shape[1]) for _, _, g_w, _ in problems)
+    queued = sum(_dw_tiles(pr[2].shape[0], pr[2].shape[1]) for pr in slab_defer.queue)
+    if (accumulate and slab_defer.arena is not None and tiles <= _DW_REQUEST_TILES
+            and tiles + queued <= _DW_QUEUE_TILES):
+        offs = [slab_defer.offsets(g_w, g_b, g_w.shape[0], g_w.shape[1])
+                for _, _, g_w, g_b in problems]
+        if all(o is not None for o in offs):
+            # one gradient twice in a launch would race in the slab reduction (weight
+            # sharing): what is queued goes out first
+            seen = {pr[2].data_ptr() for pr in slab_defer.queue}
+            mine = [pr[2].data_ptr() for pr in problems]
+            if len(set(mine)) < len(mine):
+                offs = None
+            elif seen & set(mine):
+                _run_queue(fold_last=False)
+            if offs is not None:
+                slab_defer.queue.extend((x, dz, g_w, g_b, o[0], o[1])
+                                        for (x, dz, g_w, g_b), o in zip(problems, offs))
+                return
+    flush_pending_slabs()
     for i in range(0, len(problems), 8):
-        grp = problems[i:i + 8]
-        n = len(grp)
-        M = grp[0][0].shape[0]
-        Ks = [g[2].shape[0] for g in grp]
-        Ns = [g[2].shape[1] for g in grp]
-        for (x_bf, dz_bf, g_w, g_b), K, N in zip(grp, Ks, Ns):
-            _need(x_bf.shape == (M, pad8(K)) and dz_bf.shape == (M, pad8(N)),
-                  "dense_bwd_dw_grouped_bf16: operands must be [M, pad8(K)] / [M, pad8(N)]")
-        P = ctypes.c_void_p * n
-        I = ctypes.c_int64 * n
-        Kc, Nc = I(*Ks), I(*Ns)
-        nbytes = lib().mi_dense_bwd_dw_grouped_bf16_workspace_bytes(n, Kc, Nc, M)
-        _need(nbytes >= 0, "mi_dense_bwd_dw_grouped_bf16_workspace_bytes failed")
-        # the slabs of a pending launch live in the same workspace
-        flush_pending_slabs()
-        ws = workspace(grp[0][2].device, "dense_dw_grouped", nbytes)
-        if profiler.active:
-            profiler.next_flops = 2.0 * M * sum(K * N for K, N in zip(Ks, Ns))
-            # operands once + fp32 gradients read-modify-written
-            profiler.next_bytes = (sum((g[0].numel() + g[1].numel()) * 2.0 for g in grp)
-                                   + sum(8.0 * (K * N + N) for K, N in zip(Ks, Ns)))
-        xs = P(*[ptr(g[0], bf16) for g in grp])
-        dzs = P(*[ptr(g[1], bf16) for g in grp])
-        offs = None
-        if accumulate and i + 8 >= len(problems):
-            offs = slab_defer.offsets([g[2] for g in grp], [g[3] for g in grp], Ks, Ns)
-        if offs is not None:
-            sp, S = P(), I()
-            check(lib().mi_dense_bwd_dw_grouped_slabs_bf16(n, xs, dzs, Kc, Nc, M, ptr(ws), sp, S,
-                                                           stream()),
-                  "mi_dense_bwd_dw_grouped_slabs_bf16")
-            slab_defer.pending = (list(sp), list(S), Ks, Ns, [g[2] for g in grp],
-                                  [g[3] for g in grp], offs[0], offs[1], ws)
-            continue
-        check(lib().mi_dense_bwd_dw_grouped_bf16(
-            n, xs, dzs, P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]),
-            Kc, Nc, M, ptr(ws), int(bool(accumulate)), stream()), "mi_dense_bwd_dw_grouped_bf16")
+        _dw_group(problems[i:i + 8], accumulate, None)
 
 
 def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,

@@ -297,11 +297,11 @@ def test_grouped_dw_matches_per_layer(dev):
 
 @pytest.mark.parametrize("M", [40, 3000, 61440])
 @pytest.mark.parametrize("clip", [None, 0.5])
-def test_dw_slabs_reduced_inside_adam_are_bit_identical(dev, M, clip):
-    """`mi_adam_step_slabs_f32` sums the split-M slabs of a grouped dW launch while it reads
-    the gradient arena; parameters, moments, bf16 images and the zeroed gradient must equal
-    `mi_reduce_slabs_grouped_f32` followed by `mi_adam_step_f32` bit for bit (same
-    summation order).  Through the optimiser: `begin(defer_dw=True)` vs `begin()`."""
+def test_deferred_dw_requests_go_out_as_one_launch_and_reduce_inside_adam(dev, M, clip):
+    """`Optimizer.begin(defer_dw=True)`: the dW requests of a gradient step are queued and go
+    out as one grouped launch at `update()`, whose split-M slabs `mi_adam_step_slabs_f32`
+    sums while it reads the gradient arena.  Against `begin()` (every request launched and
+    reduced at once): same parameters, moments and bf16 images, gradient left zeroed."""
     from nnx_ppo_amd import ops, optim
     from nnx_ppo_amd.networks import factories
     from nnx_ppo_amd.networks.types import Rngs
@@ -324,25 +324,36 @@ def test_dw_slabs_reduced_inside_adam_are_bit_identical(dev, M, clip):
             x = ops.cast_pad_bf16(torch.as_tensor(g.normal(size=(M, K)).astype(np.float32)).to(dev))
             dz = ops.cast_pad_bf16(torch.as_tensor(g.normal(size=(M, N)).astype(np.float32)).to(dev) * 1e-2)
             problems.append((x, dz, w.grad, bias.grad if bias is not None else None))
-        ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
-        assert (ops.slab_defer.pending is not None) == defer
+        # two requests (as two modules would make them): queued, not launched, when deferring
+        ops.dense_bwd_dw_grouped_bf16(problems[:2], accumulate=True)
+        ops.dense_bwd_dw_grouped_bf16(problems[2:], accumulate=True)
+        assert (len(ops.slab_defer.queue) == len(problems)) == defer
+        assert ops.slab_defer.pending is None
         if clip is not None:
             opt.compute_grad_norm()  # flushes: a whole-gradient reader
-            assert ops.slab_defer.pending is None
+            assert ops.slab_defer.pending is None and not ops.slab_defer.queue
             opt.update(have_norm=True)
         else:
             opt.update()
         assert ops.slab_defer.pending is None and ops.slab_defer.arena is None
+        assert not ops.slab_defer.queue
         torch.cuda.synchronize()
         assert float(opt.grads.abs().max()) == 0.0
         from nnx_ppo_amd.networks import dense_chain
         results.append((opt.params.clone(), opt.m.clone(), opt.v.clone(),
                         [l._w_bf.clone() for l, _ in dense_chain.shadows_in(opt.params)]))
     a, b = results
-    for x, y in zip(a[:3], b[:3]):
-        assert torch.equal(x, y)
+    # (the non-deferring run makes two launches of 2 + 3 problems, the deferring one a single
+    # launch of 5: the split-M plan differs, so equality is to fp32 summation order here;
+    # bit-identity of the in-Adam reduction itself is the e2e test of test_train_loop_gpu)
+    for x, y in zip(a[1:3], b[1:3]):  # moments: smooth in the gradient
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-6)
+    # a first Adam step moves every parameter by ~ lr * sign(g): an element whose gradient
+    # is within round-off of zero may land one step apart, nothing else may differ
+    dp = (a[0] - b[0]).abs()
+    assert float(dp.max()) <= 2.1e-3 and float((dp > 1e-6).float().mean()) < 1e-3
     for x, y in zip(a[3], b[3]):
-        assert torch.equal(x, y)
+        assert torch.allclose(x.float(), y.float(), rtol=1e-2, atol=1e-3)
     assert float((a[1] != 0).float().mean()) > 0.5
 
 
