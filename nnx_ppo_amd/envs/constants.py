@@ -13,6 +13,7 @@ import torch
 
 _cache: dict = {}
 _ids: dict = {}
+_zero_ids: dict = {}
 
 
 def constant(shape, dtype, value, device) -> torch.Tensor:
@@ -22,7 +23,14 @@ def constant(shape, dtype, value, device) -> torch.Tensor:
         t = torch.full(tuple(shape), value, dtype=dtype, device=device)
         _cache[key] = t
         _ids[id(t)] = t
+        if value == 0:
+            _zero_ids[id(t)] = t
     return t
+
+
+def is_zero_constant(t) -> bool:
+    """True for an all-zero tensor handed out by `constant` (identity, not value)."""
+    return isinstance(t, torch.Tensor) and _zero_ids.get(id(t)) is t
 
 
 def is_constant(t) -> bool:

@@ -23,6 +23,7 @@ from typing import Any
 import torch
 
 from .. import ops
+from ..envs.constants import constant
 from . import initializers
 from .types import Parameter, Rngs, StatefulModule, StatefulModuleOutput
 
@@ -84,7 +85,7 @@ class GRU(StatefulModule):
                                          None, train=False, mfma=self._mfma())
         h = h_out[0]
         return StatefulModuleOutput(next_state=h, output=h,
-                                    regularization_loss=torch.zeros(B, device=x.device),
+                                    regularization_loss=constant((B,), torch.float32, 0.0, x.device),
                                     metrics={}, rollout_extras=None)
 
     def initialize_state(self, batch_size: int) -> torch.Tensor:
@@ -92,7 +93,8 @@ class GRU(StatefulModule):
                            device=self.device)
 
     def reset_state(self, prev_state: torch.Tensor) -> torch.Tensor:
-        return torch.zeros_like(prev_state)
+        # read-only cached zeros: the rollout only selects from a reset state
+        return constant(prev_state.shape, prev_state.dtype, 0.0, prev_state.device)
 
     # ---- training protocol --------------------------------------------------------
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
@@ -268,7 +270,7 @@ class LSTM(StatefulModule):
                                                     c.contiguous(), None, train=False,
                                                     mfma=mfma, **kw)
         return StatefulModuleOutput(next_state=(h_f, c_f), output=h_out[0],
-                                    regularization_loss=torch.zeros(B, device=x.device),
+                                    regularization_loss=constant((B,), torch.float32, 0.0, x.device),
                                     metrics={}, rollout_extras=None)
 
     def initialize_state(self, batch_size: int):
@@ -283,7 +285,8 @@ class LSTM(StatefulModule):
         if self.trainable_initial_state:  # recurrent.py:154-158
             return (self.initial_h.data.expand(prev_state[0].shape).contiguous(),
                     self.initial_c.data.expand(prev_state[1].shape).contiguous())
-        return (torch.zeros_like(prev_state[0]), torch.zeros_like(prev_state[1]))
+        z = lambda t: constant(t.shape, t.dtype, 0.0, t.device)  # read-only cached zeros
+        return (z(prev_state[0]), z(prev_state[1]))
 
     # ---- training protocol --------------------------------------------------------
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):

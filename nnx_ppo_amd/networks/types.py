@@ -281,10 +281,19 @@ def zero_scalar(device) -> torch.Tensor:
 
 
 def add_reg(a, b):
-    """a + b where either may be the cached zero scalar or None."""
+    """a + b where either may be None, the cached zero scalar, or a cached all-zero
+    constant (`envs.constants.constant`, e.g. the `[B]` zeros a recurrent layer returns,
+    `recurrent.py:114`): those cost no launch — the other operand is returned when the sum
+    would have its shape."""
+    from ..envs.constants import is_zero_constant
+
     if b is None or any(b is z for z in _ZERO_SCALARS.values()):
         return a
     if a is None or any(a is z for z in _ZERO_SCALARS.values()):
+        return b
+    if is_zero_constant(b) and (a.shape == b.shape or b.dim() == 0):
+        return a
+    if is_zero_constant(a) and (a.shape == b.shape or a.dim() == 0):
         return b
     return a + b
 

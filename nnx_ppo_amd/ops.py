@@ -509,7 +509,13 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
                 slab_defer.queue.extend((x, dz, g_w, g_b, o[0], o[1])
                                         for (x, dz, g_w, g_b), o in zip(problems, offs))
                 return
-    flush_pending_slabs()
+    # launched now; what is queued stays queued unless it shares a gradient with this request
+    # (the order of the additions into one gradient is then kept)
+    mine = {pr[2].data_ptr() for pr in problems} | {pr[3].data_ptr() for pr in problems
+                                                   if pr[3] is not None}
+    if any(pr[2].data_ptr() in mine or (pr[3] is not None and pr[3].data_ptr() in mine)
+           for pr in slab_defer.queue):
+        _run_queue(fold_last=False)
     for i in range(0, len(problems), 8):
         _dw_group(problems[i:i + 8], accumulate, None)
 
