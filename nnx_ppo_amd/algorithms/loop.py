@@ -187,6 +187,19 @@ def should_run(steps: int, last_step: int, every_steps: int) -> bool:
     return (steps // every_steps) > (last_step // every_steps)
 
 
+def health_check(device) -> None:
+    """Raise if a bounded in-kernel wait has run out since the last check: a peer that never
+    delivered its chunks to a one-shot exchange (`comm.PeerComm.check`).  Reads device
+    words (it synchronises), so the loop calls it where it is synchronised anyway — eval,
+    checkpoint, the end of training."""
+    from .. import parallel
+
+    del device
+    comm = parallel.peer_comm()
+    if comm is not None:
+        comm.check()
+
+
 def run_training_loop(
     runner: IterationRunner,
     *,
@@ -245,6 +258,8 @@ def run_training_loop(
         if ckpt_due:
             checkpoint_fn(runner.state, steps)
             last_checkpoint_step = steps
+        if eval_due or ckpt_due or not more:
+            health_check(runner.device)
         if log_fn is not None:
             log_fn(metrics, steps)
         if not more:
