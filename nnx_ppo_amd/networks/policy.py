@@ -5,10 +5,13 @@ value=Sequential([Dense..]))])`) with its evaluation as ONE launch on the bf16 p
 Module tree, parameters, state / extras / metrics structure and every method are
 those of the plain `Sequential` — `MLPActorCritic` only recognises its own shape and
 routes `__call__` (rollout / inference) and `replay` / `replay_backward` (loss) to
-`mi_policy_fwd_bf16`: normaliser in the input stage, both trunks side by side
-(they read the same input, adapter.py:75-117), sampler on the action trunk's output.
-At this workload's sizes a policy step is bound by launch and dependency latency,
-not arithmetic: four launches on two streams become one.  Anything outside the
+`mi_policy_fwd_bf16` / `mi_policy_ws_fwd_bf16`: normaliser in the input stage, both trunks
+side by side (they read the same input, adapter.py:75-117), sampler on the action trunk's
+output.  At this workload's sizes a policy step is bound by launch and dependency latency,
+not arithmetic: four launches on two streams become one.  Trunks in the shape class of
+csrc/trunk_ws.hip take the weights-stationary kernels (a trunk's fragments requested once,
+up front, and kept in registers); the tile kernels of csrc/mlp_bf16.hip take the rest —
+same results bit for bit, so the choice is invisible.  Anything outside the
 pattern (PyTree observations, fp32 compute, CPU tensors, injected rollout extras,
 trunks the kernel cannot take) goes through the generic container path."""
 from __future__ import annotations
@@ -30,9 +33,7 @@ from .types import PPONetworkOutput, StatefulModuleOutput
 
 # MIPPO_FUSED_POLICY=0 sends everything through the generic containers (A/B timing)
 FUSED = os.environ.get("MIPPO_FUSED_POLICY", "1") != "0"
-# MIPPO_WS_POLICY=0 keeps the loss replay on the per-tile kernels of csrc/mlp_bf16.hip; by
-# default a training-size replay of trunks in their shape class runs on the
-# weights-stationary kernels (csrc/trunk_ws.hip) — same results bit for bit
+# MIPPO_WS_POLICY=0 keeps the loss replay on the tile kernels (A/B timing)
 WS_POLICY = os.environ.get("MIPPO_WS_POLICY", "1") != "0"
 # the weights-stationary backward (both trunks in one launch) measures ~1 % of an iteration
 # better than policy_bwd_kernel at C2 (2.105 vs 2.125 ms); MIPPO_WS_POLICY_BWD=0 for the latter
@@ -110,10 +111,11 @@ class MLPActorCritic(Sequential):
         off = sampler._next_offset()
         ca, cc = chain(a_layers), chain(c_layers)
         rows = M + (0 if value_tail is None else value_tail.shape[0])
-        if rows > WS_MIN_ROWS:  # training sizes: one weights-stationary launch per trunk
+        if rows > WS_MIN_ROWS:  # training sizes: any pair in the class (one launch where the
+            #                     pair is instantiated, else one per trunk)
             ws = (WS_POLICY and train and 2 * A <= 64
                   and ops.policy_ws_supported(ca[2], ca[3], cc[2], cc[3]))
-        else:                   # rollout / evaluation sizes: both trunks in one such launch
+        else:                   # rollout / evaluation sizes: only as one launch for both
             ws = (WS_POLICY_ROLLOUT and 2 * A <= 64
                   and self._ws_dual(ca[2], ca[3], cc[2], cc[3]))
         r = ops.policy_fwd_bf16(
