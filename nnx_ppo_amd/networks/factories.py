@@ -32,7 +32,7 @@ def make_mlp(sizes: list[int], rngs: Rngs, activation: Any = activations.relu,
 
 
 def make_mlp_actor_critic(
-    obs_size: int,
+    obs_size: Union[int, dict],
     action_size: int,
     actor_hidden_sizes: list[int],
     critic_hidden_sizes: list[int],
@@ -45,7 +45,18 @@ def make_mlp_actor_critic(
     std_scale: float = 1.0,
 ) -> StatefulModule:
     """Sequential([Normalizer(obs_size)?, PPOAdapter(action=Sequential([actor...,
-    NormalTanhSampler]), value=critic)]) — factories.py:88-146."""
+    NormalTanhSampler]), value=critic)]) — factories.py:88-146.
+
+    `obs_size` may also be a dict `{name: width}` (a PyTree observation of flat leaves,
+    BASELINE config 3): the network is then what a user of the reference composes by hand,
+    `Sequential([Normalizer(obs_size)?, Flattener(), PPOAdapter(...)])` — per-leaf running
+    statistics, the leaves concatenated in sorted-key order in front of the trunks."""
+    tree_obs = isinstance(obs_size, dict)
+    if tree_obs:
+        from .utils import Flattener
+
+        obs_tree = {k: int(v) for k, v in obs_size.items()}
+        obs_size = sum(obs_tree.values())
     if isinstance(activation, str):
         activation = {"swish": activations.swish, "tanh": activations.tanh,
                       "relu": activations.relu}[activation]
@@ -62,6 +73,10 @@ def make_mlp_actor_critic(
     # evaluates this particular tree in one launch on the bf16 path (networks/policy.py)
     from .policy import MLPActorCritic
 
+    if tree_obs:
+        if normalize_obs:
+            return MLPActorCritic([Normalizer(obs_tree), Flattener(), adapter])
+        return Sequential([Flattener(), adapter])
     if normalize_obs:
         return MLPActorCritic([Normalizer(obs_size), adapter])
     return adapter

@@ -25,10 +25,12 @@ from .. import config, ops
 from . import dense_chain
 from .adapter import PPOAdapter, _Fork, _can_fork
 from .containers import Sequential
+from ..tree import canonicalize, tree_leaves
 from .feedforward import Dense
 from .normalizer import Normalizer
 from .sampling_layers import NormalTanhSampler
 from .types import PPONetworkOutput, StatefulModuleOutput
+from .utils import Flattener
 
 
 # MIPPO_FUSED_POLICY=0 sends everything through the generic containers (A/B timing)
@@ -44,12 +46,20 @@ WS_MIN_ROWS = 8192
 
 
 class MLPActorCritic(Sequential):
+    """`[Normalizer, PPOAdapter]` (flat observations) or `[Normalizer(pytree), Flattener,
+    PPOAdapter]` (PyTree observations, BASELINE config 3: per-leaf statistics, leaves
+    concatenated in sorted-key order in front of the trunks)."""
+
     def __init__(self, layers):
         super().__init__(layers)
         adapter = self.layers[-1]
-        assert isinstance(adapter, PPOAdapter) and len(self.layers) == 2
+        assert isinstance(adapter, PPOAdapter) and len(self.layers) in (2, 3)
         self._norm = self.layers[0]
         self._adapter = adapter
+        # a PyTree-observation network has the Flattener between normaliser and adapter
+        self._flattener = self.layers[1] if len(self.layers) == 3 else None
+        assert self._flattener is None or (isinstance(self._flattener, Flattener)
+                                           and self._flattener.preserve_levels == 0)
 
     def _ws_dual(self, a_dims, a_acts, c_dims, c_acts) -> bool:
         key = (tuple(a_dims), tuple(a_acts), tuple(c_dims), tuple(c_acts))
@@ -57,6 +67,54 @@ class MLPActorCritic(Sequential):
         if key not in cache:
             cache[key] = ops.policy_ws_dual_supported(a_dims, a_acts, c_dims, c_acts)
         return cache[key]
+
+    def _flat_stats(self):
+        """Per-leaf normaliser statistics as ONE vector each, leaves in the Flattener's
+        order — what the kernel's input stage takes.  The leaves are re-homed as views of the
+        flat vectors (the way the optimiser re-homes parameters), so the in-place Welford
+        merge of `update_statistics` and the generic path keep working on them; anything
+        that REPLACED a leaf since (a `.to(device)`, a checkpoint load) is noticed by its
+        address and re-homed again."""
+        n = self._norm
+        flats = self.__dict__.get("_stat_flats")
+        out = []
+        for vi, var in enumerate((n.mean, n.M2)):
+            leaves = tree_leaves(var.value)
+            flat = None if flats is None else flats[vi]
+            off, ok = 0, flat is not None and flat.device == leaves[0].device
+            for t in leaves:
+                ok = ok and t.data_ptr() == flat.data_ptr() + 4 * off and t.is_contiguous()
+                off += t.numel()
+            if not ok or off != flat.numel():
+                from ..tree import tree_map
+
+                flat = torch.cat([t.reshape(-1) for t in leaves])
+                views, off = {}, 0
+                for t in leaves:
+                    views[id(t)] = flat[off:off + t.numel()].view(t.shape)
+                    off += t.numel()
+                var.value = tree_map(lambda t: views[id(t)], var.value)
+            out.append(flat)
+        self.__dict__["_stat_flats"] = out
+        return out[0], out[1]
+
+    def _flat_obs(self, obs):
+        """A PyTree observation as the `[B, K0]` tensor the Flattener would hand the trunks
+        (one concatenation), or None if it is not a tree of 2-D fp32 GPU leaves that matches
+        the normaliser's."""
+        if self._flattener is None or not isinstance(obs, dict) or self._norm is None:
+            return None
+        leaves = tree_leaves(canonicalize(obs))
+        shapes = tree_leaves(self._norm.mean.value)
+        if len(leaves) != len(shapes) or not leaves:
+            return None
+        B = leaves[0].shape[0] if isinstance(leaves[0], torch.Tensor) and leaves[0].dim() == 2 else -1
+        for t, m in zip(leaves, shapes):
+            if not (isinstance(t, torch.Tensor) and t.dim() == 2 and t.is_cuda
+                    and t.dtype == torch.float32 and t.shape[0] == B and m.dim() == 1
+                    and t.shape[1] == m.shape[0]):
+                return None
+        return torch.cat(leaves, dim=1)
 
     # ---- pattern ---------------------------------------------------------------------
     def _parts(self):
@@ -71,9 +129,10 @@ class MLPActorCritic(Sequential):
         if not x.is_cuda or x.dtype != torch.float32:
             return False
         norm = self._norm
-        if norm is not None and not (isinstance(norm, Normalizer)
-                                     and isinstance(norm.mean.value, torch.Tensor)
-                                     and norm.mean.value.dim() == 1):
+        if norm is not None and not isinstance(norm, Normalizer):
+            return False
+        if norm is not None and self._flattener is None and not (
+                isinstance(norm.mean.value, torch.Tensor) and norm.mean.value.dim() == 1):
             return False
         if not (isinstance(self._adapter.action, Sequential)
                 and isinstance(self._adapter.value, Sequential)):
@@ -104,7 +163,9 @@ class MLPActorCritic(Sequential):
         norm = None
         if self._norm is not None:
             n = self._norm
-            norm = (n.mean.value, n.M2.value, n.counter.value, n.epsilon)
+            mean, m2 = (n.mean.value, n.M2.value) if self._flattener is None \
+                else self._flat_stats()
+            norm = (mean, m2, n.counter.value, n.epsilon)
         M = x2.shape[0]
         A = a_layers[-1].out_features // 2
         eps, eps2 = sampler._noise(M, A, x2.device)
@@ -126,10 +187,15 @@ class MLPActorCritic(Sequential):
 
     # ---- rollout / inference (adapter.py:75-117 over the whole stack) -----------------
     def __call__(self, network_state, obs: Any, rollout_extras: Any = None):
-        if (rollout_extras is not None or not isinstance(obs, torch.Tensor) or obs.dim() != 2
-                or not self._fusable(obs, obs.shape[0])):
+        if rollout_extras is not None or not FUSED or config.compute_dtype() != "bf16":
             return super().__call__(network_state, obs, rollout_extras)
-        x2 = obs if obs.is_contiguous() else obs.contiguous()
+        if self._flattener is None:
+            x2 = obs if isinstance(obs, torch.Tensor) and obs.dim() == 2 else None
+        else:  # PyTree observation: one concatenation, then the same launch
+            x2 = self._flat_obs(obs)
+        if x2 is None or not self._fusable(x2, x2.shape[0]):
+            return super().__call__(network_state, obs, rollout_extras)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
         r, _, _ = self._launch(x2, None, train=False)
         a_layers, _, c_layers = self._parts()
         value = r["value"]
@@ -144,14 +210,17 @@ class MLPActorCritic(Sequential):
             metrics={"action": a_metrics, "value": {i: {} for i in range(len(c_layers))}},
             rollout_extras={"action": [None] * len(a_layers) + [r["raw"]],
                             "value": [None] * len(c_layers)})
-        pre = self._norm is not None
+        # the layers in front of the adapter: normaliser (its extras are the raw observation,
+        # normalizer.py:63-96) and, for PyTree observations, the Flattener (no state, no extras)
+        n_pre = len(self.layers) - 1
+        pre_extras = [canonicalize(obs)] + [None] * (n_pre - 1)
         return StatefulModuleOutput(
-            next_state=([()] if pre else []) + [adapter_out["next_state"]],
+            next_state=[()] * n_pre + [adapter_out["next_state"]],
             output=PPONetworkOutput(actions=r["action"], loglikelihoods=r["log_likelihood"],
                                     value_estimates=value),
             regularization_loss=r["reg"],
-            metrics=dict(enumerate(([{}] if pre else []) + [adapter_out["metrics"]])),
-            rollout_extras=([obs] if pre else []) + [adapter_out["rollout_extras"]])
+            metrics=dict(enumerate([{}] * n_pre + [adapter_out["metrics"]])),
+            rollout_extras=pre_extras + [adapter_out["rollout_extras"]])
 
     # ---- loss replay (ppo.py:411-431) ------------------------------------------------
     def replay_with_bootstrap(self, state0, x_seq, done_seq, extras_seq, last_obs):

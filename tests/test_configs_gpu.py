@@ -40,11 +40,22 @@ def _c3_net(seed=17):
                        PPOAdapter(action=Sequential([*actor, sampler]), value=critic)])
 
 
+def _c3_net_factory(seed=17):
+    """The same network from `make_mlp_actor_critic` with a dict `obs_size`: the rollout step
+    is then one concatenation + one launch (networks/policy.py)."""
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+
+    return factories.make_mlp_actor_critic({"position": 8, "velocity": 9}, 6, [256] * 4,
+                                           [512] * 2, Rngs(seed))
+
+
 def _called(prof) -> set:
     return {name for name, *_ in prof.records}
 
 
-def test_c3_shape_ppo_step_vs_oracle(dev):
+@pytest.mark.parametrize("build", ["by_hand", "factory"])
+def test_c3_shape_ppo_step_vs_oracle(dev, build):
     from nnx_ppo_amd import _lib, config
     from nnx_ppo_amd.algorithms import ppo
     from nnx_ppo_amd.envs import cheetah_shaped
@@ -54,7 +65,7 @@ def test_c3_shape_ppo_step_vs_oracle(dev):
     mk_env = lambda: EpisodeWrapper(cheetah_shaped(max_steps=11), 40)
     with config.use_compute_dtype("bf16"):
         env, oenv = mk_env(), mk_env()
-        net = _c3_net()
+        net = _c3_net() if build == "by_hand" else _c3_net_factory()
         ts = ppo.new_training_state(env, net, N, 18, 3e-4, device=dev)
         onet = on.from_product(net)
         ots = op.new_training_state(oenv, onet, N, 18, keys, 3e-4)

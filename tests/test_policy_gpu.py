@@ -165,3 +165,69 @@ def test_bootstrap_rows_ride_along_bit_identically(dev, bf16):
                     lv.clone(), opt.grads.clone()))
     for a, b in zip(*res):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [1, 100, 8192])
+@pytest.mark.parametrize("shape", [({"position": 8, "velocity": 9}, 6, [256] * 4, [512] * 2),
+                                   ({"b": 3, "a": 2, "c": 1}, 2, [64] * 2, [64] * 2)])
+def test_pytree_obs_rollout_call_is_bit_identical_to_generic(dev, bf16, M, shape):
+    """`make_mlp_actor_critic` with a dict `obs_size` builds Sequential([Normalizer(tree),
+    Flattener, PPOAdapter]) (BASELINE config 3's shape); its rollout step is one
+    concatenation + one launch, bit-identical to the generic containers — per-leaf
+    statistics, sorted-key leaf order, the raw PyTree kept as the normaliser's extras."""
+    from nnx_ppo_amd import _lib
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.containers import Sequential
+    from nnx_ppo_amd.networks.policy import MLPActorCritic
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.tree import tree_leaves
+
+    obs_tree, act_dim, ah, ch = shape
+    net = factories.make_mlp_actor_critic(obs_tree, act_dim, ah, ch, Rngs(4))
+    assert isinstance(net, MLPActorCritic) and len(net.layers) == 3
+    net.to(dev)
+    g = torch.Generator().manual_seed(1)
+    n = net.layers[0]
+    for k, w in obs_tree.items():
+        n.mean.value[k].copy_(torch.randn(w, generator=g))
+        n.M2.value[k].copy_(torch.rand(w, generator=g) * 50 + 1)
+    n.counter.value.fill_(37.0)
+    # insertion order differs from sorted order on purpose
+    x = {k: torch.randn(M, w, generator=g).to(dev) for k, w in reversed(list(obs_tree.items()))}
+    state = net.initialize_state(M)
+    smp = _sampler(net)
+    for deterministic in (False, True):
+        smp.deterministic = deterministic
+        smp._pending = 5
+        with _lib.profiler as prof:
+            fused = net(state, x)
+        used = [r[0] for r in prof.records]
+        assert sum(u in ("mi_policy_fwd_bf16", "mi_policy_ws_fwd_bf16") for u in used) == 1
+        assert "mi_normalize_fwd_f32" not in used and "mi_mlp_fwd_bf16" not in used
+        smp._pending = 5
+        plain = Sequential.__call__(net, state, x)
+        for name in ("next_state", "output", "regularization_loss", "metrics", "rollout_extras"):
+            a, b = _leaves(getattr(fused, name)), _leaves(getattr(plain, name))
+            assert len(a) == len(b), name
+            for u, v in zip(a, b):
+                assert u.shape == v.shape and torch.equal(u, v), name
+        assert set(fused.rollout_extras[0]) == set(obs_tree)
+    # the statistics stay per-leaf tensors the normaliser updates in place: one update, then
+    # the fused step still equals the generic one
+    seq = {k: torch.randn(3, M, w, generator=g).to(dev) for k, w in obs_tree.items()}
+    net.layers[0].update_statistics(seq)
+    assert all(t.dim() == 1 for t in tree_leaves(n.mean.value))
+    smp._pending = 9
+    fused = net(state, x)
+    smp._pending = 9
+    plain = Sequential.__call__(net, state, x)
+    for u, v in zip(_leaves(fused.output), _leaves(plain.output)):
+        assert torch.equal(u, v)
+    # a replaced leaf (checkpoint load, .to()) is picked up
+    n.mean.value = {k: v.clone() + 1.0 for k, v in n.mean.value.items()}
+    smp._pending = 11
+    fused = net(state, x)
+    smp._pending = 11
+    plain = Sequential.__call__(net, state, x)
+    for u, v in zip(_leaves(fused.output), _leaves(plain.output)):
+        assert torch.equal(u, v)

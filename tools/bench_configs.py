@@ -34,12 +34,9 @@ def build(name, n_envs, device):
         desc = "CartpoleBalance-shaped, MLP 4x64 / 2x256"
     elif name == "c3":
         env = EpisodeWrapper(cheetah_shaped(max_steps=1000), 1000)
-        actor = factories.make_mlp_layers([17] + [256] * 4 + [12], rngs,
-                                          activation_last_layer=False)
-        critic = factories.make_mlp([17] + [512] * 2 + [1], rngs, activation_last_layer=False)
-        sampler = NormalTanhSampler(rngs, entropy_weight=1e-2, min_std=1e-1)
-        net = Sequential([Normalizer({"position": 8, "velocity": 9}), Flattener(),
-                          PPOAdapter(action=Sequential([*actor, sampler]), value=critic)])
+        # a dict obs_size: Sequential([Normalizer(tree), Flattener(), PPOAdapter(...)])
+        net = factories.make_mlp_actor_critic({"position": 8, "velocity": 9}, 6, [256] * 4,
+                                              [512] * 2, rngs)
         desc = "CheetahRun-shaped dict obs {position 8, velocity 9}, MLP 4x256 / 2x512"
     elif name in ("c4", "c4r"):
         # c4r: the reset-heavy env of SURVEY 8(d) (an episode ends every 5 steps, so the
