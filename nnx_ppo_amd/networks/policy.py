@@ -98,6 +98,21 @@ class MLPActorCritic(Sequential):
         self.__dict__["_stat_flats"] = out
         return out[0], out[1]
 
+    def _flat_seq(self, x_seq):
+        """`_flat_obs` for a `[T, B, w]` sequence tree -> `[T, B, K0]` (else the input)."""
+        if not isinstance(x_seq, dict):
+            return x_seq
+        leaves = tree_leaves(canonicalize(x_seq))
+        shapes = tree_leaves(self._norm.mean.value)
+        if len(leaves) != len(shapes) or not leaves:
+            return x_seq
+        for t, m in zip(leaves, shapes):
+            if not (isinstance(t, torch.Tensor) and t.dim() == 3 and t.is_cuda
+                    and t.dtype == torch.float32 and t.shape[:2] == leaves[0].shape[:2]
+                    and m.dim() == 1 and t.shape[2] == m.shape[0]):
+                return x_seq
+        return torch.cat(leaves, dim=2)
+
     def _flat_obs(self, obs):
         """A PyTree observation as the `[B, K0]` tensor the Flattener would hand the trunks
         (one concatenation), or None if it is not a tree of 2-D fp32 GPU leaves that matches
@@ -124,9 +139,14 @@ class MLPActorCritic(Sequential):
         return a_layers, sampler, c_layers
 
     def _fusable(self, x, M: int) -> bool:
-        if not FUSED or config.compute_dtype() != "bf16" or not isinstance(x, torch.Tensor):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32:
             return False
-        if not x.is_cuda or x.dtype != torch.float32:
+        return self._trunks_fusable(M)
+
+    def _trunks_fusable(self, M: int) -> bool:
+        """The part of `_fusable` that does not look at the input: settings, module pattern
+        and trunk shapes for M rows (asked BEFORE a PyTree input is concatenated)."""
+        if not FUSED or config.compute_dtype() != "bf16":
             return False
         norm = self._norm
         if norm is not None and not isinstance(norm, Normalizer):
@@ -192,7 +212,10 @@ class MLPActorCritic(Sequential):
         if self._flattener is None:
             x2 = obs if isinstance(obs, torch.Tensor) and obs.dim() == 2 else None
         else:  # PyTree observation: one concatenation, then the same launch
-            x2 = self._flat_obs(obs)
+            lead = tree_leaves(obs)
+            ok = (lead and isinstance(lead[0], torch.Tensor) and lead[0].dim() == 2
+                  and self._trunks_fusable(lead[0].shape[0]))
+            x2 = self._flat_obs(obs) if ok else None
         if x2 is None or not self._fusable(x2, x2.shape[0]):
             return super().__call__(network_state, obs, rollout_extras)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
@@ -228,6 +251,12 @@ class MLPActorCritic(Sequential):
         ppo.py:433-437): the extra rows ride along in the value trunk of the same launch.
         Returns (ctx, out, reg, final_state, last_values) or None when the fused path
         does not apply."""
+        if self._flattener is not None:
+            lead = tree_leaves(x_seq)
+            if not (lead and isinstance(lead[0], torch.Tensor) and lead[0].dim() == 3
+                    and self._trunks_fusable(lead[0].shape[0] * lead[0].shape[1])):
+                return None
+            last_obs = self._flat_obs(last_obs)
         if not (isinstance(last_obs, torch.Tensor) and last_obs.dim() == 2):
             return None
         return self.replay(state0, x_seq, done_seq, extras_seq, need_input_grad=False,
@@ -235,13 +264,19 @@ class MLPActorCritic(Sequential):
 
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True,
                _bootstrap=None):
+        x_tree = x_seq
+        if self._flattener is not None and not need_input_grad and extras_seq is not None:
+            lead = tree_leaves(x_seq)
+            if (lead and isinstance(lead[0], torch.Tensor) and lead[0].dim() == 3
+                    and self._trunks_fusable(lead[0].shape[0] * lead[0].shape[1])):
+                x_seq = self._flat_seq(x_seq)  # PyTree observation: one concatenation
         fus = (not need_input_grad and extras_seq is not None
                and isinstance(x_seq, torch.Tensor) and x_seq.dim() == 3
                and self._fusable(x_seq, x_seq.shape[0] * x_seq.shape[1]))
         if not fus:
             if _bootstrap is not None:
                 return None
-            ctx, out, reg, fs = super().replay(state0, x_seq, done_seq, extras_seq,
+            ctx, out, reg, fs = super().replay(state0, x_tree, done_seq, extras_seq,
                                                need_input_grad)
             return ("generic", ctx), out, reg, fs
         T, B, K0 = x_seq.shape
@@ -270,9 +305,8 @@ class MLPActorCritic(Sequential):
                                      for (xb, aux), l in zip(saved, ls)]
         ctx = ("fused", s_ctx, (shadows(a_layers, r["actor_saved"]), M, False),
                (shadows(c_layers, r["critic_saved"]), M, False), squeezed, (T, B))
-        pre = self._norm is not None
-        final_state = ([()] if pre else []) + [{"action": list(state0[-1]["action"]),
-                                                "value": list(state0[-1]["value"])}]
+        final_state = [()] * (len(self.layers) - 1) + [{"action": list(state0[-1]["action"]),
+                                                       "value": list(state0[-1]["value"])}]
         if _bootstrap is not None:
             lv = r["value_tail_out"]
             return ctx, out, r["reg"].view(T, B), final_state, (lv.squeeze(-1) if squeezed

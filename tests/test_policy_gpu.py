@@ -231,3 +231,59 @@ def test_pytree_obs_rollout_call_is_bit_identical_to_generic(dev, bf16, M, shape
     plain = Sequential.__call__(net, state, x)
     for u, v in zip(_leaves(fused.output), _leaves(plain.output)):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("T,B", [(3, 7), (30, 1024)])
+def test_pytree_obs_replay_with_bootstrap_equals_generic(dev, bf16, T, B):
+    """The loss replay of a PyTree-observation network in the fused shape class: sequence
+    tree and bootstrap observation are concatenated once each and take the one-launch
+    replay (+ bootstrap rows); outputs bit-identical to the generic containers, gradients
+    to dW summation order."""
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.containers import Sequential
+    from nnx_ppo_amd.networks.types import PPONetworkOutput, Rngs, bump_param_epoch
+    from nnx_ppo_amd.optim import Optimizer
+    from nnx_ppo_amd.tree import tree_map
+
+    obs_tree = {"position": 8, "velocity": 9}
+    net = factories.make_mlp_actor_critic(obs_tree, 3, [128] * 2, [256] * 2, Rngs(5))
+    net.to(dev)
+    opt = Optimizer(net, 1e-3, None, None, device=dev)
+    g = torch.Generator().manual_seed(T * B)
+    n = net.layers[0]
+    for k, w in obs_tree.items():
+        n.mean.value[k].copy_(torch.randn(w, generator=g))
+        n.M2.value[k].copy_(torch.rand(w, generator=g) * 50 + 1)
+    n.counter.value.fill_(11.0)
+    x_seq = {k: torch.randn(T, B, w, generator=g).to(dev) for k, w in obs_tree.items()}
+    last = {k: torch.randn(B, w, generator=g).to(dev) for k, w in obs_tree.items()}
+    done = torch.zeros(T, B, dtype=torch.bool, device=dev)
+    state = net.initialize_state(B)
+    smp = _sampler(net)
+    steps = [net(state, {k: v[t] for k, v in x_seq.items()}).rollout_extras for t in range(T)]
+    extras = tree_map(lambda *xs: torch.stack(xs, 0), steps[0], *steps[1:])
+    g_ll = torch.randn(T, B, generator=g).to(dev)
+    g_v = torch.randn(T, B, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        bump_param_epoch()
+        opt.begin()
+        smp._pending = 11
+        if fused:
+            ctx, out, reg, fs, lv = net.replay_with_bootstrap(state, x_seq, done, extras, last)
+            assert ctx[0] == "fused" and len(fs) == 3
+            net.replay_backward(ctx, PPONetworkOutput(None, g_ll, g_v), 1.0 / (T * B))
+        else:
+            ctx, out, reg, fs = Sequential.replay(net, state, x_seq, done, extras,
+                                                  need_input_grad=False)
+            lv = Sequential.forward_value(net, state, last)
+            Sequential.replay_backward(net, ctx, PPONetworkOutput(None, g_ll, g_v),
+                                       1.0 / (T * B))
+        torch.cuda.synchronize()
+        res.append((out.loglikelihoods.clone(), out.value_estimates.clone(), reg.clone(),
+                    lv.reshape(-1).clone(), opt.grads.clone()))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    ga, gb = res[0][4], res[1][4]
+    assert float(ga.abs().sum()) > 0
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
