@@ -600,6 +600,28 @@ int mi_adam_step_slabs_f32(
     const int64_t* slab_N, const int64_t* gw_offset, const int64_t* gb_offset,
     mi_stream_t stream);
 
+/* One rollout / evaluation step of the recurrent actor-critic of make_gru_actor_critic
+ * (normaliser -> Dense(K0 -> H, relu) -> GRU(H -> H) -> Dense(H -> 2A) -> NormalTanhSampler,
+ * beside an MLP value trunk) in ONE launch; the recurrent contract is the reference's
+ * networks/recurrent.py:89-161, the composition recurrent_test.py:245-261.  w_in / w_proj /
+ * w_out: forward fragment-major images (w_proj: the GRU's input projection [H, 3H], columns
+ * r | z | n); w_h: fp32 [H, 3H]; h_in / h_out: the carry [M, H].  Sampler arguments and
+ * outputs as mi_policy_fwd_bf16.  Bit-identical to the generic containers' launches.
+ * mi_gru_policy_step_supported: K0 <= 32, H in {64, 128}, 2A <= 16, value trunk in the
+ * class of mi_mlp_ws_supported and the (value trunk, H) pair instantiated. */
+int mi_gru_policy_step_supported(int64_t K0, int64_t H, int64_t A2, int64_t Lc,
+                                 const int64_t* c_dims, const int64_t* c_acts);
+int mi_gru_policy_step_bf16(
+    const float* obs, int64_t M, int64_t K0, int64_t H, int64_t A2, const float* norm_mean,
+    const float* norm_m2, const float* norm_count, float norm_eps, const void* w_in,
+    const float* b_in, const void* w_proj, const float* b_proj, const float* w_h,
+    const float* b_hn, const void* w_out, const float* b_out, const float* h_in, float* h_out,
+    int64_t Lc, const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const uint64_t* rng_state, uint64_t offset_add, const float* eps,
+    const float* eps2, float min_std, float std_scale, float entropy_weight, int deterministic,
+    float* mean_and_std, float* raw_out, float* action, float* loglik, float* reg,
+    float* mu_out, float* sigma_out, float* value, mi_stream_t stream);
+
 /* Weights-stationary forms of mi_mlp_bwd_dx_bf16 (no input gradient, linear last layer)
  * and mi_policy_bwd_bf16 for training sizes: same operands (w_bf: the BACKWARD
  * fragment-major images; aux[l] = y_l, dz_bf[l] = dz_l for l < L - 1; dz_last = dz_{L-1}),

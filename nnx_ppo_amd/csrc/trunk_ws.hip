@@ -400,6 +400,285 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
   }
 }
 
+// ---- one time step of the recurrent actor of make_gru_actor_critic ------------------------
+// (nnx_ppo_amd/networks/factories.py: Dense(obs -> H, relu) -> GRU(H -> H) -> Dense(H -> 2A)
+// -> sampler; the recurrent contract of networks/recurrent.py:89-161, cell of gru_mfma.hip.)
+// At a rollout / evaluation step the "sequence" is one step long, so the whole actor is
+// row-local like an MLP: normaliser, Dense, the GRU's input projection AND its recurrent
+// product, the gate arithmetic, the output Dense and the sampler — seven launches of the
+// generic containers — run here on one 16*RT-row tile with every weight in registers:
+//   chain layer 0: obs -> H (relu); layer 1: the GRU's input projection H -> 3H (columns
+//   r | z | n, bias b_i); layer 2: H -> N_out (the head);  `gx`: the recurrent kernel (fp32,
+//   converted once per workgroup exactly as gru_fwd_mfma_kernel converts it), b_hn, the
+//   carry in and out.
+// Wave (wc, wr) owns unit tile wc: the r, z and n columns of its 16 units, so the gates of a
+// (row, unit) meet in one lane and the fp32 carry never leaves registers — gru_mfma.hip's
+// arrangement in the transposed MFMA form of this file.  Same operand roundings, same
+// k-order, same expressions as the launches it replaces: bit-identical
+// (tests/test_gru_policy_gpu.py).
+struct GruStepExtra {
+  const float* w_h;   // [H][3H]
+  const float* b_hn;  // [H]
+  const float* h_in;  // [M][H]
+  float* h_out;       // [M][H]
+};
+
+template <int H, int RT>
+__device__ __forceinline__ void ws_gru_step_body(const WsChain& c, const GruStepExtra& gx,
+                                                 const int bid, const int nblk,
+                                                 unsigned char* smem) {
+  static_assert(H == 64 || H == 128, "GRU width: 64 or 128");
+  using G = WsGeom<H>;
+  constexpr int CW = G::CW, RW = G::RW;
+  static_assert(G::TPW == 1 && RT % RW == 0, "one unit tile per wave");
+  constexpr int RTW = RT / RW;
+  constexpr int ROWS = 16 * RT;
+  constexpr int KSH = H / 32;
+  constexpr int UT = H / 16;
+  constexpr int AROW = H + 8;
+  constexpr int XROW = 32 + 8;
+  using Lds = WsFwdLds<H, RT, true>;
+  bf16_t* const bufX = reinterpret_cast<bf16_t*>(smem + Lds::bufX);
+  bf16_t* const bufA = reinterpret_cast<bf16_t*>(smem + Lds::bufA);  // h, then h'
+  bf16_t* const bufB = reinterpret_cast<bf16_t*>(smem + Lds::bufB);  // layer 0's output
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % CW, wr = wave / CW;
+  const int li = lane & 15, lq = lane >> 4;
+  const int64_t M = c.M;
+  const int K0 = c.K0, N_out = c.N_out;
+  const int64_t ntiles = (M + ROWS - 1) / ROWS;
+
+  // ---- per-tile global operands: the observation tile, the carry tile (as the recurrent
+  // product's operand) and this lane's own carry elements (for the blend) -----------------
+  constexpr int IN_PT = (ROWS * 32 + kWsThreads - 1) / kWsThreads;
+  constexpr int H_CH = ROWS * (H / 4);                               // 16-byte chunks of h
+  constexpr int H_PT = (H_CH + kWsThreads - 1) / kWsThreads;
+  const int nel = ROWS * K0;
+  const float rcpK0 = 1.0f / (float)K0;
+  float xin[IN_PT];
+  f32x4 hin[H_PT];
+  f32x4 hp[RTW];
+  auto request_tile = [&](int64_t tile) {
+    const int64_t i0 = tile * ROWS;
+#pragma unroll
+    for (int u = 0; u < IN_PT; ++u) {
+      const int e = tid + u * kWsThreads;
+      const int row = (int)(((float)e + 0.5f) * rcpK0);
+      const int64_t gi = i0 + row;
+      xin[u] = 0.0f;
+      if (e < nel && gi < M) xin[u] = c.x[gi * K0 + (e - row * K0)];
+    }
+#pragma unroll
+    for (int u = 0; u < H_PT; ++u) {
+      const int ch = tid + u * kWsThreads;
+      const int row = ch / (H / 4), q = ch % (H / 4);
+      const int64_t gi = i0 + row;
+      hin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ch < H_CH && gi < M)
+        hin[u] = *reinterpret_cast<const f32x4*>(gx.h_in + gi * H + 4 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) {
+      const int64_t gi = i0 + (wr * RTW + r) * 16 + li;
+      hp[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gi < M) hp[r] = *reinterpret_cast<const f32x4*>(gx.h_in + gi * H + wc * 16 + 4 * lq);
+    }
+  };
+  float* const s_mean = reinterpret_cast<float*>(smem + Lds::mean);
+  float* const s_sd = reinterpret_cast<float*>(smem + Lds::sd);
+  const bool norm = c.norm_mean != nullptr;
+  if (norm && tid < K0) {
+    const float cnt = *c.norm_count;
+    s_mean[tid] = c.norm_mean[tid];
+    s_sd[tid] = cnt > 0.0f ? sqrtf(fmaxf(c.norm_m2[tid] / cnt, c.norm_eps)) : 10.0f;
+  }
+  int64_t tile = bid;
+  if (tile < ntiles) request_tile(tile);
+
+  // ---- the actor, once ------------------------------------------------------------------
+  auto bias4 = [&](const float* b, int col) {
+    return b ? *reinterpret_cast<const f32x4*>(b + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  const bf16x8 W0 = ws_frag(c.layer[0].w, (unsigned)wc, 0, 1, lane);
+  const f32x4 B0 = bias4(c.layer[0].bias, wc * 16 + 4 * lq);
+  bf16x8 WI[3][KSH], WR[3][KSH];
+  f32x4 BI[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int ks = 0; ks < KSH; ++ks) {
+      WI[g][ks] = ws_frag(c.layer[1].w, (unsigned)(g * UT + wc), ks, KSH, lane);
+      bf16x8 f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        f[i] = (bf16_t)gx.w_h[(int64_t)(ks * 32 + 8 * lq + i) * (3 * H) + g * H + wc * 16 + li];
+      WR[g][ks] = f;
+    }
+    BI[g] = bias4(c.layer[1].bias, g * H + wc * 16 + 4 * lq);
+  }
+  const f32x4 BN = bias4(gx.b_hn, wc * 16 + 4 * lq);
+  bf16x8 WO[KSH];
+#pragma unroll
+  for (int ks = 0; ks < KSH; ++ks) WO[ks] = ws_frag(c.layer[2].w, 0, ks, KSH, lane);
+  f32x4 BO = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c.layer[2].bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * lq + e < N_out) BO[e] = c.layer[2].bias[4 * lq + e];
+  }
+  for (int row = tid >> 5; row < ROWS; row += kWsThreads >> 5)
+    for (int k = K0 + (tid & 31); k < 32; k += 32) bufX[row * XROW + k] = (bf16_t)0.0f;
+  __syncthreads();  // s_mean / s_sd
+
+  // the sampler's rows wait in LDS as in ws_fwd_body (one thread per row, many tiles at once)
+  constexpr int kStashFloats = 4096;
+  constexpr int kStashTilesMax = kWsThreads / ROWS;
+  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);
+  int64_t stash_first = 0;
+  int stash_n = 0;
+  int stash_cap = kStashFloats / (ROWS * N_out);
+  if (stash_cap > kStashTilesMax) stash_cap = kStashTilesMax;
+  auto run_sampler = [&]() {
+    const int slot = tid / ROWS, row = tid % ROWS;
+    if (slot < stash_n) {
+      const int64_t gi = (stash_first + (int64_t)slot * nblk) * ROWS + row;
+      if (gi < M) mippo_sampler::fwd_row(ms_s + (slot * ROWS + row) * N_out, gi, c.samp);
+    }
+    __syncthreads();
+  };
+
+  for (; tile < ntiles; tile += nblk) {
+    const int64_t i0 = tile * ROWS;
+    // stage 0: observation tile -> bufX (normalised, bf16); carry tile -> bufA (bf16)
+#pragma unroll
+    for (int u = 0; u < IN_PT; ++u) {
+      const int e = tid + u * kWsThreads;
+      if (e < nel) {
+        const int row = (int)(((float)e + 0.5f) * rcpK0);
+        const int k = e - row * K0;
+        float v = xin[u];
+        if (norm && i0 + row < M) v = (v - s_mean[k]) / s_sd[k];
+        bufX[row * XROW + k] = (bf16_t)v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < H_PT; ++u) {
+      const int ch = tid + u * kWsThreads;
+      if (ch < H_CH) {
+        const int row = ch / (H / 4), q = ch % (H / 4);
+        bf16x4 hb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hb[e] = (bf16_t)hin[u][e];
+        *reinterpret_cast<bf16x4*>(bufA + row * AROW + 4 * q) = hb;
+      }
+    }
+    f32x4 hprev[RTW];
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) hprev[r] = hp[r];
+    if (tile + nblk < ntiles) request_tile(tile + nblk);
+    __syncthreads();
+    // ---- Dense(obs -> H, relu) -----------------------------------------------------------
+    {
+#pragma unroll
+      for (int r = 0; r < RTW; ++r) {
+        const bf16x8 af =
+            *reinterpret_cast<const bf16x8*>(bufX + ((wr * RTW + r) * 16 + li) * XROW + 8 * lq);
+        const f32x4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            W0, af, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        bf16x4 vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)fmaxf(a0[e] + B0[e], 0.0f);
+        *reinterpret_cast<bf16x4*>(bufB + ((wr * RTW + r) * 16 + li) * AROW + wc * 16 + 4 * lq) = vo;
+      }
+    }
+    __syncthreads();
+    // ---- the GRU cell: gi = a1 . W_i + b_i, gh = h . W_h, gates in registers ------------
+    f32x4 hnew[RTW];
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) {
+      f32x4 ai[3], ah[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) ai[g] = ah[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) {
+        const int off = ((wr * RTW + r) * 16 + li) * AROW + ks * 32 + 8 * lq;
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(bufB + off);
+        const bf16x8 fh = *reinterpret_cast<const bf16x8*>(bufA + off);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          ai[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WI[g][ks], fa, ai[g], 0, 0, 0);
+          ah[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WR[g][ks], fh, ah[g], 0, 0, 0);
+        }
+      }
+      const int64_t gi_row = i0 + (wr * RTW + r) * 16 + li;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // gru_fwd_mfma_kernel's step, on gi = (a1 . W_i + b_i) as the projection launch
+        // leaves it
+        const float rg = fast_sigmoid((ai[0][e] + BI[0][e]) + ah[0][e]);
+        const float zg = fast_sigmoid((ai[1][e] + BI[1][e]) + ah[1][e]);
+        const float qn = ah[2][e] + BN[e];
+        const float ng = fast_tanh((ai[2][e] + BI[2][e]) + rg * qn);
+        hnew[r][e] = (1.0f - zg) * ng + zg * hprev[r][e];
+      }
+      if (gi_row < M)
+        *reinterpret_cast<f32x4*>(gx.h_out + gi_row * H + wc * 16 + 4 * lq) = hnew[r];
+    }
+    __syncthreads();  // every wave has read h and a1: bufA takes h' now
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) {
+      bf16x4 vo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)hnew[r][e];
+      *reinterpret_cast<bf16x4*>(bufA + ((wr * RTW + r) * 16 + li) * AROW + wc * 16 + 4 * lq) = vo;
+    }
+    __syncthreads();
+    // ---- Dense(H -> N_out) on h', wave w the row tile w; rows to the sampler stash -------
+    if (wave < RT) {
+      f32x4 ao = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(bufA + (wave * 16 + li) * AROW +
+                                                          ks * 32 + 8 * lq);
+        ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WO[ks], a, ao, 0, 0, 0);
+      }
+      const int row = wave * 16 + li;
+      const int64_t gi = i0 + row;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (4 * lq + e < N_out) {
+          const float v = ao[e] + BO[e];
+          if (gi < M && c.out) c.out[gi * N_out + 4 * lq + e] = v;
+          ms_s[(stash_n * ROWS + row) * N_out + 4 * lq + e] = v;
+        }
+      }
+    }
+    if (stash_n == 0) stash_first = tile;
+    ++stash_n;
+    if (stash_n == stash_cap || tile + nblk >= ntiles) {
+      __syncthreads();
+      run_sampler();
+      stash_n = 0;
+    }
+    __syncthreads();  // the buffers are free for the next row tile
+  }
+}
+
+// The recurrent policy's rollout step in one launch: value-trunk workgroups (ws_fwd_body)
+// beside recurrent-actor workgroups, as policy_ws_dual_kernel.
+template <int HV, int NHV, int H, int RT>
+__global__ void __launch_bounds__(kWsThreads, 2)
+gru_policy_ws_kernel(WsChain a, GruStepExtra gx, WsChain v, int n_value) {
+  constexpr size_t nv = WsFwdLds<HV, RT, false>::bytes, na = WsFwdLds<H, RT, true>::bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[nv > na ? nv : na];
+  if ((int)blockIdx.x < n_value)
+    ws_fwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value, smem);
+  else
+    ws_gru_step_body<H, RT>(a, gx, (int)blockIdx.x - n_value, (int)gridDim.x - n_value, smem);
+}
+
 template <int H, int NH, int RT, bool SAMP>
 __global__ void __launch_bounds__(kWsThreads, 2)
 trunk_ws_fwd_kernel(WsChain c) {
@@ -1031,6 +1310,105 @@ int ws_dual_launch(const WsChain& a, const WsChain& v, int64_t hv, int64_t nhv, 
 }
 
 }  // namespace
+
+// ---- the recurrent policy's rollout step ---------------------------------------------------
+namespace {
+
+// (value trunk) x (GRU width) pairs the one-launch recurrent step is instantiated for
+#define GRU_STEP_MENU(X) \
+  X(256, 1, 64) X(256, 1, 128) X(256, 0, 64) X(128, 1, 64) X(128, 1, 128) X(64, 1, 64)
+
+bool gru_step_has(int64_t hv, int64_t nhv, int64_t h) {
+#define X(a, b, c) if (hv == a && nhv == b && h == c) return true;
+  GRU_STEP_MENU(X)
+#undef X
+  return false;
+}
+
+}  // namespace
+
+// 1 if mi_gru_policy_step_bf16 takes this network: observation width <= 32, GRU width 64 or
+// 128 (Dense_in: K0 -> H relu; head: H -> 2A <= 16 columns), value trunk in the
+// weights-stationary shape class, and the pair instantiated.
+extern "C" int mi_gru_policy_step_supported(int64_t K0, int64_t H, int64_t A2, int64_t Lc,
+                                            const int64_t* c_dims, const int64_t* c_acts) {
+  if (K0 < 1 || K0 > 32 || A2 < 2 || A2 > 16 || (A2 & 1)) return 0;
+  if (!mi_mlp_ws_supported(Lc, c_dims, c_acts) || c_dims[0] != K0) return 0;
+  return gru_step_has(c_dims[1], Lc - 2, H) ? 1 : 0;
+}
+
+// One rollout / evaluation step of make_gru_actor_critic's network (networks/factories.py;
+// recurrent contract networks/recurrent.py:89-161): normaliser -> Dense(K0 -> H, relu) ->
+// GRU(H -> H) -> Dense(H -> 2A) -> NormalTanhSampler beside the value trunk, ONE launch
+// (gru_policy_ws_kernel).  w_in / w_proj / w_out: forward fragment-major images of the three
+// Dense-like kernels (the GRU's input projection [H, 3H] with columns r | z | n); w_h: the
+// fp32 recurrent kernel [H, 3H]; h_in / h_out: the carry [M, H] (h_out is also the GRU's
+// output).  Sampler arguments and outputs as mi_policy_fwd_bf16 (mean_and_std optional).
+// Bit-identical to the generic containers' seven launches.
+extern "C" int mi_gru_policy_step_bf16(
+    const float* obs, int64_t M, int64_t K0, int64_t H, int64_t A2, const float* norm_mean,
+    const float* norm_m2, const float* norm_count, float norm_eps, const void* w_in,
+    const float* b_in, const void* w_proj, const float* b_proj, const float* w_h,
+    const float* b_hn, const void* w_out, const float* b_out, const float* h_in, float* h_out,
+    int64_t Lc, const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const uint64_t* rng_state, uint64_t offset_add, const float* eps,
+    const float* eps2, float min_std, float std_scale, float entropy_weight, int deterministic,
+    float* mean_and_std, float* raw_out, float* action, float* loglik, float* reg,
+    float* mu_out, float* sigma_out, float* value, mi_stream_t stream) {
+  const char* who = "mi_gru_policy_step_bf16";
+  MI_REQUIRE(M >= 0, "%s: bad M", who);
+  if (M == 0) return 0;
+  MI_REQUIRE(obs && w_in && w_proj && w_h && w_out && h_in && h_out && value && c_dims && c_acts,
+             "%s: null pointer", who);
+  MI_REQUIRE(mi_gru_policy_step_supported(K0, H, A2, Lc, c_dims, c_acts),
+             "%s: network outside the supported class", who);
+  MI_REQUIRE(!norm_mean || (norm_m2 && norm_count), "%s: incomplete normaliser", who);
+  MI_REQUIRE(rng_state || (eps && eps2), "%s: need rng_state or both injected noises", who);
+  MI_REQUIRE(al16(w_in) && al16(w_proj) && al16(w_out) && al16(h_in) && al16(h_out) &&
+                 al16(b_in) && al16(b_proj) && al16(b_hn),
+             "%s: buffers must be 16-byte aligned", who);
+  hipStream_t st = mippo::as_stream(stream);
+  WsChain a = {};
+  a.x = obs;
+  a.M = a.M_head = M;
+  a.K0 = (int)K0;
+  a.N_out = (int)A2;
+  a.out = mean_and_std;
+  a.layer[0].w = static_cast<const bf16_t*>(w_in);
+  a.layer[0].bias = b_in;
+  a.layer[1].w = static_cast<const bf16_t*>(w_proj);
+  a.layer[1].bias = b_proj;
+  a.layer[2].w = static_cast<const bf16_t*>(w_out);
+  a.layer[2].bias = b_out;
+  a.norm_mean = norm_mean;
+  a.norm_m2 = norm_m2;
+  a.norm_count = norm_count;
+  a.norm_eps = norm_eps;
+  a.samp = {nullptr, {rng_state, offset_add, eps, eps2}, raw_out, action, mu_out, sigma_out,
+            loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
+  const GruStepExtra gx = {w_h, b_hn, h_in, h_out};
+  WsChain v;
+  int rc = ws_fill(v, who, obs, M, Lc, c_w, c_bias, c_dims, c_acts, value, nullptr, nullptr);
+  if (rc) return rc;
+  v.norm_mean = norm_mean;
+  v.norm_m2 = norm_m2;
+  v.norm_count = norm_count;
+  v.norm_eps = norm_eps;
+  constexpr int RT = 2;
+  MI_REQUIRE(16 * RT * A2 <= 4096, "%s: 2A too wide for the sampler stash", who);
+  int64_t nv, na;
+  ws_dual_split(mippo::ceil_div(M, 16 * RT), mippo::ceil_div(M, 16 * RT), &nv, &na);
+  const int64_t hv = c_dims[1], nhv = Lc - 2;
+#define X(p, q, r)                                                                          \
+  if (hv == p && nhv == q && H == r) {                                                      \
+    hipLaunchKernelGGL((gru_policy_ws_kernel<p, q, r, RT>), dim3((unsigned)(nv + na)),      \
+                       dim3(kWsThreads), 0, st, a, gx, v, (int)nv);                         \
+    return mippo::check_launch(who);                                                        \
+  }
+  GRU_STEP_MENU(X)
+#undef X
+  MI_REQUIRE(false, "%s: no instantiation", who);
+}
 
 // 1 if mi_policy_ws_fwd_bf16 runs these two trunks as ONE launch (at any size; required
 // below 8192 rows, where the one-launch-per-trunk form is not used).

@@ -115,5 +115,9 @@ def make_gru_actor_critic(
                                 std_scale=std_scale)
     adapter = PPOAdapter(action=Sequential([*actor_layers, sampler]), value=critic)
     if normalize_obs:
-        return Sequential([Normalizer(obs_size), adapter])
+        # the same module tree; `GRUActorCritic` is a `Sequential` that evaluates a rollout
+        # step of this particular tree in one launch on the bf16 path (networks/policy.py)
+        from .policy import GRUActorCritic
+
+        return GRUActorCritic([Normalizer(obs_size), adapter])
     return adapter

@@ -365,3 +365,105 @@ class MLPActorCritic(Sequential):
             dense_chain.backward(a_layers, a_ctx, g_ms)
             dense_chain.backward(c_layers, v_ctx, g_v)
         return None
+
+
+class GRUActorCritic(Sequential):
+    """The network `make_gru_actor_critic` builds — `Sequential([Normalizer, PPOAdapter(
+    action=Sequential([Dense, GRU, Dense, NormalTanhSampler]), value=Sequential([Dense..]))])`
+    — with its ROLLOUT / evaluation step as one launch on the bf16 path
+    (`mi_gru_policy_step_bf16`).  A single step of a recurrent actor is row-local like an
+    MLP's, so normaliser, both Dense layers, the GRU's input projection, its recurrent product
+    and gate arithmetic and the sampler run on one row tile with every weight in registers,
+    beside the value trunk: one launch for the generic containers' seven.  Module tree,
+    parameters, carry / extras / metrics structure are the plain `Sequential`'s; the loss
+    replay (whole sequences, BPTT) stays on the sequence kernels of networks/recurrent.py.
+    Anything outside the pattern goes through the generic container path."""
+
+    def __init__(self, layers):
+        super().__init__(layers)
+        assert len(self.layers) == 2 and isinstance(self.layers[-1], PPOAdapter)
+        self._norm = self.layers[0]
+        self._adapter = self.layers[-1]
+
+    def _parts(self):
+        a = self._adapter.action.layers
+        return a[0], a[1], a[2], a[3], self._adapter.value.layers
+
+    def _fusable(self, obs) -> bool:
+        from .recurrent import GRU
+
+        if not FUSED or config.compute_dtype() != "bf16":
+            return False
+        if not (isinstance(obs, torch.Tensor) and obs.dim() == 2 and obs.is_cuda
+                and obs.dtype == torch.float32):
+            return False
+        n = self._norm
+        if not (isinstance(n, Normalizer) and isinstance(n.mean.value, torch.Tensor)
+                and n.mean.value.dim() == 1):
+            return False
+        act, val = self._adapter.action, self._adapter.value
+        if not (isinstance(act, Sequential) and isinstance(val, Sequential)
+                and len(act.layers) == 4):
+            return False
+        d_in, gru, d_out, sampler, c_layers = self._parts()
+        if not (type(d_in) is Dense and type(gru) is GRU and type(d_out) is Dense
+                and type(sampler) is NormalTanhSampler and c_layers
+                and all(type(l) is Dense for l in c_layers)):
+            return False
+        if d_in.act_code != ops.ACT_RELU or d_out.act_code != ops.ACT_NONE:
+            return False
+        if d_in.bias is None or d_out.bias is None or not gru._mfma():
+            return False
+        H = gru.hidden_features
+        if d_in.out_features != H or gru.in_features != H or d_out.in_features != H:
+            return False
+        key = (obs.shape[1], H, d_out.out_features,
+               tuple(l.out_features for l in c_layers), tuple(l.act_code for l in c_layers))
+        cache = self.__dict__.setdefault("_step_cache", {})
+        if key not in cache:
+            cache[key] = ops.gru_policy_step_supported(
+                obs.shape[1], H, d_out.out_features,
+                [c_layers[0].in_features] + [l.out_features for l in c_layers],
+                [l.act_code for l in c_layers])
+        return cache[key]
+
+    def __call__(self, network_state, obs: Any, rollout_extras: Any = None):
+        if rollout_extras is not None or not self._fusable(obs):
+            return super().__call__(network_state, obs, rollout_extras)
+        d_in, gru, d_out, sampler, c_layers = self._parts()
+        proj = gru._proj()
+        dense_chain.refresh([d_in, proj, d_out, *c_layers])  # one launch for all of them
+        n = self._norm
+        M = obs.shape[0]
+        A = d_out.out_features // 2
+        a_state = network_state[-1]["action"]
+        v_state = network_state[-1]["value"]
+        h = a_state[1]
+        eps, eps2 = sampler._noise(M, A, obs.device)
+        r = ops.gru_policy_step(
+            obs if obs.is_contiguous() else obs.contiguous(),
+            (n.mean.value, n.M2.value, n.counter.value, n.epsilon),
+            (d_in._ff, d_in.bias.data), (proj._ff, proj.bias.data if proj.bias is not None
+                                         else None),
+            gru.w_h.data, gru.b_hn.data, (d_out._ff, d_out.bias.data),
+            h if h.is_contiguous() else h.contiguous(),
+            ([l._ff for l in c_layers], [dense_chain._bias(l) for l in c_layers],
+             [c_layers[0].in_features] + [l.out_features for l in c_layers],
+             [l.act_code for l in c_layers]),
+            sampler._state(obs.device), sampler._next_offset(),
+            deterministic=sampler.deterministic, eps=eps, eps2=eps2, **sampler._kw())
+        value = r["value"]
+        if value.shape[-1] == 1:
+            value = value.squeeze(-1)
+        next_action = list(a_state)
+        next_action[1] = r["h"]
+        a_metrics = {0: {}, 1: {}, 2: {}, 3: {"mu": r["mu"], "sigma": r["sigma"]}}
+        return StatefulModuleOutput(
+            next_state=[(), {"action": next_action, "value": list(v_state)}],
+            output=PPONetworkOutput(actions=r["action"], loglikelihoods=r["log_likelihood"],
+                                    value_estimates=value),
+            regularization_loss=r["reg"],
+            metrics={0: {}, 1: {"action": a_metrics,
+                                "value": {i: {} for i in range(len(c_layers))}}},
+            rollout_extras=[obs, {"action": [None, None, None, r["raw"]],
+                                  "value": [None] * len(c_layers)}])

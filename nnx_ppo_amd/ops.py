@@ -716,6 +716,55 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
     return out
 
 
+def gru_policy_step_supported(K0: int, H: int, A2: int, c_dims: list, c_acts: list) -> bool:
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    return bool(lib().mi_gru_policy_step_supported(int(K0), int(H), int(A2), len(c_acts),
+                                                   i64s(c_dims), i64s(c_acts)))
+
+
+def gru_policy_step(obs: torch.Tensor, norm, dense_in, proj, w_h: torch.Tensor,
+                    b_hn: torch.Tensor, dense_out, h_in: torch.Tensor, critic, rng_state,
+                    offset_add: int, *, min_std: float, std_scale: float,
+                    entropy_weight: float, deterministic: bool, eps=None, eps2=None):
+    """One rollout step of the recurrent actor-critic in ONE launch
+    (`mi_gru_policy_step_bf16`).  `dense_in` / `proj` / `dense_out` = (forward fragment
+    image, bias); `critic` = (frag images, biases, dims, acts).  Returns a dict: h, raw,
+    action, log_likelihood, reg, mu, sigma, value."""
+    M, K0 = obs.shape
+    H = h_in.shape[1]
+    dev = obs.device
+    c_w, c_b, c_dims, c_acts = critic
+    Lc = len(c_w)
+    A2 = dense_out[1].shape[0] if dense_out[1] is not None else None
+    _need(A2 is not None, "gru_policy_step: the output layer needs a bias vector (its width)")
+    A = A2 // 2
+    _need(h_in.shape == (M, H) and h_in.is_contiguous() and w_h.shape == (H, 3 * H),
+          "gru_policy_step: carry [M, H] and recurrent kernel [H, 3H]")
+    mk = lambda *sh: torch.empty(*sh, dtype=f32, device=dev)
+    h_out, raw, action = mk(M, H), mk(M, A), mk(M, A)
+    ll, reg, mu, sigma = mk(M), mk(M), mk(M, A), mk(M, A)
+    value = mk(M, c_dims[-1])
+    P = ctypes.c_void_p * Lc
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    n_mean, n_m2, n_cnt, n_eps = norm if norm is not None else (None, None, None, 0.0)
+    if profiler.active:
+        flop = K0 * H + 6 * H * H + H * A2 + sum(c_dims[l] * c_dims[l + 1] for l in range(Lc))
+        profiler.next_flops = 2.0 * M * flop
+        profiler.next_bytes = 4.0 * M * (K0 + 2 * H + 4 * A + 3)
+    check(lib().mi_gru_policy_step_bf16(
+        ptr(obs, f32), M, K0, H, A2, ptr(n_mean, f32), ptr(n_m2, f32), ptr(n_cnt, f32),
+        float(n_eps), ptr(dense_in[0], bf16), ptr(dense_in[1], f32), ptr(proj[0], bf16),
+        ptr(proj[1], f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(dense_out[0], bf16),
+        ptr(dense_out[1], f32), ptr(h_in, f32), ptr(h_out, f32),
+        Lc, P(*[ptr(t) for t in c_w]), P(*[ptr(t) for t in c_b]), i64s(c_dims), i64s(c_acts),
+        ptr(rng_state), int(offset_add), ptr(eps, f32), ptr(eps2, f32), float(min_std),
+        float(std_scale), float(entropy_weight), int(bool(deterministic)), None,
+        ptr(raw, f32), ptr(action, f32), ptr(ll, f32), ptr(reg, f32), ptr(mu, f32),
+        ptr(sigma, f32), ptr(value, f32), stream()), "mi_gru_policy_step_bf16")
+    return dict(h=h_out, raw=raw, action=action, log_likelihood=ll, reg=reg, mu=mu, sigma=sigma,
+                value=value)
+
+
 def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float,
                     g_value, actor, critic, *, min_std: float, std_scale: float,
                     entropy_weight: float, eps2=None, ws: bool = False):

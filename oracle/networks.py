@@ -573,7 +573,8 @@ def from_product(net: Any, dtype=DTYPE) -> Module:
     """Build the oracle twin of a product network by duck-typing on class names
     and copying its weights / statistics / noise seeds (no product import)."""
     name = type(net).__name__
-    if name in ("Sequential", "MLPActorCritic"):  # the latter is a Sequential (policy.py)
+    # (MLPActorCritic / GRUActorCritic are Sequentials with a fused evaluation: policy.py)
+    if name in ("Sequential", "MLPActorCritic", "GRUActorCritic"):
         return Sequential([from_product(l, dtype) for l in net.layers])
     if name == "PPOAdapter":
         return PPOAdapter(from_product(net.action, dtype), from_product(net.value, dtype))

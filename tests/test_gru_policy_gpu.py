@@ -1,0 +1,118 @@
+"""The recurrent actor-critic's rollout step as ONE launch (`mi_gru_policy_step_bf16`,
+networks/policy.py:GRUActorCritic) against the generic containers it replaces — normaliser,
+Dense, the GRU's projection + recurrent step (gru_mfma.hip), Dense, sampler, value trunk:
+the same operand roundings, k-order and expressions, so every output must be BIT-identical."""
+import pytest
+import torch
+
+from nnx_ppo_amd import config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16():
+    prev = config.compute_dtype()
+    config.set_compute_dtype("bf16")
+    yield
+    config.set_compute_dtype(prev)
+
+
+def _net(dev, obs, act, H, critic_h, seed=3):
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+
+    net = factories.make_gru_actor_critic(obs, act, H, critic_h, Rngs(seed))
+    net.to(dev)
+    n = net.layers[0]
+    g = torch.Generator().manual_seed(seed)
+    n.mean.value.copy_(torch.randn(obs, generator=g))
+    n.M2.value.copy_(torch.rand(obs, generator=g) * 50 + 1)
+    n.counter.value.fill_(37.0)
+    # non-zero biases everywhere (they initialise to zero)
+    for p in net.parameters():
+        if len(p.shape) == 1:
+            p.data.copy_(torch.randn(p.shape[0], generator=g) * 0.3)
+    return net
+
+
+def _leaves(x):
+    from nnx_ppo_amd.tree import tree_leaves
+
+    return [t for t in tree_leaves(x) if isinstance(t, torch.Tensor)]
+
+
+@pytest.mark.parametrize("M", [1, 100, 4096])
+@pytest.mark.parametrize("shape", [(5, 1, 64, [256, 256]), (17, 3, 128, [128, 128]),
+                                   (9, 2, 64, [64, 64])])
+def test_gru_rollout_step_is_bit_identical_to_generic(dev, bf16, M, shape):
+    from nnx_ppo_amd import _lib
+    from nnx_ppo_amd.networks.containers import Sequential
+    from nnx_ppo_amd.networks.policy import GRUActorCritic
+
+    obs_dim, act_dim, H, ch = shape
+    net = _net(dev, obs_dim, act_dim, H, ch)
+    assert isinstance(net, GRUActorCritic)
+    g = torch.Generator().manual_seed(M)
+    smp = net.layers[-1].action.layers[-1]
+    state_f = state_p = net.initialize_state(M)
+    # a non-zero carry to start from
+    h0 = torch.randn(M, H, generator=g).to(dev)
+    state_f = [(), {"action": [(), h0.clone(), (), ()], "value": list(state_f[-1]["value"])}]
+    state_p = [(), {"action": [(), h0.clone(), (), ()], "value": list(state_p[-1]["value"])}]
+    for step in range(3):  # the carry is threaded through
+        x = torch.randn(M, obs_dim, generator=g).to(dev)
+        smp.deterministic = step == 2
+        smp._pending = 5 + step
+        with _lib.profiler as prof:
+            fused = net(state_f, x)
+        assert "mi_gru_policy_step_bf16" in [r[0] for r in prof.records]
+        assert not any(r[0].startswith("mi_gru_seq") for r in prof.records)
+        smp._pending = 5 + step
+        plain = Sequential.__call__(net, state_p, x)
+        for name in ("next_state", "output", "regularization_loss", "metrics", "rollout_extras"):
+            a, b = _leaves(getattr(fused, name)), _leaves(getattr(plain, name))
+            assert len(a) == len(b) and (len(a) > 0), name
+            for u, v in zip(a, b):
+                assert u.shape == v.shape and torch.equal(u, v), (name, step)
+        state_f, state_p = fused.next_state, plain.next_state
+    torch.cuda.synchronize()
+
+
+def test_gru_ppo_step_fused_rollout_equals_generic(dev, bf16):
+    """A whole iteration (rollout with resets, replay, BPTT, update) with the one-launch
+    rollout step == the same iteration through the generic containers."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import factories, policy
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    outs = []
+    for fused in (True, False):
+        policy.FUSED = fused
+        try:
+            env = EpisodeWrapper(MockEnv(5, 1, max_steps=5), 40)
+            net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(17))
+            ts = ppo.new_training_state(env, net, 256, 17, 1e-3, device=dev)
+            for _ in range(2):
+                ts, m = ppo.ppo_step(env, ts, 256, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
+            outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()},
+                         [t.clone() for t in _leaves(ts.network_states)]))
+        finally:
+            policy.FUSED = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+
+
+def test_gru_step_support_query(dev):
+    from nnx_ppo_amd import ops
+
+    R, N = ops.ACT_RELU, ops.ACT_NONE
+    assert ops.gru_policy_step_supported(5, 64, 2, [5, 256, 256, 1], [R, R, N])
+    assert ops.gru_policy_step_supported(17, 128, 6, [17, 128, 128, 1], [R, R, N])
+    assert not ops.gru_policy_step_supported(5, 96, 2, [5, 256, 256, 1], [R, R, N])   # width
+    assert not ops.gru_policy_step_supported(40, 64, 2, [40, 256, 256, 1], [R, R, N])  # K0 <= 32
+    assert not ops.gru_policy_step_supported(5, 64, 2, [5, 512, 1], [R, N])           # value trunk
