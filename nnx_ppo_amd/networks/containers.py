@@ -114,6 +114,27 @@ class Sequential(StatefulModule):
                 from . import dense_chain
 
                 j = runs[i]
+                # a recurrent layer right behind the run: its input projection rides in the
+                # run's launch as one more (linear) layer
+                rec = self.layers[j] if j < n else None
+                proj = getattr(rec, "chain_projection", lambda: None)() if rec is not None else None
+                if proj is not None and x.dim() == 3:
+                    lead = x.shape[:-1]
+                    x2 = x.reshape(-1, x.shape[-1])
+                    chain = list(self.layers[i:j]) + [proj]
+                    cctx, gi2 = dense_chain.forward_train(
+                        chain, x2 if x2.is_contiguous() else x2.contiguous(), upstream_needs)
+                    layer_extras = None if extras_seq is None else extras_seq[j]
+                    rctx, x, r, fs = rec.replay(state0[j], None, done_seq, layer_extras,
+                                                need_input_grad=True,
+                                                gi_seq=gi2.view(*lead, gi2.shape[-1]))
+                    ctxs.append(("chain+rec", i, j, cctx, lead, rctx))
+                    final_state.extend(state0[i:j])
+                    final_state.append(fs)
+                    reg = add_reg(reg, r)
+                    upstream_needs = True
+                    i = j + 1
+                    continue
                 lead = x.shape[:-1]
                 x2 = x.reshape(-1, x.shape[-1])
                 cctx, y = dense_chain.forward_train(
@@ -139,7 +160,17 @@ class Sequential(StatefulModule):
     def replay_backward(self, ctxs, g_out, g_reg):
         g = g_out
         for entry in reversed(ctxs):
-            if entry[0] == "chain":
+            if entry[0] == "chain+rec":
+                from . import dense_chain
+
+                _, i, j, cctx, lead, rctx = entry
+                rec = self.layers[j]
+                dgi = rec.replay_backward(rctx, g, g_reg)
+                d2 = dgi.reshape(-1, dgi.shape[-1])
+                gi = dense_chain.backward(list(self.layers[i:j]) + [rec.chain_projection()], cctx,
+                                          d2 if d2.is_contiguous() else d2.contiguous())
+                g = None if gi is None else gi.view(*lead, gi.shape[-1])
+            elif entry[0] == "chain":
                 from . import dense_chain
 
                 _, i, j, cctx, lead = entry

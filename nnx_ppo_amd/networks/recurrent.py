@@ -97,21 +97,35 @@ class GRU(StatefulModule):
         return constant(prev_state.shape, prev_state.dtype, 0.0, prev_state.device)
 
     # ---- training protocol --------------------------------------------------------
-    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
-        T, B, _ = x_seq.shape
+    def chain_projection(self):
+        """The input projection as a Dense-like layer a preceding run of Dense layers can
+        take into its own launch (`containers.Sequential.replay`), or None when the
+        projection does not run on the bf16 trunk kernels."""
+        return self._proj() if self._mfma() else None
+
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None):
+        """`gi_seq` [T, B, 3H]: the input projection, already evaluated by the caller as the
+        last layer of the preceding Dense chain (`x_seq` is then unused and
+        `replay_backward` returns the gradient w.r.t. `gi_seq`)."""
         H = self.hidden_features
-        x2 = x_seq.reshape(T * B, self.in_features)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
         mfma = self._mfma()
         pctx = None
-        if mfma:
-            from . import dense_chain
-
-            pctx, gi2 = dense_chain.forward_train([self._proj()], x2, need_input_grad)
-            gi = gi2.view(T, B, 3 * H)
+        if gi_seq is not None:
+            T, B, _ = gi_seq.shape
+            x2, pctx = None, "external"
+            gi = gi_seq if gi_seq.is_contiguous() else gi_seq.contiguous()
         else:
-            gi = self._gi(x2).view(T, B, 3 * H)
+            T, B, _ = x_seq.shape
+            x2 = x_seq.reshape(T * B, self.in_features)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            if mfma:
+                from . import dense_chain
+
+                pctx, gi2 = dense_chain.forward_train([self._proj()], x2, need_input_grad)
+                gi = gi2.view(T, B, 3 * H)
+            else:
+                gi = self._gi(x2).view(T, B, 3 * H)
         h_out, h_prev, gates, h_final = ops.gru_seq_fwd(
             gi, self.w_h.data, self.b_hn.data, state0.contiguous(), done_seq.contiguous(),
             train=True, mfma=mfma)
@@ -133,6 +147,8 @@ class GRU(StatefulModule):
                 [(ops.cast_pad_bf16(h_prev.view(T * B, H)), ops.cast_pad_bf16(dgh2),
                   self.w_h.grad, gb_h)], accumulate=True)
             self.b_hn.grad += gb_h[2 * H:]
+            if isinstance(pctx, str):  # the projection belongs to the caller's chain
+                return dgi
             g_x = dense_chain.backward([self._proj()], pctx, dgi2)
             return None if g_x is None else g_x.view(T, B, self.in_features)
         gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
