@@ -322,14 +322,18 @@ int mi_gru_seq_bwd_f32(const float* g_h, const float* gates, const float* h_prev
 
 /* The same recurrence and BPTT with h W_h (dgh W_h^T) on the bf16 matrix cores
  * (operands rounded to bf16, fp32 accumulation, fp32 cell arithmetic and carry):
- * same arguments as mi_gru_seq_fwd_f32 / mi_gru_seq_bwd_f32; H in {32, 64, 96, 128};
- * h_prev_out and gates_out are both null (inference) or both given (training). */
+ * the arguments of mi_gru_seq_fwd_f32 / mi_gru_seq_bwd_f32; H in {32, 64, 96, 128};
+ * h_prev_out and gates_out are both null (inference) or both given (training).  Two more,
+ * nullable: h_prev_bf [T*B, H] / dgh_bf [T*B, 3H] receive the bf16 images of h_prev / dgh —
+ * the operands of the recurrent kernel's dW launch, which otherwise cost a cast launch
+ * each; with dgh_bf the fp32 dgh may be null. */
 int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const float* b_hn, const float* h0,
                         const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out,
-                        float* h_final, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+                        float* h_final, void* h_prev_bf, int64_t T, int64_t B, int64_t H,
+                        mi_stream_t stream);
 int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_prev,
                         const float* w_h, const uint8_t* done, float* dgi, float* dgh, float* dh0,
-                        int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+                        void* dgh_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
 
 /* ---- f2: LSTM carry (`nnx_ppo/networks/recurrent.py:16-161`) -------------- */
 

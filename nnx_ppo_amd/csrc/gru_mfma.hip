@@ -44,7 +44,8 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
                     const uint8_t* __restrict__ done, float* __restrict__ h_out,
                     float* __restrict__ h_prev_out, float* __restrict__ gates_out,
-                    float* __restrict__ h_final, int64_t T, int64_t B, int H) {
+                    float* __restrict__ h_final, bf16_t* __restrict__ h_prev_bf, int64_t T,
+                    int64_t B, int H) {
   constexpr int PFW = UTW == 1 ? PF : PF / 2;  // look-ahead that still fits the registers
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int HROW = H + 8;
@@ -147,6 +148,8 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     float* ho = h_out + t * B * H;
     float* hpo = TRAIN ? h_prev_out + t * B * H : nullptr;
     float* gto = TRAIN ? gates_out + t * B * 4 * H : nullptr;
+    // bf16 image of h_prev [T*B][H]: the x operand of the recurrent kernel's dW launch
+    bf16_t* hpb = (TRAIN && h_prev_bf) ? h_prev_bf + t * B * H : nullptr;
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       if (wave + 4 * ui >= UT) continue;  // wave-uniform
@@ -163,6 +166,7 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
           ho[o] = hnew;
           if constexpr (TRAIN) {
             hpo[o] = hp;
+            if (hpb) hpb[o] = (bf16_t)hp;
             const unsigned og = rowc[e] * (unsigned)(4 * H) + unit[ui];
             gto[og] = r;
             gto[og + (unsigned)H] = z;
@@ -202,8 +206,8 @@ __global__ void __launch_bounds__(kThreads)
 gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
                     const float* __restrict__ h_prev, const float* __restrict__ w_h,
                     const uint8_t* __restrict__ done, float* __restrict__ dgi,
-                    float* __restrict__ dgh, float* __restrict__ dh0, int64_t T, int64_t B,
-                    int H) {
+                    float* __restrict__ dgh, float* __restrict__ dh0,
+                    bf16_t* __restrict__ dgh_bf, int64_t T, int64_t B, int H) {
   constexpr int PFW = UTW == 1 ? PF : 1;  // 2 unit tiles: no registers left for a ring
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int H3 = 3 * H;
@@ -286,7 +290,9 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
   auto step = [&](int64_t t, In& in) {
     float dhp[UTW][4];
     float* gio = dgi + t * B * H3;
-    float* gho = dgh + t * B * H3;
+    float* gho = dgh ? dgh + t * B * H3 : nullptr;
+    // bf16 image of dgh [T*B][3H]: the dz operand of the recurrent kernel's dW launch
+    bf16_t* ghb = dgh_bf ? dgh_bf + t * B * H3 : nullptr;
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       if (wave + 4 * ui >= UT) continue;  // wave-uniform
@@ -310,9 +316,16 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
           gio[o3] = da_r;
           gio[o3 + (unsigned)H] = da_z;
           gio[o3 + (unsigned)(2 * H)] = da_n;
-          gho[o3] = da_r;
-          gho[o3 + (unsigned)H] = da_z;
-          gho[o3 + (unsigned)(2 * H)] = dgn;
+          if (gho) {
+            gho[o3] = da_r;
+            gho[o3 + (unsigned)H] = da_z;
+            gho[o3 + (unsigned)(2 * H)] = dgn;
+          }
+          if (ghb) {
+            ghb[o3] = (bf16_t)da_r;
+            ghb[o3 + (unsigned)H] = (bf16_t)da_z;
+            ghb[o3 + (unsigned)(2 * H)] = (bf16_t)dgn;
+          }
         } else {
           da_r = da_z = dgn = dp = 0.0f;
         }
@@ -367,7 +380,8 @@ bool mfma_shape_ok(int64_t H) { return H >= 32 && H <= 128 && H % 32 == 0; }
 extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const float* b_hn,
                                    const float* h0, const uint8_t* done, float* h_out,
                                    float* h_prev_out, float* gates_out, float* h_final,
-                                   int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
+                                   void* h_prev_bf, int64_t T, int64_t B, int64_t H,
+                                   mi_stream_t stream) {
   MI_REQUIRE(T >= 0 && B >= 0 && mfma_shape_ok(H) && B * 4 * H < (1LL << 31),
              "mi_gru_seq_fwd_bf16: bad shape T=%lld B=%lld H=%lld (H in {32, 64, 96, 128})",
              (long long)T, (long long)B, (long long)H);
@@ -382,7 +396,8 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
   hipStream_t st = mippo::as_stream(stream);
 #define MI_GRU_FWD(TRAIN, UTW)                                                                  \
   hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, UTW>), grid, dim3(kThreads), lds, st, gi, w_h, \
-                     b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, T, B, (int)H)
+                     b_hn, h0, done, h_out, h_prev_out, gates_out, h_final,                      \
+                     static_cast<bf16_t*>(h_prev_bf), T, B, (int)H)
   if (h_prev_out) {
     if (H <= 64) MI_GRU_FWD(true, 1); else MI_GRU_FWD(true, 2);
   } else {
@@ -394,20 +409,21 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
 
 extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_prev,
                                    const float* w_h, const uint8_t* done, float* dgi, float* dgh,
-                                   float* dh0, int64_t T, int64_t B, int64_t H,
+                                   float* dh0, void* dgh_bf, int64_t T, int64_t B, int64_t H,
                                    mi_stream_t stream) {
   MI_REQUIRE(T >= 1 && B >= 1 && mfma_shape_ok(H) && B * 4 * H < (1LL << 31),
              "mi_gru_seq_bwd_bf16: bad shape");
-  MI_REQUIRE(g_h && gates && h_prev && w_h && dgi && dgh, "mi_gru_seq_bwd_bf16: null pointer");
+  MI_REQUIRE(g_h && gates && h_prev && w_h && dgi && (dgh || dgh_bf),
+             "mi_gru_seq_bwd_bf16: null pointer (dgh or its bf16 image is required)");
   const size_t lds = (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t);
   const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
   hipStream_t st = mippo::as_stream(stream);
   if (H <= 64) {
     hipLaunchKernelGGL((gru_bwd_mfma_kernel<1>), grid, dim3(kThreads), lds, st, g_h, gates, h_prev,
-                       w_h, done, dgi, dgh, dh0, T, B, (int)H);
+                       w_h, done, dgi, dgh, dh0, static_cast<bf16_t*>(dgh_bf), T, B, (int)H);
   } else {
     hipLaunchKernelGGL((gru_bwd_mfma_kernel<2>), grid, dim3(kThreads), lds, st, g_h, gates, h_prev,
-                       w_h, done, dgi, dgh, dh0, T, B, (int)H);
+                       w_h, done, dgi, dgh, dh0, static_cast<bf16_t*>(dgh_bf), T, B, (int)H);
   }
   return mippo::check_launch("mi_gru_seq_bwd_bf16");
 }

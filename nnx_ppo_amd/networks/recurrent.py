@@ -136,21 +136,27 @@ class GRU(StatefulModule):
         x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx
         H = self.hidden_features
         dgi, dgh = ops.gru_seq_bwd(g_out.contiguous(), gates, h_prev, self.w_h.data,
-                                   done_seq.contiguous(), mfma=mfma)
-        dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)
+                                   done_seq.contiguous(), mfma=mfma, dgh_as_bf16=mfma)
+        dgi2 = dgi.view(T * B, 3 * H)
         if mfma:
-            # bf16 compute: weight gradients on the bf16 matrix cores too
+            # bf16 compute: weight gradients on the bf16 matrix cores too; the sequence
+            # kernels left the bf16 images of both operands (no cast launches)
             from . import dense_chain
 
+            hp_bf = getattr(h_prev, "bf16_image", None)
+            if hp_bf is None:
+                hp_bf = ops.cast_pad_bf16(h_prev.view(T * B, H))
+            dgh_bf = dgh if dgh.dtype == torch.bfloat16 else ops.cast_pad_bf16(
+                dgh.view(T * B, 3 * H))
             gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
-            ops.dense_bwd_dw_grouped_bf16(
-                [(ops.cast_pad_bf16(h_prev.view(T * B, H)), ops.cast_pad_bf16(dgh2),
-                  self.w_h.grad, gb_h)], accumulate=True)
+            ops.dense_bwd_dw_grouped_bf16([(hp_bf, dgh_bf, self.w_h.grad, gb_h)],
+                                          accumulate=True)
             self.b_hn.grad += gb_h[2 * H:]
             if isinstance(pctx, str):  # the projection belongs to the caller's chain
                 return dgi
             g_x = dense_chain.backward([self._proj()], pctx, dgi2)
             return None if g_x is None else g_x.view(T, B, self.in_features)
+        dgh2 = dgh.view(T * B, 3 * H)
         gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
         ops.dense_bwd_dw(h_prev.view(T * B, H), dgh2, None, self.w_h.grad, gb_h, ops.ACT_NONE,
                          accumulate=True)

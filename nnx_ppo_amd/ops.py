@@ -1319,7 +1319,8 @@ def gru_mfma_ok(H: int) -> bool:
 
 def gru_seq_fwd(gi, w_h, b_hn, h0, done, train: bool, mfma: bool = False):
     """gi [T,B,3H] -> (h_out [T,B,H], h_prev | None, gates | None, h_final [B,H]).
-    `mfma`: h W_h on the bf16 matrix cores (`mi_gru_seq_fwd_bf16`)."""
+    `mfma`: h W_h on the bf16 matrix cores (`mi_gru_seq_fwd_bf16`); training then also
+    leaves the bf16 image of h_prev (the dW operand) in `h_prev.bf16_image` [T*B, H]."""
     T, B, H3 = gi.shape
     H = H3 // 3
     _need(w_h.shape == (H, H3) and b_hn.shape == (H,) and h0.shape == (B, H), "gru_seq_fwd: shapes")
@@ -1331,24 +1332,43 @@ def gru_seq_fwd(gi, w_h, b_hn, h0, done, train: bool, mfma: bool = False):
     d = None if done is None else _as_u8(done)
     if d is not None:
         _need(d.shape == (T, B), "gru_seq_fwd: done must be [T, B]")
-    fn = lib().mi_gru_seq_fwd_bf16 if mfma else lib().mi_gru_seq_fwd_f32
-    check(fn(ptr(gi, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32), ptr(d), ptr(h_out, f32),
-             ptr(h_prev, f32), ptr(gates, f32), ptr(h_final, f32), T, B, H, stream()),
-          "mi_gru_seq_fwd_bf16" if mfma else "mi_gru_seq_fwd_f32")
+    if mfma:
+        hp_bf = torch.empty(T * B, H, dtype=bf16, device=dev) if (train and H % 8 == 0) else None
+        check(lib().mi_gru_seq_fwd_bf16(
+            ptr(gi, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32), ptr(d), ptr(h_out, f32),
+            ptr(h_prev, f32), ptr(gates, f32), ptr(h_final, f32), ptr(hp_bf), T, B, H, stream()),
+            "mi_gru_seq_fwd_bf16")
+        if hp_bf is not None:
+            h_prev.bf16_image = hp_bf
+        return h_out, h_prev, gates, h_final
+    check(lib().mi_gru_seq_fwd_f32(
+        ptr(gi, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32), ptr(d), ptr(h_out, f32),
+        ptr(h_prev, f32), ptr(gates, f32), ptr(h_final, f32), T, B, H, stream()),
+        "mi_gru_seq_fwd_f32")
     return h_out, h_prev, gates, h_final
 
 
-def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False):
-    """Returns (dgi [T,B,3H], dgh [T,B,3H])."""
+def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False, dgh_as_bf16: bool = False):
+    """Returns (dgi [T,B,3H], dgh [T,B,3H]).  `dgh_as_bf16` (matrix-core path): dgh comes
+    back as its bf16 image [T*B, 3H] — the dz operand of the recurrent kernel's dW launch —
+    and the fp32 tensor is not written."""
     T, B, H = g_h.shape
     dev = g_h.device
     dgi = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
-    dgh = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
     d = None if done is None else _as_u8(done)
-    fn = lib().mi_gru_seq_bwd_bf16 if mfma else lib().mi_gru_seq_bwd_f32
-    check(fn(ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d),
-             ptr(dgi, f32), ptr(dgh, f32), None, T, B, H, stream()),
-          "mi_gru_seq_bwd_bf16" if mfma else "mi_gru_seq_bwd_f32")
+    if mfma:
+        as_bf = dgh_as_bf16 and (3 * H) % 8 == 0
+        dgh = None if as_bf else torch.empty(T, B, 3 * H, dtype=f32, device=dev)
+        dgh_bf = torch.empty(T * B, 3 * H, dtype=bf16, device=dev) if as_bf else None
+        check(lib().mi_gru_seq_bwd_bf16(
+            ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d),
+            ptr(dgi, f32), ptr(dgh, f32), None, ptr(dgh_bf), T, B, H, stream()),
+            "mi_gru_seq_bwd_bf16")
+        return dgi, (dgh_bf if as_bf else dgh)
+    dgh = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
+    check(lib().mi_gru_seq_bwd_f32(
+        ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d),
+        ptr(dgi, f32), ptr(dgh, f32), None, T, B, H, stream()), "mi_gru_seq_bwd_f32")
     return dgi, dgh
 
 
