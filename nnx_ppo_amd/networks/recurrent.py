@@ -311,21 +311,31 @@ class LSTM(StatefulModule):
         return (z(prev_state[0]), z(prev_state[1]))
 
     # ---- training protocol --------------------------------------------------------
-    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
-        T, B, _ = x_seq.shape
+    def chain_projection(self):
+        """As `GRU.chain_projection`: the input projection for a preceding Dense run's launch."""
+        return self._proj() if self._mfma() else None
+
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None):
+        """`gi_seq` [T, B, 4H]: see `GRU.replay`."""
         H = self.hidden_features
-        x2 = x_seq.reshape(T * B, self.in_features)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
         mfma = self._mfma()
         pctx = None
-        if mfma:
-            from . import dense_chain
-
-            pctx, gi2 = dense_chain.forward_train([self._proj()], x2, need_input_grad)
-            gi = gi2.view(T, B, 4 * H)
+        if gi_seq is not None:
+            T, B, _ = gi_seq.shape
+            x2, pctx = None, "external"
+            gi = gi_seq if gi_seq.is_contiguous() else gi_seq.contiguous()
         else:
-            gi = self._gi(x2).view(T, B, 4 * H)
+            T, B, _ = x_seq.shape
+            x2 = x_seq.reshape(T * B, self.in_features)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            if mfma:
+                from . import dense_chain
+
+                pctx, gi2 = dense_chain.forward_train([self._proj()], x2, need_input_grad)
+                gi = gi2.view(T, B, 4 * H)
+            else:
+                gi = self._gi(x2).view(T, B, 4 * H)
         h0, c0 = state0
         kw = {} if mfma else self._cell_kw()
         h_out, h_prev, c_prev, gates, h_f, c_f = ops.lstm_seq_fwd(
@@ -360,6 +370,8 @@ class LSTM(StatefulModule):
             ops.dense_bwd_dw_grouped_bf16(
                 [(ops.cast_pad_bf16(h_prev.view(T * B, H)), ops.cast_pad_bf16(da2),
                   self.w_h.grad, None)], accumulate=True)
+            if isinstance(pctx, str):  # the projection belongs to the caller's chain
+                return da
             g_x = dense_chain.backward([self._proj()], pctx, da2)  # dW_i, db_h, dx
             return None if g_x is None else g_x.view(T, B, self.in_features)
         ops.dense_bwd_dw(h_prev.view(T * B, H), da2, None, self.w_h.grad, self.b_h.grad,
