@@ -761,6 +761,10 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
   const int64_t M = c.M;
   const int N_out = c.N_out;
   const int64_t ntiles = (M + ROWS - 1) / ROWS;
+#ifdef MIPPO_TRACE
+  int ev_ = 0;
+#endif
+  WS_TR();  // 0: start
 
   // ---- the transposed trunk, once -------------------------------------------------------
   bf16x8 WO[TPW];
@@ -794,12 +798,14 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
     }
   };
 
+  WS_TR();  // 1: weights requested
   int64_t tile = bid;
   int stash_n = 0, stash_i = 0;  // SAMP: head-gradient rows of `stash_n` row tiles wait in bufX
   if (tile < ntiles) request_input(tile);
   for (; tile < ntiles; tile += nblk) {
     const int64_t i0 = tile * ROWS;
     const bf16_t* xin = bufX;
+    WS_TR();  // tile + 0
     if constexpr (SAMP) {
       // sampling_layers.py:82-147 differentiated, one thread per row — a long chain of
       // transcendentals whatever the number of rows, so the rows of up to kStashTiles of
@@ -849,7 +855,9 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           auxr[l][r][b] = a;
         }
       }
+    WS_TR();  // tile + 1: head gradient staged, aux requested
     __syncthreads();
+    WS_TR();  // tile + 2
     if (c.dz_last && tid < ROWS && i0 + tid < M) {  // bf16 image of the head's gradient
       const int64_t ldx = c.ldx;
       for (int k = 0; k < (int)ldx; k += 8)
@@ -903,9 +911,13 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               WO[b], af[r], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
+    WS_TR();  // tile + 3: head multiplied
     epilogue(auxr[0], bufA);
+    WS_TR();  // tile + 4: epilogue (waits for the aux loads)
     __syncthreads();
+    WS_TR();  // tile + 5
     copy_out(bufA, c.layer[0].out_bf, c.layer[0].ld);
+    WS_TR();  // tile + 6: copy-out issued
     bf16_t* cur = bufA;
     bf16_t* nxt = bufB;
 #pragma unroll
@@ -928,14 +940,19 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
             acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[l][b][ks], af[r], acc[r][b],
                                                                 0, 0, 0);
       }
+      WS_TR();  // hidden: multiplied
       epilogue(auxr[1 + l], nxt);
+      WS_TR();  // hidden: epilogue
       __syncthreads();
+      WS_TR();
       copy_out(nxt, c.layer[1 + l].out_bf, c.layer[1 + l].ld);
+      WS_TR();  // hidden: copy-out issued
       bf16_t* t = cur;
       cur = nxt;
       nxt = t;
     }
     __syncthreads();  // the buffers are free for the next row tile
+    WS_TR();  // tile end
   }
 }
 
