@@ -556,7 +556,9 @@ int mi_mlp_ws_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* 
 
 /* mi_policy_fwd_bf16 on the weights-stationary kernels (action trunk + sampler, value
  * trunk + bootstrap tail rows; one launch or two, see below): same arguments (mean_and_std
- * is required; the pre-activation arrays are unused: relu trunks), same results bit for bit.
+ * is required; relu trunks keep no pre-activations: a_pre_bf[l] / c_pre_bf[l], when given,
+ * receive the relu' mask of layer l's output instead — see mi_policy_ws_bwd_bf16), same
+ * results bit for bit.
  * mi_policy_ws_supported: both trunks in the shape class of mi_mlp_ws_supported, 2A <= 16. */
 int mi_policy_ws_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts, int64_t Lc,
                            const int64_t* c_dims, const int64_t* c_acts);
@@ -629,7 +631,12 @@ int mi_gru_policy_step_bf16(
 /* Weights-stationary forms of mi_mlp_bwd_dx_bf16 (no input gradient, linear last layer)
  * and mi_policy_bwd_bf16 for training sizes: same operands (w_bf: the BACKWARD
  * fragment-major images; aux[l] = y_l, dz_bf[l] = dz_l for l < L - 1; dz_last = dz_{L-1}),
- * same results bit for bit. */
+ * same results bit for bit.  a_mask / c_mask (both or neither; entry l for l < L - 1): the
+ * relu' masks that mi_policy_ws_fwd_bf16 wrote through its a_pre_bf / c_pre_bf arrays —
+ * uint8 [ceil(rows / 64)][N_l / 16][64][4]: 16 x 16 tile (rt, ct) has the byte at
+ * [rt >> 2][ct][lane][rt & 3], bit e = y_l[16 rt + (lane & 15)][16 ct + 4 (lane >> 4) + e] > 0.
+ * With them the backward reads one byte per lane and tile instead of 8 bytes of the bf16
+ * image (half its HBM bytes). */
 int mi_mlp_ws_bwd_dx_bf16(const float* g_out, int64_t M, int64_t L, const void* const* w_bf,
                           const int64_t* dims, const int64_t* acts, const void* const* aux,
                           void* dz_last, void* const* dz_bf, mi_stream_t stream);
@@ -640,7 +647,8 @@ int mi_policy_ws_bwd_bf16(
     const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
     const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
     const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
-    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf, mi_stream_t stream);
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
+    const void* const* a_mask, const void* const* c_mask, mi_stream_t stream);
 
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
  * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,

@@ -59,6 +59,13 @@ struct WsLayer {
   const float* bias;  // [N] or null
   bf16_t* out_bf;     // [M][ldo] bf16 image of this layer's output, or null
   int64_t ldo;
+  // relu' of this layer's output, 4 bits per lane of the transposed MFMA tile, or null:
+  // 16 x 16 tile (row tile rt, column tile ct) has byte [(((rt >> 2) * N/16 + ct) * 64 + lane)
+  // * 4 + (rt & 3)], bit e = y[16 rt + (lane & 15)][16 ct + 4 (lane >> 4) + e] > 0 — the four
+  // row tiles of a 64-row block side by side, so a wave that owns RTW of them moves RTW bytes
+  // per lane in one access.  The backward reads ONE byte per lane and tile instead of 8 bytes
+  // of the bf16 image (trunk_ws backward, MASK).
+  unsigned char* mask_out;
 };
 
 struct WsChain {
@@ -85,6 +92,30 @@ struct WsChain {
 __device__ inline bf16x8 ws_frag(const bf16_t* w, unsigned ct, unsigned ks, unsigned KS, int lane) {
   const char* p = reinterpret_cast<const char*>(w) + (((size_t)ct * KS + ks) << 10) + lane * 16;
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+
+// relu' masks (WsLayer::mask_out): the RTW bytes of row tiles rt0 .. rt0 + RTW - 1 (rt0 a
+// multiple of RTW, RTW in {1, 2, 4}) of column tile ct, for this lane, as one access.
+template <int RTW>
+__device__ inline size_t ws_mask_index(int64_t rt0, int n_ct, int ct, int lane) {
+  static_assert(RTW == 1 || RTW == 2 || RTW == 4, "a wave owns 1, 2 or 4 row tiles");
+  return (size_t)((((rt0 >> 2) * n_ct + ct) * 64 + lane) * 4 + (rt0 & 3));
+}
+template <int RTW>
+__device__ inline void ws_mask_store(unsigned char* m, int64_t rt0, int n_ct, int ct, int lane,
+                                     unsigned pack) {
+  unsigned char* p = m + ws_mask_index<RTW>(rt0, n_ct, ct, lane);
+  if constexpr (RTW == 4) *reinterpret_cast<unsigned int*>(p) = pack;
+  else if constexpr (RTW == 2) *reinterpret_cast<unsigned short*>(p) = (unsigned short)pack;
+  else *p = (unsigned char)pack;
+}
+template <int RTW>
+__device__ inline unsigned ws_mask_load(const unsigned char* m, int64_t rt0, int n_ct, int ct,
+                                        int lane) {
+  const unsigned char* p = m + ws_mask_index<RTW>(rt0, n_ct, ct, lane);
+  if constexpr (RTW == 4) return *reinterpret_cast<const unsigned int*>(p);
+  else if constexpr (RTW == 2) return *reinterpret_cast<const unsigned short*>(p);
+  else return *p;
 }
 
 // H: hidden width; NH: number of H x H layers; RT: 16-row tiles per row tile.
@@ -117,7 +148,8 @@ struct WsFwdLds {
   static constexpr size_t mean = bufB + kRows * (H + 8) * 2;
   static constexpr size_t sd = mean + 32 * 4;
   static constexpr size_t stash = sd + 32 * 4;
-  static constexpr size_t bytes = stash + (SAMP ? 4096 : 4) * 4;
+  static constexpr size_t wo = stash + (SAMP ? 4096 : 4) * 4;  // head fragments: H/32 KiB
+  static constexpr size_t bytes = wo + (H / 32) * 1024;
 };
 
 template <int H, int NH, int RT, bool SAMP>
@@ -188,8 +220,14 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
   // ---- the trunk, once: weight fragments and biases of this wave's column tiles --------
   bf16x8 W0[TPW];
   bf16x8 WH[NH > 0 ? NH : 1][TPW][KSH];
-  bf16x8 WO[KSH];
   f32x4 B0[TPW], BH[NH > 0 ? NH : 1][TPW], BO;
+  // the head's fragments (one column tile, KSH k-steps) wait in LDS: only RT of the 8 waves
+  // multiply the head, and 4 KSH registers per lane in every wave are what pushes the
+  // 256-wide trunk over the register file
+  bf16_t* const wo_s = reinterpret_cast<bf16_t*>(smem + Lds::wo);  // [KSH][64 lanes][8]
+  if (tid < KSH * 64)
+    *reinterpret_cast<u32x4*>(wo_s + tid * 8) =
+        *reinterpret_cast<const u32x4*>(c.layer[NH + 1].w + tid * 8);
 #pragma unroll
   for (int b = 0; b < TPW; ++b) {
     const unsigned ct = (unsigned)(wc + CW * b);
@@ -210,8 +248,6 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
                      : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-#pragma unroll
-  for (int ks = 0; ks < KSH; ++ks) WO[ks] = ws_frag(c.layer[NH + 1].w, 0, ks, KSH, lane);
   BO = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c.layer[NH + 1].bias) {
 #pragma unroll
@@ -289,17 +325,22 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
     }
     WS_TR();  // tile + 3: layer 0 multiplied
     // bias + relu + round to bf16 -> the next layer's LDS operand
-    auto epilogue_hidden = [&](const f32x4(&bias)[TPW], bf16_t* nbuf) {
+    auto epilogue_hidden = [&](const f32x4(&bias)[TPW], bf16_t* nbuf, unsigned char* mask) {
 #pragma unroll
       for (int b = 0; b < TPW; ++b) {
         const int col = (wc + CW * b) * 16 + 4 * lq;
+        unsigned pack = 0;  // byte r: the mask of this wave's row tile r
 #pragma unroll
         for (int r = 0; r < RTW; ++r) {
           bf16x4 vo;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)fmaxf(acc[r][b][e] + bias[b][e], 0.0f);
+          for (int e = 0; e < 4; ++e) {
+            vo[e] = (bf16_t)fmaxf(acc[r][b][e] + bias[b][e], 0.0f);
+            pack |= ((float)vo[e] > 0.0f ? 1u : 0u) << (8 * r + e);
+          }
           *reinterpret_cast<bf16x4*>(nbuf + ((wr * RTW + r) * 16 + li) * AROW + col) = vo;
         }
+        if (mask) ws_mask_store<RTW>(mask, (i0 >> 4) + wr * RTW, H / 16, wc + CW * b, lane, pack);
       }
     };
     // The layer's bf16 image, out of the published LDS buffer in whole rows: 16 bytes per
@@ -324,7 +365,7 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
           *reinterpret_cast<u32x4*>(ly.out_bf + (i0 + row) * ly.ldo + cc * 8) = v[p];
       }
     };
-    epilogue_hidden(B0, bufB);
+    epilogue_hidden(B0, bufB, c.layer[0].mask_out);
     WS_TR();  // tile + 4: layer 0 epilogue
     __syncthreads();
     WS_TR();  // tile + 5
@@ -354,7 +395,7 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
                                                                 0, 0, 0);
       }
       WS_TR();  // hidden: multiplied
-      epilogue_hidden(BH[l], nxt);
+      epilogue_hidden(BH[l], nxt, c.layer[1 + l].mask_out);
       WS_TR();  // hidden: epilogue
       __syncthreads();
       WS_TR();
@@ -371,7 +412,8 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
       for (int ks = 0; ks < KSH; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + (wave * 16 + li) * AROW +
                                                           ks * 32 + 8 * lq);
-        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WO[ks], a, ah, 0, 0, 0);
+        const bf16x8 wo = *reinterpret_cast<const bf16x8*>(wo_s + (ks * 64 + lane) * 8);
+        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, a, ah, 0, 0, 0);
       }
       const int row = wave * 16 + li;
       const int64_t gi = i0 + row;
@@ -717,6 +759,7 @@ struct WsBwdLayer {
   const bf16_t* aux;    // y_{l-1} [M][ld]: relu' operand of the emitted gradient
   bf16_t* out_bf;       // dz_{l-1} [M][ld]
   int64_t ld;
+  const unsigned char* mask;  // relu'(y_{l-1}) as WsLayer::mask_out wrote it (MASK kernels)
 };
 struct WsBwdChain {
   WsBwdLayer layer[WS_MAXL];  // [0] = head (reduce N_out), then the H x H layers, last first
@@ -738,7 +781,10 @@ struct WsBwdLds {
   static constexpr size_t bytes = bufB + kRows * (H + 8) * 2;
 };
 
-template <int H, int NH, int RT, bool SAMP>
+// MASK: relu' comes from the forward's masks — one byte per lane and 16 x 16 tile instead of
+// 8 bytes of the bf16 image; the images are 48 % of this kernel's HBM bytes at BASELINE C2
+// and the kernel waits on exactly those loads (profiles/r02_trace_ws_bwd.txt).
+template <int H, int NH, int RT, bool SAMP, bool MASK = false>
 __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, const int nblk,
                                             unsigned char* smem) {
   using G = WsGeom<H>;
@@ -840,19 +886,27 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
       }
       if (tile + nblk < ntiles) request_input(tile + nblk);
     }
-    // relu' operands of this row tile: 8 bytes per (row, column tile), requested now
-    s16x4 auxr[NH + 1][RTW][TPW];
+    // relu' operands of this row tile, requested now: 8 bytes of the bf16 image per (row,
+    // column tile) — or, MASK, the lane's byte of the forward's mask
+    s16x4 auxr[NH + 1][MASK ? 1 : RTW][MASK ? 1 : TPW];
+    unsigned auxm[NH + 1][MASK ? TPW : 1];  // byte r: this wave's row tile r
 #pragma unroll
     for (int l = 0; l <= NH; ++l)
 #pragma unroll
       for (int b = 0; b < TPW; ++b) {
         const int col = (wc + CW * b) * 16 + 4 * lq;
+        if constexpr (MASK)
+          auxm[l][b] = ws_mask_load<RTW>(c.layer[l].mask, (i0 >> 4) + wr * RTW, H / 16,
+                                         wc + CW * b, lane);
 #pragma unroll
         for (int r = 0; r < RTW; ++r) {
-          const int64_t gi = i0 + (wr * RTW + r) * 16 + li;
-          s16x4 a = s16x4{0, 0, 0, 0};
-          if (gi < M) a = *reinterpret_cast<const s16x4*>(c.layer[l].aux + gi * c.layer[l].ld + col);
-          auxr[l][r][b] = a;
+          if constexpr (!MASK) {
+            const int64_t gi = i0 + (wr * RTW + r) * 16 + li;
+            s16x4 a = s16x4{0, 0, 0, 0};
+            if (gi < M)
+              a = *reinterpret_cast<const s16x4*>(c.layer[l].aux + gi * c.layer[l].ld + col);
+            auxr[l][r][b] = a;
+          }
         }
       }
     WS_TR();  // tile + 1: head gradient staged, aux requested
@@ -865,17 +919,25 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
             *reinterpret_cast<const u32x4*>(xin + tid * XROW + k);
     }
     f32x4 acc[RTW][TPW];
-    auto epilogue = [&](const s16x4(&aux)[RTW][TPW], bf16_t* nbuf) {
+    auto epilogue = [&](const s16x4(&aux)[MASK ? 1 : RTW][MASK ? 1 : TPW],
+                        const unsigned(&am)[MASK ? TPW : 1], bf16_t* nbuf) {
 #pragma unroll
       for (int b = 0; b < TPW; ++b) {
         const int col = (wc + CW * b) * 16 + 4 * lq;
 #pragma unroll
         for (int r = 0; r < RTW; ++r) {
-          const bf16x4 a4 = __builtin_bit_cast(bf16x4, aux[r][b]);
           bf16x4 vo;
+          if constexpr (MASK) {
+            const unsigned mk = am[b] >> (8 * r);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            vo[e] = (bf16_t)(acc[r][b][e] * ((float)a4[e] > 0.0f ? 1.0f : 0.0f));
+            for (int e = 0; e < 4; ++e)
+              vo[e] = (bf16_t)(acc[r][b][e] * (((mk >> e) & 1u) ? 1.0f : 0.0f));
+          } else {
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, aux[r][b]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              vo[e] = (bf16_t)(acc[r][b][e] * ((float)a4[e] > 0.0f ? 1.0f : 0.0f));
+          }
           *reinterpret_cast<bf16x4*>(nbuf + ((wr * RTW + r) * 16 + li) * AROW + col) = vo;
         }
       }
@@ -912,7 +974,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
               WO[b], af[r], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     WS_TR();  // tile + 3: head multiplied
-    epilogue(auxr[0], bufA);
+    epilogue(auxr[0], auxm[0], bufA);
     WS_TR();  // tile + 4: epilogue (waits for the aux loads)
     __syncthreads();
     WS_TR();  // tile + 5
@@ -941,7 +1003,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
                                                                 0, 0, 0);
       }
       WS_TR();  // hidden: multiplied
-      epilogue(auxr[1 + l], nxt);
+      epilogue(auxr[1 + l], auxm[1 + l], nxt);
       WS_TR();  // hidden: epilogue
       __syncthreads();
       WS_TR();
@@ -965,16 +1027,16 @@ trunk_ws_bwd_kernel(WsBwdChain c) {
 
 // Sampler backward + both dX chains in one launch: workgroups 0 .. n_value-1 the value
 // trunk, the rest the action trunk (the CUs split between them as in policy_ws_dual_kernel).
-template <int HV, int NHV, int HA, int NHA, int RT>
+template <int HV, int NHV, int HA, int NHA, int RT, bool MASK>
 __global__ void __launch_bounds__(kWsThreads, 2)
 policy_ws_bwd_dual_kernel(WsBwdChain a, WsBwdChain v, int n_value) {
   constexpr size_t nv = WsBwdLds<HV, RT, false>::bytes, na = WsBwdLds<HA, RT, true>::bytes;
   __shared__ __attribute__((aligned(16))) unsigned char smem[nv > na ? nv : na];
   if ((int)blockIdx.x < n_value)
-    ws_bwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value, smem);
+    ws_bwd_body<HV, NHV, RT, false, MASK>(v, (int)blockIdx.x, n_value, smem);
   else
-    ws_bwd_body<HA, NHA, RT, true>(a, (int)blockIdx.x - n_value, (int)gridDim.x - n_value,
-                                   smem);
+    ws_bwd_body<HA, NHA, RT, true, MASK>(a, (int)blockIdx.x - n_value,
+                                         (int)gridDim.x - n_value, smem);
 }
 
 int ws_grid(int64_t ntiles) {
@@ -1049,7 +1111,8 @@ namespace {
 
 int ws_fill(WsChain& c, const char* who, const float* x, int64_t M, int64_t L,
             const void* const* wt_bf, const float* const* bias, const int64_t* dims,
-            const int64_t* acts, float* out, void* const* y_bf, void* x_bf) {
+            const int64_t* acts, float* out, void* const* y_bf, void* x_bf,
+            void* const* relu_mask = nullptr) {
   MI_REQUIRE(x && wt_bf && dims && acts && out, "%s: null pointer", who);
   MI_REQUIRE(mi_mlp_ws_supported(L, dims, acts),
              "%s: trunk outside the weights-stationary shape class", who);
@@ -1070,6 +1133,8 @@ int ws_fill(WsChain& c, const char* who, const float* x, int64_t M, int64_t L,
                    l == L - 1,
                "%s: hidden biases must be 16-byte aligned", who);
     c.layer[l].out_bf = (y_bf && l + 1 < L) ? static_cast<bf16_t*>(y_bf[l]) : nullptr;
+    c.layer[l].mask_out =
+        (relu_mask && l + 1 < L) ? static_cast<unsigned char*>(relu_mask[l]) : nullptr;
     c.layer[l].ldo = mippo::ceil_div(dims[l + 1], 8) * 8;
     MI_REQUIRE(al16(c.layer[l].out_bf), "%s: outputs must be 16-byte aligned", who);
   }
@@ -1155,7 +1220,8 @@ int ws_bwd_dispatch(const WsBwdChain& c, int64_t H, int64_t NH, hipStream_t st) 
 // image of layer l; aux[l] = y_l, dz_bf[l] = dz_l for l < L - 1; dz_last = dz_{L-1}).
 int ws_bwd_fill(WsBwdChain& c, const char* who, const float* g_out, int64_t M, int64_t L,
                 const void* const* w_bf, const int64_t* dims, const int64_t* acts,
-                const void* const* aux, void* dz_last, void* const* dz_bf) {
+                const void* const* aux, void* dz_last, void* const* dz_bf,
+                const void* const* relu_mask = nullptr) {
   MI_REQUIRE(w_bf && dims && acts && aux && dz_last && dz_bf, "%s: null pointer", who);
   MI_REQUIRE(mi_mlp_ws_supported(L, dims, acts),
              "%s: trunk outside the weights-stationary shape class", who);
@@ -1176,6 +1242,9 @@ int ws_bwd_fill(WsBwdChain& c, const char* who, const float* g_out, int64_t M, i
     c.layer[q].aux = static_cast<const bf16_t*>(aux[l - 1]);
     c.layer[q].out_bf = static_cast<bf16_t*>(dz_bf[l - 1]);
     c.layer[q].ld = mippo::ceil_div(dims[l], 8) * 8;
+    c.layer[q].mask = relu_mask ? static_cast<const unsigned char*>(relu_mask[l - 1]) : nullptr;
+    MI_REQUIRE(!relu_mask || c.layer[q].mask, "%s: mask of layer %lld missing", who,
+               (long long)(l - 1));
   }
   return 0;
 }
@@ -1229,8 +1298,12 @@ int ws_bwd_dual_launch_rt(const WsBwdChain& a, const WsBwdChain& v, int64_t hv, 
   ws_dual_split(mippo::ceil_div(v.M, 16 * RT), mippo::ceil_div(a.M, 16 * RT), &nv, &na);
 #define X(p, q, r, s_)                                                                       \
   if (hv == p && nhv == q && ha == r && nha == s_) {                                         \
-    hipLaunchKernelGGL((policy_ws_bwd_dual_kernel<p, q, r, s_, RT>),                         \
-                       dim3((unsigned)(nv + na)), dim3(kWsThreads), 0, st, a, v, (int)nv);   \
+    if (a.layer[0].mask)                                                                     \
+      hipLaunchKernelGGL((policy_ws_bwd_dual_kernel<p, q, r, s_, RT, true>),                 \
+                         dim3((unsigned)(nv + na)), dim3(kWsThreads), 0, st, a, v, (int)nv); \
+    else                                                                                     \
+      hipLaunchKernelGGL((policy_ws_bwd_dual_kernel<p, q, r, s_, RT, false>),                \
+                         dim3((unsigned)(nv + na)), dim3(kWsThreads), 0, st, a, v, (int)nv); \
     return mippo::check_launch("mi_policy_ws_bwd_bf16(one launch)");                         \
   }
   WS_DUAL_MENU(X)
@@ -1247,8 +1320,11 @@ extern "C" int mi_policy_ws_bwd_bf16(
     const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
     const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
     const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
-    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf, mi_stream_t stream) {
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
+    const void* const* a_mask, const void* const* c_mask, mi_stream_t stream) {
   MI_REQUIRE(M >= 0, "mi_policy_ws_bwd_bf16: bad M");
+  MI_REQUIRE((a_mask == nullptr) == (c_mask == nullptr),
+             "mi_policy_ws_bwd_bf16: masks for both trunks or for neither");
   if (M == 0) return 0;
   MI_REQUIRE(mean_and_std && extras && g_value && a_dims && c_dims && a_acts && c_acts,
              "mi_policy_ws_bwd_bf16: null pointer");
@@ -1258,14 +1334,14 @@ extern "C" int mi_policy_ws_bwd_bf16(
   hipStream_t st = mippo::as_stream(stream);
   WsBwdChain a;
   int rc = ws_bwd_fill(a, "mi_policy_ws_bwd_bf16(action)", nullptr, M, La, a_w, a_dims, a_acts,
-                       a_aux, a_dz_last, a_dz_bf);
+                       a_aux, a_dz_last, a_dz_bf, a_mask);
   if (rc) return rc;
   const int64_t A2 = a_dims[La];
   a.sbwd = {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
             (int)(A2 / 2), min_std, std_scale, entropy_weight};
   WsBwdChain v;
   rc = ws_bwd_fill(v, "mi_policy_ws_bwd_bf16(value)", g_value, M, Lc, c_w, c_dims, c_acts, c_aux,
-                   c_dz_last, c_dz_bf);
+                   c_dz_last, c_dz_bf, c_mask);
   if (rc) return rc;
   static const bool two_launches = [] {  // MIPPO_WS_BWD_DUAL=0: one launch per trunk (A/B)
     const char* e = getenv("MIPPO_WS_BWD_DUAL");
@@ -1452,8 +1528,9 @@ extern "C" int mi_policy_ws_fwd_bf16(
     float* reg, float* mu_out, float* sigma_out, float* value, void* const* a_y_bf,
     void* const* a_pre_bf, void* a_x_bf, void* const* c_y_bf, void* const* c_pre_bf,
     void* c_x_bf, const float* value_tail_obs, int64_t M_tail, mi_stream_t stream) {
-  (void)a_pre_bf;
-  (void)c_pre_bf;  // relu trunks keep no pre-activations
+  // relu trunks keep no pre-activations: a_pre_bf[l] / c_pre_bf[l], when given, receive the
+  // relu' MASK of layer l's output instead (uint8 [ceil(rows / 64)][N_l / 16][64][4],
+  // WsLayer::mask_out) — what mi_policy_ws_bwd_bf16 takes as a_mask / c_mask
   MI_REQUIRE(M >= 0 && M_tail >= 0 && (M_tail == 0 || value_tail_obs),
              "mi_policy_ws_fwd_bf16: bad M / tail");
   if (M == 0) return 0;
@@ -1467,7 +1544,7 @@ extern "C" int mi_policy_ws_fwd_bf16(
   hipStream_t st = mippo::as_stream(stream);
   WsChain a;
   int rc = ws_fill(a, "mi_policy_ws_fwd_bf16(action)", obs, M, La, a_w, a_bias, a_dims, a_acts,
-                   mean_and_std, a_y_bf, a_x_bf);
+                   mean_and_std, a_y_bf, a_x_bf, a_pre_bf);
   if (rc) return rc;
   const int64_t A2 = a_dims[La];
   a.norm_mean = norm_mean;
@@ -1478,7 +1555,7 @@ extern "C" int mi_policy_ws_fwd_bf16(
             loglik, reg, (int)(A2 / 2), min_std, std_scale, entropy_weight, deterministic};
   WsChain v;
   rc = ws_fill(v, "mi_policy_ws_fwd_bf16(value)", obs, M + M_tail, Lc, c_w, c_bias, c_dims,
-               c_acts, value, c_y_bf, c_x_bf);
+               c_acts, value, c_y_bf, c_x_bf, c_pre_bf);
   if (rc) return rc;
   v.x_tail = value_tail_obs;
   v.M_head = M;

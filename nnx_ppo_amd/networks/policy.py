@@ -43,6 +43,8 @@ WS_POLICY_BWD = os.environ.get("MIPPO_WS_POLICY_BWD", "1") != "0"
 # MIPPO_WS_ROLLOUT=0 keeps rollout / evaluation steps (<= 8192 rows) on the tile kernel
 WS_POLICY_ROLLOUT = os.environ.get("MIPPO_WS_ROLLOUT", "1") != "0"
 WS_MIN_ROWS = 8192
+# MIPPO_WS_MASKS=0: the weights-stationary backward reads relu' from the bf16 images (A/B)
+USE_MASKS = os.environ.get("MIPPO_WS_MASKS", "1") != "0"
 
 
 class MLPActorCritic(Sequential):
@@ -303,8 +305,9 @@ class MLPActorCritic(Sequential):
         s_ctx = (r["mean_and_std"], ex2, off, eps2, (T, B, 2 * A))
         shadows = lambda ls, saved: [(xb, aux, dense_chain._shadows(l)[0])
                                      for (xb, aux), l in zip(saved, ls)]
+        masks = None if r.get("actor_masks") is None else (r["actor_masks"], r["critic_masks"])
         ctx = ("fused", s_ctx, (shadows(a_layers, r["actor_saved"]), M, False),
-               (shadows(c_layers, r["critic_saved"]), M, False), squeezed, (T, B))
+               (shadows(c_layers, r["critic_saved"]), M, False), squeezed, (T, B), masks)
         final_state = [()] * (len(self.layers) - 1) + [{"action": list(state0[-1]["action"]),
                                                        "value": list(state0[-1]["value"])}]
         if _bootstrap is not None:
@@ -316,7 +319,7 @@ class MLPActorCritic(Sequential):
     def replay_backward(self, ctx, g_out, g_reg):
         if ctx[0] == "generic":
             return super().replay_backward(ctx[1], g_out, g_reg)
-        _, s_ctx, a_ctx, v_ctx, squeezed, (T, B) = ctx
+        _, s_ctx, a_ctx, v_ctx, squeezed, (T, B), masks = ctx
         a_layers, sampler, c_layers = self._parts()
         M = T * B
         g_v = g_out.value_estimates.reshape(M, -1)
@@ -339,7 +342,7 @@ class MLPActorCritic(Sequential):
               and ops.policy_ws_supported(da[1], da[2], dc[1], dc[2]))
         a_dz, c_dz = ops.policy_bwd_bf16(
             ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, g_v, da, dc, eps2=eps2,
-            ws=ws, **sampler._kw())
+            ws=ws, masks=(masks if ws and USE_MASKS else None), **sampler._kw())
         # dW / db of every layer of both trunks: one grouped launch per tile class
         problems = []
         for ls, c, dz in ((c_layers, v_ctx, c_dz), (a_layers, a_ctx, a_dz)):

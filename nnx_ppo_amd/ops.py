@@ -672,6 +672,15 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
 
     a_y, a_pre, a_x = images(La, a_dims, a_acts, M)
     c_y, c_pre, c_x = images(Lc, c_dims, c_acts, M + Mt)
+    a_mask = c_mask = None
+    if ws and train:
+        # relu trunks keep no pre-activations: the `pre` slots carry the relu' masks the
+        # weights-stationary backward reads (4 bits per lane of a 16 x 16 tile, one byte)
+        def masks(L, dims, rows):  # [64-row block][column tile][lane][row tile of the block]
+            return [torch.empty(-(-rows // 64), dims[l + 1] // 16, 64, 4, dtype=torch.uint8,
+                                device=dev) if l < L - 1 else None for l in range(L)]
+        a_mask, c_mask = masks(La, a_dims, M), masks(Lc, c_dims, M + Mt)
+        a_pre, c_pre = a_mask, c_mask
     arr = lambda ts, L: None if ts is None else (ctypes.c_void_p * L)(*[ptr(t) for t in ts])
     i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
     n_mean, n_m2, n_cnt, n_eps = norm if norm is not None else (None, None, None, 0.0)
@@ -679,8 +688,9 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
         flop = sum(a_dims[l] * a_dims[l + 1] for l in range(La)) \
             + sum(c_dims[l] * c_dims[l + 1] for l in range(Lc))
         profiler.next_flops = 2.0 * M * flop
-        kept = sum(t.numel() * 2 for t in [a_x, c_x, *(a_y or []), *(a_pre or []),
-                                           *(c_y or []), *(c_pre or [])] if t is not None)
+        kept = sum(t.numel() * t.element_size()
+                   for t in [a_x, c_x, *(a_y or []), *(a_pre or []), *(c_y or []), *(c_pre or [])]
+                   if t is not None)
         w_bytes = sum(2 * a_dims[l] * a_dims[l + 1] for l in range(La)) \
             + sum(2 * c_dims[l] * c_dims[l + 1] for l in range(Lc))
         outs = sum(t.numel() * 4 for t in [raw, action, ll, reg, mu, sigma, value, ms, extras]
@@ -703,7 +713,9 @@ def policy_fwd_bf16(obs: torch.Tensor, norm, actor, critic, rng_state, offset_ad
         "mi_policy_ws_fwd_bf16" if ws else "mi_policy_fwd_bf16")
     out = dict(raw=extras if replay else raw, action=action, log_likelihood=ll, reg=reg, mu=mu,
                sigma=sigma, value=value[:M], value_tail_out=value[M:] if Mt else None,
-               mean_and_std=ms)
+               mean_and_std=ms, actor_masks=a_mask, critic_masks=c_mask)
+    if a_mask is not None:
+        a_pre, c_pre = [None] * La, [None] * Lc  # (relu: no pre-activation images)
     if train:
         def saved(L, acts, x_bf, y, pre):
             return [((x_bf if l == 0 else y[l - 1]), (pre[l] if acts[l] == ACT_SWISH else y[l]))
@@ -767,11 +779,14 @@ def gru_policy_step(obs: torch.Tensor, norm, dense_in, proj, w_h: torch.Tensor,
 
 def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float,
                     g_value, actor, critic, *, min_std: float, std_scale: float,
-                    entropy_weight: float, eps2=None, ws: bool = False):
+                    entropy_weight: float, eps2=None, ws: bool = False, masks=None):
     """Sampler backward + both dX chains in ONE launch (`mi_policy_bwd_bf16`).
     `actor` / `critic` = (backward frag images, dims, acts, auxs per layer).  Returns
     (actor dz list, critic dz list): bf16 [M, pad8(N_l)] per layer.  `ws`: the
-    weights-stationary kernels (`mi_policy_ws_bwd_bf16`), same results bit for bit."""
+    weights-stationary kernels (`mi_policy_ws_bwd_bf16`), same results bit for bit; `masks`
+    = (actor masks, critic masks) of the weights-stationary forward (`policy_fwd_bf16(...,
+    ws=True)["actor_masks" / "critic_masks"]`): relu' is read from them instead of the bf16
+    images."""
     M, A2 = mean_and_std.shape
     dev = mean_and_std.device
     (a_w, a_dims, a_acts, a_aux), (c_w, c_dims, c_acts, c_aux) = actor, critic
@@ -788,12 +803,24 @@ def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_re
         flop = sum(a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
             + sum(c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
         profiler.next_flops = 2.0 * M * flop
-        moved = sum(t.numel() * 2 for t in [*a_aux[:La - 1], *c_aux[:Lc - 1], *a_dz, *c_dz]
+        # relu' operands: the bf16 images, or (weights-stationary, masks) a byte per 4 elements
+        read = [*masks[0], *masks[1]] if (ws and masks is not None) \
+            else [*a_aux[:La - 1], *c_aux[:Lc - 1]]
+        moved = sum(t.numel() * t.element_size() for t in [*read, *a_dz, *c_dz]
                     if t is not None)
         w_bytes = sum(2 * a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
             + sum(2 * c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
         profiler.next_bytes = (4.0 * M * (A2 + A2 // 2 + 1 + c_dims[-1]) + w_bytes + moved)
     entry = lib().mi_policy_ws_bwd_bf16 if ws else lib().mi_policy_bwd_bf16
+    extra = ()
+    if ws:
+        extra = (None, None)
+        if masks is not None:
+            am, cm = masks
+            _need(len(am) >= La - 1 and len(cm) >= Lc - 1 and all(
+                t is not None and t.dtype == torch.uint8 for t in [*am[:La - 1], *cm[:Lc - 1]]),
+                "policy_bwd_bf16: one uint8 mask per hidden layer")
+            extra = (arr(am[:La - 1], La - 1), arr(cm[:Lc - 1], Lc - 1))
     check(entry(
         ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
         ptr(eps2, f32), ptr(g_ll, f32), float(g_reg), float(min_std), float(std_scale),
@@ -801,7 +828,7 @@ def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_re
         La, arr(a_w, La), i64s(a_dims), i64s(a_acts), arr(a_aux[:La - 1], La - 1),
         ptr(a_dz[La - 1], bf16), arr(a_dz[:La - 1], La - 1),
         Lc, arr(c_w, Lc), i64s(c_dims), i64s(c_acts), arr(c_aux[:Lc - 1], Lc - 1),
-        ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1), stream()),
+        ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1), *extra, stream()),
         "mi_policy_ws_bwd_bf16" if ws else "mi_policy_bwd_bf16")
     return a_dz, c_dz
 

@@ -268,3 +268,28 @@ def test_policy_ws_backward_bit_identical(dev, shape, M):
     for name, wl, gl in (("actor", want[0], got[0]), ("critic", want[1], got[1])):
         for l, (a, b) in enumerate(zip(wl, gl)):
             assert torch.equal(a, b), (name, l, float((a.float() - b.float()).abs().max()))
+    # the same through the relu' masks of the weights-stationary forward
+    rw = ops.policy_fwd_bf16(obs, None, (a_ff, a_b, a_dims, a_acts), (c_ff, c_b, c_dims, c_acts),
+                             rng_state, 2, deterministic=False, extras=extras, train=True,
+                             want_stats=False, ws=True, **kw)
+    masks = (rw["actor_masks"], rw["critic_masks"])
+    assert all(m is not None for m in masks[0][:-1] + masks[1][:-1])
+    # format: tile (rt, ct) has byte [rt >> 2][ct][lane][rt & 3];
+    # bit e <-> y[16 rt + (lane & 15)][16 ct + 4 (lane >> 4) + e] > 0
+    for saved, ms in ((rw["actor_saved"], masks[0]), (rw["critic_saved"], masks[1])):
+        for l, m in enumerate(ms[:-1]):
+            n_ct = m.shape[1]
+            y = saved[l][1][:, :n_ct * 16].float()                 # [M, N]: aux of layer l
+            rows = (M // 64) * 64
+            if rows == 0:
+                continue
+            pos = (y[:rows] > 0).view(rows // 64, 4, 16, n_ct, 4, 4)  # g, rt&3, li, ct, lq, e
+            want_bits = pos.permute(0, 3, 4, 2, 1, 5).reshape(rows // 64, n_ct, 64, 4, 4)
+            bits = torch.arange(4, device=dev)
+            got_bits = ((m[:rows // 64].unsqueeze(-1).to(torch.int32) >> bits) & 1).bool()
+            assert torch.equal(got_bits, want_bits), l
+    gotm = ops.policy_bwd_bf16(rw["mean_and_std"], extras, rng_state, 2, g_ll, 1.0 / M, g_v,
+                               actor, critic, ws=True, masks=masks, **kw)
+    for name, wl, gl in (("actor", want[0], gotm[0]), ("critic", want[1], gotm[1])):
+        for l, (a, b) in enumerate(zip(wl, gl)):
+            assert torch.equal(a, b), ("masks", name, l)
