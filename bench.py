@@ -205,18 +205,19 @@ def roofline_of_dominant_kernel(env, ts):
         traffic_db = json.loads(pmc.read_text()).get("kernels", {})
     trunk = {k: v for k, v in classes.items()
              if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel",
-                              "trunk_ws_", "policy_ws_"))}
+                              "trunk_ws_", "policy_ws_", "tn_gemm_dw", "dW group"))}
     if trunk:
-        # Dominant kernel = the trunk class with the most device time.  Its arithmetic
-        # intensity (~100-150 flop/B with the activations kept for the backward) is below
-        # the bf16 ridge (2500 TF/s / 8 TB/s = 312 flop/B), so HBM bounds it.
+        # Dominant kernel = the dense class (trunk forward / backward, dW) with the most
+        # device time.  Their arithmetic intensity (50-150 flop/B with the activations kept
+        # for the backward) is below the bf16 ridge (2500 TF/s / 8 TB/s = 312 flop/B), so HBM
+        # bounds them.
         dom = max(trunk, key=lambda k: trunk[k]["ms"])
         c = trunk[dom]
         gbps = c["bytes"] / (c["ms"] * 1e-3) / 1e9
         tf = c["flops"] / (c["ms"] * 1e-3) / 1e12
         # rocprofv3 names carry every template argument; the class names above only the
         # tile shape: match on the common prefix
-        stem = dom.split(" pair")[0].rstrip(">")
+        stem = dom.split(" pair")[0].split(" (")[0].rstrip(">")
         t = traffic_db.get(dom) or next(
             (v for k, v in traffic_db.items() if k.startswith(stem)), None)
         roof = {
