@@ -38,17 +38,36 @@ constexpr int PF = 4;
 // no per-element branches — with one wave per SIMD every instruction's latency is
 // exposed and the first version of this kernel spent ~2000 instructions per step on
 // predicates and 64-bit address arithmetic.
-template <bool TRAIN, int UTW>
+// H (32 / 64 / 96 / 128) is a template parameter, GUARD (rows past B exist: B % 16 != 0) and
+// BF (write the bf16 image of h_prev) too: every data-dependent or pointer-dependent branch
+// around a memory instruction makes the compiler's wait counting take the path with the
+// FEWEST younger instructions, i.e. wait for almost everything — the steady state below
+// must be straight-line code.
+template <bool TRAIN, int H, bool GUARD, bool BF>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
                     const uint8_t* __restrict__ done, float* __restrict__ h_out,
                     float* __restrict__ h_prev_out, float* __restrict__ gates_out,
                     float* __restrict__ h_final, bf16_t* __restrict__ h_prev_bf, int64_t T,
-                    int64_t B, int H) {
-  constexpr int PFW = UTW == 1 ? PF : PF / 2;  // look-ahead that still fits the registers
+                    int64_t B) {
+  // (the gate expressions are evaluated as written — no fma contraction — in every
+  // instantiation and in the one-launch rollout step of trunk_ws.hip: bit-identical carries)
+#pragma clang fp contract(off)
+  constexpr int UT = H / 16;          // unit tiles
+  constexpr int UTW = (UT + 3) / 4;   // per wave
+  constexpr int KS = H / 32 + (H % 32 ? 1 : 0);
+  // Look-ahead of the per-step operands.  vmcnt counts loads AND stores, in order, up to 63:
+  // the wait for the operands requested PFW steps ago can leave at most 63 younger memory
+  // instructions in flight.  With the tile in its natural orientation (a lane = 4 rows x 1
+  // unit: 12 + 4 scalar loads and up to 28 scalar stores per step) that window was barely
+  // one step, so every step waited for the PREVIOUS step's stores to reach memory (~2 us;
+  // 62 us for T = 30 whatever the look-ahead).  In the TRANSPOSED orientation (weights as
+  // the A operand: a lane = 1 row x 4 consecutive units) a step is 3 + 1 loads and <= 7
+  // stores of 16 bytes, and PFW = 5 steps of them fit the window.
+  constexpr int PFW = UTW == 1 ? 5 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int HROW = H + 8;
+  constexpr int HROW = H + 8;
   bf16_t* hb0 = reinterpret_cast<bf16_t*>(lds_raw);  // [2][16][H + 8]
   bf16_t* hb1 = hb0 + GROWS * HROW;
   const int tid = threadIdx.x;
@@ -56,11 +75,10 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * GROWS;
-  const int H3 = 3 * H;
-  const int KS = H / 32;
-  const int UT = H / 16;
+  constexpr int H3 = 3 * H;
 
-  // W_h fragments of this wave's units: B operand = W_h[k][gate*H + unit]
+  // W_h fragments of this wave's units: W_h[k][gate*H + unit], lane (li, lq) the column
+  // `unit tile * 16 + li`, reduce elements 8 lq .. 8 lq + 7 of the k-step
   bf16x8 wf[UTW][3][4];
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
@@ -79,55 +97,53 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
         wf[ui][g][ks] = f;
       }
   }
-  // element (ui, e): row 4*lq + e, unit (wave + 4*ui)*16 + li
-  bool valid[4];
-  unsigned rowc[4];  // row clamped into [0, B): loads never leave the tensors
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int64_t row = row0 + 4 * lq + e;
-    valid[e] = row < B;
-    rowc[e] = (unsigned)(valid[e] ? row : B - 1);
-  }
-  float h[UTW][4];
-  float bn[UTW];
-  unsigned unit[UTW];
+  // this lane: row `row0 + li`, units (wave + 4 ui) * 16 + 4 lq + e  (e = 0..3)
+  const int64_t row = row0 + li;
+  const bool valid = !GUARD || row < B;
+  const unsigned rowc = (unsigned)(valid ? row : B - 1);  // clamped: loads stay inside
+  f32x4 h[UTW], bn[UTW];
+  unsigned ucol[UTW];
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
     const int ut = wave + 4 * ui;
     const bool on = ut < UT;
-    unit[ui] = (unsigned)((on ? ut : 0) * 16 + li);
-    bn[ui] = on ? b_hn[unit[ui]] : 0.0f;
+    ucol[ui] = (unsigned)((on ? ut : 0) * 16 + 4 * lq);
+    bn[ui] = on ? *reinterpret_cast<const f32x4*>(b_hn + ucol[ui]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    h[ui] = (on && valid) ? *reinterpret_cast<const f32x4*>(h0 + rowc * (unsigned)H + ucol[ui])
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (on) {
+      bf16x4 hb4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float v = (on && valid[e]) ? h0[rowc[e] * (unsigned)H + unit[ui]] : 0.0f;
-      h[ui][e] = v;
-      if (on) hb0[(4 * lq + e) * HROW + unit[ui]] = (bf16_t)v;
+      for (int e = 0; e < 4; ++e) hb4[e] = (bf16_t)h[ui][e];
+      *reinterpret_cast<bf16x4*>(hb0 + li * HROW + ucol[ui]) = hb4;
     }
   }
   const int64_t last_t = T - 1;
   // gi / done of steps t .. t+PFW-1 for the owned elements (ring of PFW register slots)
-  float gq[PFW][UTW][3][4];
-  float dq[PFW][4];
-  auto load_step = [&](int64_t t, float (&dst)[UTW][3][4], float (&dn)[4]) {
+  f32x4 gq[PFW][UTW][3];
+  // (the done byte stays RAW in its slot: testing it here would make every load_step wait
+  // for its own load — and, vmcnt being in order, for every store before it: one full
+  // memory round trip per time step, which is what this kernel used to cost)
+  unsigned dq[PFW];
+  const uint8_t* const done_c = done ? done : reinterpret_cast<const uint8_t*>(w_h);
+  auto load_step = [&](int64_t t, f32x4 (&dst)[UTW][3], unsigned& dn) {
     const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
     const float* gt = gi + tc * B * H3;
-    const uint8_t* dt = done ? done + tc * B : nullptr;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dn[e] = (dt && dt[rowc[e]] != 0) ? 1.0f : 0.0f;
+    dn = done_c[done ? tc * B + rowc : 0];
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
       for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          dst[ui][g][e] = gt[rowc[e] * (unsigned)H3 + (unsigned)(g * H) + unit[ui]];
+        dst[ui][g] = *reinterpret_cast<const f32x4*>(gt + rowc * (unsigned)H3 +
+                                                     (unsigned)(g * H) + ucol[ui]);
   };
 #pragma unroll
   for (int d = 0; d < PFW; ++d) load_step(d, gq[d], dq[d]);
   __syncthreads();
   bf16_t* hb = hb0;
   bf16_t* hbn = hb1;
-  auto step = [&](int64_t t, float (&gcur)[UTW][3][4], float (&dcur)[4]) {
+  auto step = [&](int64_t t, f32x4 (&gcur)[UTW][3], unsigned& dcur) {
+    const bool reset = done != nullptr && dcur != 0;
     f32x4 acc[UTW][3];
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui)
@@ -140,8 +156,8 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 #pragma unroll
         for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
-          for (int g = 0; g < 3; ++g)  // D[row = 4*lq + e][col = li]
-            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ui][g][ks], acc[ui][g],
+          for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
+            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
                                                                 0, 0, 0);
       }
     }
@@ -149,35 +165,46 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     float* hpo = TRAIN ? h_prev_out + t * B * H : nullptr;
     float* gto = TRAIN ? gates_out + t * B * 4 * H : nullptr;
     // bf16 image of h_prev [T*B][H]: the x operand of the recurrent kernel's dW launch
-    bf16_t* hpb = (TRAIN && h_prev_bf) ? h_prev_bf + t * B * H : nullptr;
+    bf16_t* hpb = (TRAIN && BF) ? h_prev_bf + t * B * H : nullptr;
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       if (wave + 4 * ui >= UT) continue;  // wave-uniform
+      const f32x4 hp = h[ui];
+      f32x4 r, z, n, qn, hnew;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float hp = h[ui][e];
-        const float r = fast_sigmoid(gcur[ui][0][e] + acc[ui][0][e]);
-        const float z = fast_sigmoid(gcur[ui][1][e] + acc[ui][1][e]);
-        const float qn = acc[ui][2][e] + bn[ui];
-        const float n = fast_tanh(gcur[ui][2][e] + r * qn);
-        const float hnew = (1.0f - z) * n + z * hp;
-        if (valid[e]) {
-          const unsigned o = rowc[e] * (unsigned)H + unit[ui];
-          ho[o] = hnew;
-          if constexpr (TRAIN) {
-            hpo[o] = hp;
-            if (hpb) hpb[o] = (bf16_t)hp;
-            const unsigned og = rowc[e] * (unsigned)(4 * H) + unit[ui];
-            gto[og] = r;
-            gto[og + (unsigned)H] = z;
-            gto[og + (unsigned)(2 * H)] = n;
-            gto[og + (unsigned)(3 * H)] = qn;
-          }
-        }
-        const float hc = dcur[e] != 0.0f ? 0.0f : hnew;
-        h[ui][e] = hc;
-        hbn[(4 * lq + e) * HROW + unit[ui]] = (bf16_t)hc;
+        r[e] = fast_sigmoid(gcur[ui][0][e] + acc[ui][0][e]);
+        z[e] = fast_sigmoid(gcur[ui][1][e] + acc[ui][1][e]);
+        qn[e] = acc[ui][2][e] + bn[ui][e];
+        n[e] = fast_tanh(gcur[ui][2][e] + r[e] * qn[e]);
+        hnew[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
       }
+      if (valid) {
+        const unsigned o = rowc * (unsigned)H + ucol[ui];
+        *reinterpret_cast<f32x4*>(ho + o) = hnew;
+        if constexpr (TRAIN) {
+          *reinterpret_cast<f32x4*>(hpo + o) = hp;
+          if constexpr (BF) {
+            bf16x4 pb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pb[e] = (bf16_t)hp[e];
+            *reinterpret_cast<bf16x4*>(hpb + o) = pb;
+          }
+          const unsigned og = rowc * (unsigned)(4 * H) + ucol[ui];
+          *reinterpret_cast<f32x4*>(gto + og) = r;
+          *reinterpret_cast<f32x4*>(gto + og + (unsigned)H) = z;
+          *reinterpret_cast<f32x4*>(gto + og + (unsigned)(2 * H)) = n;
+          *reinterpret_cast<f32x4*>(gto + og + (unsigned)(3 * H)) = qn;
+        }
+      }
+      bf16x4 hb4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float hc = reset ? 0.0f : hnew[e];
+        h[ui][e] = hc;
+        hb4[e] = (bf16_t)hc;
+      }
+      *reinterpret_cast<bf16x4*>(hbn + li * HROW + ucol[ui]) = hb4;
     }
     __syncthreads();
     bf16_t* tmp = hb;
@@ -185,17 +212,19 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     hbn = tmp;
     load_step(t + PFW, gcur, dcur);  // refill this slot: consumed PFW steps from now
   };
-  for (int64_t t0 = 0; t0 < T; t0 += PFW) {
+  // whole groups of PFW steps: straight-line; then the remainder
+  int64_t t0 = 0;
+  for (; t0 + PFW <= T; t0 += PFW) {
 #pragma unroll
-    for (int d = 0; d < PFW; ++d)
-      if (t0 + d < T) step(t0 + d, gq[d], dq[d]);
+    for (int d = 0; d < PFW; ++d) step(t0 + d, gq[d], dq[d]);
   }
+#pragma unroll
+  for (int d = 0; d < PFW; ++d)
+    if (t0 + d < T) step(t0 + d, gq[d], dq[d]);
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
     if (wave + 4 * ui >= UT) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (valid[e]) h_final[rowc[e] * (unsigned)H + unit[ui]] = h[ui][e];
+    if (valid) *reinterpret_cast<f32x4*>(h_final + rowc * (unsigned)H + ucol[ui]) = h[ui];
   }
 }
 
@@ -394,15 +423,29 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
   const size_t lds = (size_t)2 * GROWS * (H + 8) * sizeof(bf16_t);
   const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
   hipStream_t st = mippo::as_stream(stream);
-#define MI_GRU_FWD(TRAIN, UTW)                                                                  \
-  hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, UTW>), grid, dim3(kThreads), lds, st, gi, w_h, \
-                     b_hn, h0, done, h_out, h_prev_out, gates_out, h_final,                      \
-                     static_cast<bf16_t*>(h_prev_bf), T, B, (int)H)
-  if (h_prev_out) {
-    if (H <= 64) MI_GRU_FWD(true, 1); else MI_GRU_FWD(true, 2);
-  } else {
-    if (H <= 64) MI_GRU_FWD(false, 1); else MI_GRU_FWD(false, 2);
+  const bool guard = B % GROWS != 0;
+  bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
+#define MI_GRU_FWD(TRAIN, HH, GUARD, BF)                                                       \
+  hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, HH, GUARD, BF>), grid, dim3(kThreads), lds, st, \
+                     gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, hpb, T, B)
+#define MI_GRU_FWD_H(HH)                                                       \
+  if (H == HH) {                                                               \
+    if (!h_prev_out) {                                                         \
+      if (guard) MI_GRU_FWD(false, HH, true, false);                           \
+      else MI_GRU_FWD(false, HH, false, false);                                \
+    } else if (hpb) {                                                          \
+      if (guard) MI_GRU_FWD(true, HH, true, true);                             \
+      else MI_GRU_FWD(true, HH, false, true);                                  \
+    } else {                                                                   \
+      if (guard) MI_GRU_FWD(true, HH, true, false);                            \
+      else MI_GRU_FWD(true, HH, false, false);                                 \
+    }                                                                          \
   }
+  MI_GRU_FWD_H(32)
+  MI_GRU_FWD_H(64)
+  MI_GRU_FWD_H(96)
+  MI_GRU_FWD_H(128)
+#undef MI_GRU_FWD_H
 #undef MI_GRU_FWD
   return mippo::check_launch("mi_gru_seq_fwd_bf16");
 }

@@ -469,6 +469,7 @@ template <int H, int RT>
 __device__ __forceinline__ void ws_gru_step_body(const WsChain& c, const GruStepExtra& gx,
                                                  const int bid, const int nblk,
                                                  unsigned char* smem) {
+#pragma clang fp contract(off)  // the gate expressions as written, as gru_fwd_mfma_kernel
   static_assert(H == 64 || H == 128, "GRU width: 64 or 128");
   using G = WsGeom<H>;
   constexpr int CW = G::CW, RW = G::RW;
