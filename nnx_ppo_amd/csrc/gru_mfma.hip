@@ -79,21 +79,28 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 
   // W_h fragments of this wave's units: W_h[k][gate*H + unit], lane (li, lq) the column
   // `unit tile * 16 + li`, reduce elements 8 lq .. 8 lq + 7 of the k-step
-  bf16x8 wf[UTW][3][4];
+  // (loads unconditional — a wave without a unit tile re-reads tile 0 and never uses it — so
+  // that all of them are in flight at once: behind a per-element branch each one was waited
+  // for before the next was issued)
+  bf16x8 wf[UTW][3][KS];
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
-    const int ut = wave + 4 * ui;
+    const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+    float wv[3][KS][8];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          wv[g][ks][i] = w_h[(ks * 32 + 8 * lq + i) * H3 + g * H + ut * 16 + li];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
         bf16x8 f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = ks * 32 + 8 * lq + i;
-          f[i] = (ut < UT && ks < KS) ? (bf16_t)w_h[(int64_t)k * H3 + g * H + ut * 16 + li]
-                                      : (bf16_t)0.0f;
-        }
+        for (int i = 0; i < 8; ++i) f[i] = (bf16_t)wv[g][ks][i];
         wf[ui][g][ks] = f;
       }
   }
@@ -150,16 +157,14 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[ui][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < KS) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
 #pragma unroll
-        for (int ui = 0; ui < UTW; ++ui)
+      for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
-          for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
-            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
-                                                                0, 0, 0);
-      }
+        for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
+          acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
+                                                              0, 0, 0);
     }
     float* ho = h_out + t * B * H;
     float* hpo = TRAIN ? h_prev_out + t * B * H : nullptr;
