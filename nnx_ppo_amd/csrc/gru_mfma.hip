@@ -24,12 +24,11 @@ namespace {
 using namespace mippo_bf16;
 
 constexpr int GROWS = 16;
-// Steps of look-ahead for the per-step global operands (gi forward; gates, g_h, h_prev
-// backward).  They do not depend on the recurrence, and a step's arithmetic (~0.3 us)
-// is far shorter than an HBM round trip (~2 us): with one step of look-ahead every
-// step waited for memory (3.4 us / step measured); the time loop is unrolled PF times
-// over a ring of register slots instead.
-constexpr int PF = 4;
+// Look-ahead for the per-step global operands (gi forward; gates, g_h, h_prev backward).
+// They do not depend on the recurrence, and a step's arithmetic (~0.3 us) is far shorter
+// than an HBM round trip (~2 us): the time loop is unrolled PFW times over a ring of register
+// slots (PFW per kernel, see there: it is bounded by the 63 memory instructions vmcnt can
+// leave in flight).
 
 
 // Addressing: a lane's element offsets (row * stride + unit) are fixed for the whole
@@ -233,19 +232,27 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   }
 }
 
-// BPTT (formulas in gru.hip).  dh carry in registers; dgh tile (bf16) in LDS is the A
-// operand of dh_prev += dgh . W_h^T; B operand = W_h[unit][j] rows (contiguous in j).
-template <int UTW>
+// BPTT (formulas in gru.hip), same arrangement as the forward: transposed tile (a lane =
+// one row x 4 consecutive units), 16-byte loads and stores, raw done bytes in the ring,
+// H / GUARD / output flags as template parameters, straight-line groups of PFW steps.
+// dh carry in registers; the dgh tile (bf16) in LDS is the B operand of
+// dh_prev^T += W_h . dgh^T; A operand = W_h[unit][j] rows (contiguous in j).
+// F32: write dgh as fp32; BF: write its bf16 image (the dW operand).
+template <int H, bool GUARD, bool F32, bool BF>
 __global__ void __launch_bounds__(kThreads)
 gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
                     const float* __restrict__ h_prev, const float* __restrict__ w_h,
                     const uint8_t* __restrict__ done, float* __restrict__ dgi,
                     float* __restrict__ dgh, float* __restrict__ dh0,
-                    bf16_t* __restrict__ dgh_bf, int64_t T, int64_t B, int H) {
-  constexpr int PFW = UTW == 1 ? PF : 1;  // 2 unit tiles: no registers left for a ring
+                    bf16_t* __restrict__ dgh_bf, int64_t T, int64_t B) {
+#pragma clang fp contract(off)
+  constexpr int UT = H / 16;
+  constexpr int UTW = (UT + 3) / 4;
+  constexpr int H3 = 3 * H;
+  constexpr int KS = H3 / 32;  // <= 12
+  constexpr int GROW = H3 + 8;
+  constexpr int PFW = UTW == 1 ? 4 : 2;  // 7 loads + 6 stores per step: PFW steps < 63
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int H3 = 3 * H;
-  const int GROW = H3 + 8;
   bf16_t* dg0 = reinterpret_cast<bf16_t*>(lds_raw);  // [2][16][3H + 8]
   bf16_t* dg1 = dg0 + GROWS * GROW;
   const int tid = threadIdx.x;
@@ -253,121 +260,131 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * GROWS;
-  const int KS = H3 / 32;  // <= 12
-  const int UT = H / 16;
 
-  // W_h^T fragments: B[k_red = j][col = unit] = W_h[unit][j]
-  bf16x8 wf[UTW][12];
+  // W_h rows of this wave's units: A[i = unit tile * 16 + li][k = j] = W_h[unit][j]
+  bf16x8 wf[UTW][KS];
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
-    const int ut = wave + 4 * ui;
+    const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+    f32x4 wv[KS][2];
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* src = w_h + (ut * 16 + li) * H3 + ks * 32 + 8 * lq;
+      wv[ks][0] = *reinterpret_cast<const f32x4*>(src);
+      wv[ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
       bf16x8 f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        f[i] = (ut < UT && ks < KS)
-                   ? (bf16_t)w_h[(int64_t)(ut * 16 + li) * H3 + ks * 32 + 8 * lq + i]
-                   : (bf16_t)0.0f;
+      for (int i = 0; i < 4; ++i) {
+        f[i] = (bf16_t)wv[ks][0][i];
+        f[4 + i] = (bf16_t)wv[ks][1][i];
+      }
       wf[ui][ks] = f;
     }
   }
-  bool valid[4];
-  unsigned rowc[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int64_t row = row0 + 4 * lq + e;
-    valid[e] = row < B;
-    rowc[e] = (unsigned)(valid[e] ? row : B - 1);
-  }
-  unsigned unit[UTW];
-  float dh[UTW][4];
+  const int64_t row = row0 + li;
+  const bool valid = !GUARD || row < B;
+  const unsigned rowc = (unsigned)(valid ? row : B - 1);
+  unsigned ucol[UTW];
+  f32x4 dh[UTW];
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
-    const int ut = wave + 4 * ui;
-    unit[ui] = (unsigned)((ut < UT ? ut : 0) * 16 + li);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dh[ui][e] = 0.0f;
+    const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+    ucol[ui] = (unsigned)(ut * 16 + 4 * lq);
+    dh[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // per-step operands of the owned elements: (r, z, n, qn, g_h, h_prev), done; ring of PFW
   struct In {
-    float v[UTW][4][6];
-    float dn[4];
+    f32x4 v[UTW][6];
+    unsigned dn;
   };
   In inq[PFW];
+  const uint8_t* const done_c = done ? done : reinterpret_cast<const uint8_t*>(w_h);
   auto load_in = [&](int64_t t, In& dst) {
     const int64_t tc = t > 0 ? t : 0;  // before the start: reload step 0
     const float* gt = gates + tc * B * 4 * H;
     const float* ght = g_h + tc * B * H;
     const float* hpt = h_prev + tc * B * H;
-    const uint8_t* dt = done ? done + tc * B : nullptr;
+    dst.dn = done_c[done ? tc * B + rowc : 0];  // raw: tested where it is used
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dst.dn[e] = (dt && dt[rowc[e]] != 0) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int ui = 0; ui < UTW; ++ui)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned og = rowc[e] * (unsigned)(4 * H) + unit[ui];
-        const unsigned o = rowc[e] * (unsigned)H + unit[ui];
-        dst.v[ui][e][0] = gt[og];
-        dst.v[ui][e][1] = gt[og + (unsigned)H];
-        dst.v[ui][e][2] = gt[og + (unsigned)(2 * H)];
-        dst.v[ui][e][3] = gt[og + (unsigned)(3 * H)];
-        dst.v[ui][e][4] = ght[o];
-        dst.v[ui][e][5] = hpt[o];
-      }
+    for (int ui = 0; ui < UTW; ++ui) {
+      const unsigned og = rowc * (unsigned)(4 * H) + ucol[ui];
+      const unsigned o = rowc * (unsigned)H + ucol[ui];
+      dst.v[ui][0] = *reinterpret_cast<const f32x4*>(gt + og);
+      dst.v[ui][1] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)H);
+      dst.v[ui][2] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(2 * H));
+      dst.v[ui][3] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(3 * H));
+      dst.v[ui][4] = *reinterpret_cast<const f32x4*>(ght + o);
+      dst.v[ui][5] = *reinterpret_cast<const f32x4*>(hpt + o);
+    }
   };
 #pragma unroll
   for (int d = 0; d < PFW; ++d) load_in(T - 1 - d, inq[d]);
   bf16_t* dg = dg0;
   bf16_t* dgn_buf = dg1;
   auto step = [&](int64_t t, In& in) {
-    float dhp[UTW][4];
+    const bool reset = done != nullptr && in.dn != 0;
+    f32x4 dhp[UTW];
     float* gio = dgi + t * B * H3;
-    float* gho = dgh ? dgh + t * B * H3 : nullptr;
+    float* gho = F32 ? dgh + t * B * H3 : nullptr;
     // bf16 image of dgh [T*B][3H]: the dz operand of the recurrent kernel's dW launch
-    bf16_t* ghb = dgh_bf ? dgh_bf + t * B * H3 : nullptr;
+    bf16_t* ghb = BF ? dgh_bf + t * B * H3 : nullptr;
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
-      if (wave + 4 * ui >= UT) continue;  // wave-uniform
+      if (wave + 4 * ui >= UT) continue;  // wave-uniform (never taken when UT % 4 == 0)
+      f32x4 a_r, a_z, a_n, g_n;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int lr = 4 * lq + e;
-        const float r = in.v[ui][e][0], z = in.v[ui][e][1], n = in.v[ui][e][2],
-                    qn = in.v[ui][e][3];
-        const float dht = in.v[ui][e][4] + (in.dn[e] != 0.0f ? 0.0f : dh[ui][e]);
-        const float hp = in.v[ui][e][5];
+        const float r = in.v[ui][0][e], z = in.v[ui][1][e], n = in.v[ui][2][e],
+                    qn = in.v[ui][3][e];
+        const float dht = in.v[ui][4][e] + (reset ? 0.0f : dh[ui][e]);
+        const float hp = in.v[ui][5][e];
         const float dn = dht * (1.0f - z);
         const float dz = dht * (hp - n);
-        float dp = dht * z;
-        float da_n = dn * (1.0f - n * n);
+        const float dp = dht * z;
+        const float da_n = dn * (1.0f - n * n);
         const float dr = da_n * qn;
-        float da_z = dz * z * (1.0f - z);
-        float da_r = dr * r * (1.0f - r);
-        float dgn = da_n * r;
-        if (valid[e]) {
-          const unsigned o3 = rowc[e] * (unsigned)H3 + unit[ui];
-          gio[o3] = da_r;
-          gio[o3 + (unsigned)H] = da_z;
-          gio[o3 + (unsigned)(2 * H)] = da_n;
-          if (gho) {
-            gho[o3] = da_r;
-            gho[o3 + (unsigned)H] = da_z;
-            gho[o3 + (unsigned)(2 * H)] = dgn;
-          }
-          if (ghb) {
-            ghb[o3] = (bf16_t)da_r;
-            ghb[o3 + (unsigned)H] = (bf16_t)da_z;
-            ghb[o3 + (unsigned)(2 * H)] = (bf16_t)dgn;
-          }
-        } else {
-          da_r = da_z = dgn = dp = 0.0f;
-        }
-        dg[lr * GROW + unit[ui]] = (bf16_t)da_r;
-        dg[lr * GROW + H + unit[ui]] = (bf16_t)da_z;
-        dg[lr * GROW + 2 * H + unit[ui]] = (bf16_t)dgn;
-        dhp[ui][e] = dp;
+        const float da_z = dz * z * (1.0f - z);
+        const float da_r = dr * r * (1.0f - r);
+        const float dgn = da_n * r;
+        // rows past B (GUARD) contribute nothing
+        a_r[e] = valid ? da_r : 0.0f;
+        a_z[e] = valid ? da_z : 0.0f;
+        a_n[e] = valid ? da_n : 0.0f;
+        g_n[e] = valid ? dgn : 0.0f;
+        dhp[ui][e] = valid ? dp : 0.0f;
       }
+      if (valid) {
+        const unsigned o3 = rowc * (unsigned)H3 + ucol[ui];
+        *reinterpret_cast<f32x4*>(gio + o3) = a_r;
+        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)H) = a_z;
+        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)(2 * H)) = a_n;
+        if constexpr (F32) {
+          *reinterpret_cast<f32x4*>(gho + o3) = a_r;
+          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)H) = a_z;
+          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)(2 * H)) = g_n;
+        }
+      }
+      bf16x4 b_r, b_z, b_n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        b_r[e] = (bf16_t)a_r[e];
+        b_z[e] = (bf16_t)a_z[e];
+        b_n[e] = (bf16_t)g_n[e];
+      }
+      if constexpr (BF) {
+        if (valid) {
+          const unsigned o3 = rowc * (unsigned)H3 + ucol[ui];
+          *reinterpret_cast<bf16x4*>(ghb + o3) = b_r;
+          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)H) = b_z;
+          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)(2 * H)) = b_n;
+        }
+      }
+      *reinterpret_cast<bf16x4*>(dg + li * GROW + ucol[ui]) = b_r;
+      *reinterpret_cast<bf16x4*>(dg + li * GROW + H + ucol[ui]) = b_z;
+      *reinterpret_cast<bf16x4*>(dg + li * GROW + 2 * H + ucol[ui]) = b_n;
     }
     load_in(t - PFW, in);  // refill this slot: consumed PFW steps from now
     __syncthreads();
@@ -375,13 +392,11 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) {
-      if (ks < KS) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
 #pragma unroll
-        for (int ui = 0; ui < UTW; ++ui)
-          acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ui][ks], acc[ui], 0, 0, 0);
-      }
+      for (int ui = 0; ui < UTW; ++ui)  // D[unit = 4*lq + e][row = li]
+        acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][ks], af, acc[ui], 0, 0, 0);
     }
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui)
@@ -391,18 +406,19 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
     dg = dgn_buf;
     dgn_buf = tmp;
   };
-  for (int64_t t0 = T - 1; t0 >= 0; t0 -= PFW) {
+  int64_t t0 = T - 1;
+  for (; t0 - (PFW - 1) >= 0; t0 -= PFW) {
 #pragma unroll
-    for (int d = 0; d < PFW; ++d)
-      if (t0 - d >= 0) step(t0 - d, inq[d]);
+    for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
   }
+#pragma unroll
+  for (int d = 0; d < PFW; ++d)
+    if (t0 - d >= 0) step(t0 - d, inq[d]);
   if (dh0) {
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       if (wave + 4 * ui >= UT) continue;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (valid[e]) dh0[rowc[e] * (unsigned)H + unit[ui]] = dh[ui][e];
+      if (valid) *reinterpret_cast<f32x4*>(dh0 + rowc * (unsigned)H + ucol[ui]) = dh[ui];
     }
   }
 }
@@ -466,12 +482,29 @@ extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const f
   const size_t lds = (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t);
   const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
   hipStream_t st = mippo::as_stream(stream);
-  if (H <= 64) {
-    hipLaunchKernelGGL((gru_bwd_mfma_kernel<1>), grid, dim3(kThreads), lds, st, g_h, gates, h_prev,
-                       w_h, done, dgi, dgh, dh0, static_cast<bf16_t*>(dgh_bf), T, B, (int)H);
-  } else {
-    hipLaunchKernelGGL((gru_bwd_mfma_kernel<2>), grid, dim3(kThreads), lds, st, g_h, gates, h_prev,
-                       w_h, done, dgi, dgh, dh0, static_cast<bf16_t*>(dgh_bf), T, B, (int)H);
+  const bool guard = B % GROWS != 0;
+  bf16_t* gb = static_cast<bf16_t*>(dgh_bf);
+#define MI_GRU_BWD(HH, GUARD, F32, BF)                                                       \
+  hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, F32, BF>), grid, dim3(kThreads), lds, st, \
+                     g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, gb, T, B)
+#define MI_GRU_BWD_H(HH)                                      \
+  if (H == HH) {                                              \
+    if (dgh && gb) {                                          \
+      if (guard) MI_GRU_BWD(HH, true, true, true);            \
+      else MI_GRU_BWD(HH, false, true, true);                 \
+    } else if (gb) {                                          \
+      if (guard) MI_GRU_BWD(HH, true, false, true);           \
+      else MI_GRU_BWD(HH, false, false, true);                \
+    } else {                                                  \
+      if (guard) MI_GRU_BWD(HH, true, true, false);           \
+      else MI_GRU_BWD(HH, false, true, false);                \
+    }                                                         \
   }
+  MI_GRU_BWD_H(32)
+  MI_GRU_BWD_H(64)
+  MI_GRU_BWD_H(96)
+  MI_GRU_BWD_H(128)
+#undef MI_GRU_BWD_H
+#undef MI_GRU_BWD
   return mippo::check_launch("mi_gru_seq_bwd_bf16");
 }
