@@ -152,7 +152,14 @@ struct WsFwdLds {
   static constexpr size_t bytes = wo + (H / 32) * 1024;
 };
 
-template <int H, int NH, int RT, bool SAMP>
+// FULL: a training launch whose every row tile is whole (M, and the head's M_head, multiples
+// of 16 RT) and that writes every image and mask — the guards around the tile loop's
+// stores are then compile-time true.  That matters beyond the guards' own cost: vmcnt counts
+// loads and stores in order, and the wait for the NEXT tile's prefetched input may leave as
+// many younger instructions in flight as EVERY control-flow path issued; behind a data- or
+// pointer-dependent guard one path has no stores at all, so the wait became vmcnt(0) and each
+// tile's input stage sat until the previous tile's ~20 copy-out stores had reached memory.
+template <int H, int NH, int RT, bool SAMP, bool FULL = false>
 __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, const int nblk,
                                             unsigned char* smem) {
   static_assert(H == 64 || H == 128 || H == 256, "hidden width: 64, 128 or 256");
@@ -302,7 +309,7 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
     WS_TR();  // tile + 1: input staged
     __syncthreads();
     WS_TR();  // tile + 2
-    if (c.x_bf && tid < ROWS && i0 + tid < M) {  // bf16 image of the input (dW operand)
+    if ((FULL || (c.x_bf && i0 + tid < M)) && tid < ROWS) {  // bf16 image of the input (dW operand)
       const int64_t ldx = c.ldx;                 // pad8(K0) <= 32 columns: 16-byte chunks
       for (int k = 0; k < (int)ldx; k += 8)
         *reinterpret_cast<u32x4*>(c.x_bf + (i0 + tid) * ldx + k) =
@@ -340,14 +347,15 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
           }
           *reinterpret_cast<bf16x4*>(nbuf + ((wr * RTW + r) * 16 + li) * AROW + col) = vo;
         }
-        if (mask) ws_mask_store<RTW>(mask, (i0 >> 4) + wr * RTW, H / 16, wc + CW * b, lane, pack);
+        if (FULL || mask)
+          ws_mask_store<RTW>(mask, (i0 >> 4) + wr * RTW, H / 16, wc + CW * b, lane, pack);
       }
     };
     // The layer's bf16 image, out of the published LDS buffer in whole rows: 16 bytes per
     // lane, a wave-instruction covers 1 KiB of consecutive addresses.  All the LDS reads of
     // a thread first, then its stores; the stores drain while the next layer multiplies.
     auto copy_out = [&](const bf16_t* buf, const WsLayer& ly) {
-      if (!ly.out_bf) return;
+      if (!FULL && !ly.out_bf) return;
       constexpr int CPR = H / 8;               // 16-byte chunks per row
       constexpr int RPP = kWsThreads / CPR;    // rows per pass
       constexpr int NP = (ROWS + RPP - 1) / RPP;
@@ -361,7 +369,7 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int row = r0 + p * RPP;
-        if (row < ROWS && i0 + row < M)
+        if ((ROWS % RPP == 0 || row < ROWS) && (FULL || i0 + row < M))
           *reinterpret_cast<u32x4*>(ly.out_bf + (i0 + row) * ly.ldo + cc * 8) = v[p];
       }
     };
@@ -421,7 +429,7 @@ __device__ __forceinline__ void ws_fwd_body(const WsChain& c, const int bid, con
       for (int e = 0; e < 4; ++e) {
         if (4 * lq + e < N_out) {
           const float v = ah[e] + BO[e];
-          if (gi < M) c.out[gi * N_out + 4 * lq + e] = v;
+          if (FULL || gi < M) c.out[gi * N_out + 4 * lq + e] = v;
           // the sampler's input rows wait in LDS until the stash is full (below)
           if (has_samp) ms_s[(stash_n * ROWS + row) * N_out + 4 * lq + e] = v;
         }
@@ -736,16 +744,16 @@ trunk_ws_fwd_kernel(WsChain c) {
 // 64-deep step ahead — at 16 rows per workgroup that is a chain of dependent L2 round
 // trips (~27 000 cycles for ~300 of MFMA); here all of a trunk's fragments are requested
 // at once, up front, and the layers run out of registers.
-template <int HV, int NHV, int HA, int NHA, int RT>
+template <int HV, int NHV, int HA, int NHA, int RT, bool FULL>
 __global__ void __launch_bounds__(kWsThreads, 2)
 policy_ws_dual_kernel(WsChain a, WsChain v, int n_value) {
   constexpr size_t nv = WsFwdLds<HV, RT, false>::bytes, na = WsFwdLds<HA, RT, true>::bytes;
   __shared__ __attribute__((aligned(16))) unsigned char smem[nv > na ? nv : na];
   if ((int)blockIdx.x < n_value)
-    ws_fwd_body<HV, NHV, RT, false>(v, (int)blockIdx.x, n_value, smem);
+    ws_fwd_body<HV, NHV, RT, false, FULL>(v, (int)blockIdx.x, n_value, smem);
   else
-    ws_fwd_body<HA, NHA, RT, true>(a, (int)blockIdx.x - n_value, (int)gridDim.x - n_value,
-                                   smem);
+    ws_fwd_body<HA, NHA, RT, true, FULL>(a, (int)blockIdx.x - n_value,
+                                         (int)gridDim.x - n_value, smem);
 }
 
 // ---- backward (dX chain) ------------------------------------------------------------------
@@ -1379,10 +1387,22 @@ int ws_dual_launch_rt(const WsChain& a, const WsChain& v, int64_t hv, int64_t nh
              "sampler stash", a.N_out);
   int64_t nv, na;
   ws_dual_split(mippo::ceil_div(v.M, 16 * RT), mippo::ceil_div(a.M, 16 * RT), &nv, &na);
+  // every row tile whole, every image and mask asked for: the guard-free instantiation
+  auto whole = [](const WsChain& c, int L) {
+    if (c.M % (16 * RT) || c.M_head % (16 * RT) || !c.x_bf) return false;
+    for (int l = 0; l + 1 < L; ++l)
+      if (!c.layer[l].out_bf || !c.layer[l].mask_out) return false;
+    return true;
+  };
+  const bool full = RT == 4 && whole(a, (int)nha + 2) && whole(v, (int)nhv + 2);
 #define X(p, q, r, s_)                                                                      \
   if (hv == p && nhv == q && ha == r && nha == s_) {                                        \
-    hipLaunchKernelGGL((policy_ws_dual_kernel<p, q, r, s_, RT>), dim3((unsigned)(nv + na)), \
-                       dim3(kWsThreads), 0, st, a, v, (int)nv);                             \
+    if (full)                                                                               \
+      hipLaunchKernelGGL((policy_ws_dual_kernel<p, q, r, s_, RT, RT == 4>),                 \
+                         dim3((unsigned)(nv + na)), dim3(kWsThreads), 0, st, a, v, (int)nv); \
+    else                                                                                    \
+      hipLaunchKernelGGL((policy_ws_dual_kernel<p, q, r, s_, RT, false>),                   \
+                         dim3((unsigned)(nv + na)), dim3(kWsThreads), 0, st, a, v, (int)nv); \
     return mippo::check_launch("mi_policy_ws_fwd_bf16(one launch)");                        \
   }
   WS_DUAL_MENU(X)
