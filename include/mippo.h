@@ -650,6 +650,36 @@ int mi_policy_ws_bwd_bf16(
     const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
     const void* const* a_mask, const void* const* c_mask, mi_stream_t stream);
 
+/* mi_gae_ppo_loss_f32 + mi_policy_ws_bwd_bf16 in ONE launch (replaces the GAE / loss launch
+ * between the replay forward and the backward of `nnx_ppo/algorithms/ppo.py:433-503` for the
+ * fused MLP actor-critic): the [T, B] operands of mi_gae_ppo_loss_f32 come in instead of
+ * g_loglik / g_value.  Every workgroup scans the env groups of its own row tiles; the
+ * advantage statistics are summed from per-group partials that B / 64 action-trunk
+ * workgroups publish (same accumulation order and shuffle trees as gae_loss_kernel: the same
+ * bits); d loss / d log-likelihood and d loss / d value are evaluated where they are
+ * consumed; loss_out[4] (actor, critic, regularisation, clipping fraction) is summed from
+ * per-tile fp64 partials by the last workgroup.  dz images bit-identical to the two-launch
+ * path; the four scalars differ from it in fp64 summation order only.
+ * Supported: T <= 32, B % 64 == 0, B <= 2048, scalar value head, the one-launch trunk menu at
+ * 64-row tiles, masks given.  workspace: mi_policy_ws_bwd_gae_workspace_bytes(T * B) bytes,
+ * zeroed once (the launch re-arms it). */
+int64_t mi_policy_ws_bwd_gae_workspace_bytes(int64_t M);
+int mi_policy_ws_bwd_gae_supported(int64_t T, int64_t B, int64_t La, const int64_t* a_dims,
+                                   const int64_t* a_acts, int64_t Lc, const int64_t* c_dims,
+                                   const int64_t* c_acts);
+int mi_policy_ws_bwd_gae_bf16(
+    const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, float g_reg, float min_std, float std_scale,
+    float entropy_weight, const float* rewards, const float* values, const float* last_value,
+    const uint8_t* done, const uint8_t* truncated, const float* ll_new, const float* ll_old,
+    const float* reg, float gamma, float lambda, int normalize, float clip_range,
+    float critic_weight, float* loss_out, void* workspace, int64_t T, int64_t B, int64_t La,
+    const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
+    const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
+    const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
+    const void* const* a_mask, const void* const* c_mask, mi_stream_t stream);
+
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
  * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,
  * done = step' >= max_steps, obs = unit-variance noise from fold(key, step') written to

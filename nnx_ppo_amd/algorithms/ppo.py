@@ -454,7 +454,21 @@ def ppo_loss(
         reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
         fused_loss = (FUSED_GAE_LOSS and not parallel.is_distributed()
                       and ops.gae_ppo_loss_supported(T, B))
-        if fused_loss:
+        gae_bwd = (fused_loss and backward and LoggingLevel.CRITIC_EXTRA not in logging_level
+                   and fused is not None and hasattr(networks, "replay_backward_gae")
+                   and networks.gae_backward_supported(ctx, T, B))
+        if gae_bwd:
+            # no launch at all between the replay forward and the backward: the scan, the
+            # statistics and the loss gradients are evaluated by the backward's workgroups
+            loss_out = networks.replay_backward_gae(
+                ctx, 1.0 / float(T * B), rewards.contiguous(), values,
+                last_values.contiguous(), done.contiguous(), truncated.contiguous(),
+                ll_new.contiguous(), ll_old.contiguous(),
+                None if reg_seq is None else reg_seq.contiguous(), discounting_factor,
+                gae_lambda, normalize_advantages, clip_range, critic_loss_weight,
+                loss_out=loss_out)
+            backward = False
+        elif fused_loss:
             # GAE, advantage statistics, loss terms and gradients in ONE launch (the
             # advantages never leave registers); a sharded run exchanges the statistics
             # between the two phases and keeps the two launches

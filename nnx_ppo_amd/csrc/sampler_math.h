@@ -116,11 +116,13 @@ struct BwdParams {
 
 // Gradient w.r.t. the 2A inputs of row b, written to grow[0..2A) through `store`
 // (fp32 global row in the stand-alone kernel, bf16 LDS row in the fused backward).
+// `gl` = d loss / d log-likelihood of the row (bwd_row reads it from p.g_ll; the backward
+// that evaluates the loss terms itself, trunk_ws.hip GAE, has it in a register).
 template <typename Store>
-__device__ __forceinline__ void bwd_row(int64_t b, const BwdParams& p, Store store) {
+__device__ __forceinline__ void bwd_row_gl(int64_t b, const BwdParams& p, const float gl,
+                                           Store store) {
   const int A = p.A;
   const float* row = p.ms + b * 2 * A;
-  const float gl = p.g_ll ? p.g_ll[b] : 0.0f;
   const float gh = -p.entropy_weight * p.g_reg;  // d loss / d H
   for (int a = 0; a < A; ++a) {
     const int64_t e = b * A + a;
@@ -141,6 +143,11 @@ __device__ __forceinline__ void bwd_row(int64_t b, const BwdParams& p, Store sto
     store(a, g_mu);
     store(A + a, g_sigma * sigmoidf(s) * p.std_scale);
   }
+}
+
+template <typename Store>
+__device__ __forceinline__ void bwd_row(int64_t b, const BwdParams& p, Store store) {
+  bwd_row_gl(b, p, p.g_ll ? p.g_ll[b] : 0.0f, store);
 }
 
 }  // namespace mippo_sampler

@@ -790,12 +790,167 @@ struct WsBwdLds {
   static constexpr size_t bytes = bufB + kRows * (H + 8) * 2;
 };
 
+// ---- GAE: the reverse scan, the advantage statistics and the loss terms INSIDE this launch ----
+// (a13 + a14, ppo.py:351-394, 447-458, 477-503; arithmetic of gae_loss.hip expression for
+// expression).  mi_gae_ppo_loss_f32 is a launch of 16 workgroups between the replay forward
+// and this kernel — 15 us of launch, round-trip and exchange latency per gradient step for
+// 0.4 MB of operands.  Here every workgroup scans the 64 envs of each of its OWN row tiles
+// (row tile = 64 rows = (step t, env group g): the group's scan from T-1 down to t, one wave
+// per tile) and keeps the tile's advantages (and values) in LDS; d loss / d value needs the
+// raw advantage only.  The advantage STATISTICS are the one global quantity: action-trunk
+// workgroup g < B / 64 also scans env group g whole and publishes its (sum, sum of squares);
+// every action-trunk workgroup waits for the B / 64 partials (a counter and a bounded spin:
+// the launch has at most one workgroup per CU, all co-resident) and sums them in
+// gae_loss_kernel's order — same per-env accumulation, same shuffle trees, the same bits.
+// (A first form had every action-trunk workgroup scan all of [T, B] itself, no exchange: 2 x
+// 13 000 cycles of fp64 accumulation and LDS transposes per workgroup, slower than the launch
+// it replaced.)  d loss / d log-likelihood and d loss / d value are evaluated by the threads
+// that consume them (the sampler backward's row thread, the head-gradient stage), and the four
+// loss scalars are summed from per-tile fp64 partials by the last workgroup to finish.
+// B % 64 == 0.
+struct WsGae {
+  const float *rewards, *values, *last_value;  // [T][B], [T][B], [B]
+  const unsigned char *done, *trunc;           // [T][B]
+  const float *ll_new, *ll_old, *reg;          // [T][B]; reg nullable
+  float* loss_out;                             // [4] actor, critic, regularisation, clip fraction
+  double* part;                                // workspace: [ntiles][4] partial sums
+  double* sp;                                  // workspace: [groups][2] statistics partials
+  unsigned int *ticket, *arrive;               // workspace header (zero between launches)
+  int T, B;
+  float gamma, lambda, clip, critic_weight;
+  int normalize;
+};
+constexpr int kGaeMaxT = 32;
+constexpr int kGaeMaxQ = 16;    // row tiles a workgroup may own
+constexpr int kGaeMaxGroups = 32;  // B <= 2048
+constexpr int kGaeHeaderBytes = 64 + kGaeMaxGroups * 2 * 8;  // [ticket | arrive | pad][sp]
+constexpr unsigned long long kGaeSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+constexpr size_t kGaeStageBytes = kGaeMaxT * 64 * 5;  // per wave: 32 x 64 floats + 32 x 64 bytes
+struct WsGaeLds {
+  static constexpr size_t adv = 0;                                   // float [kGaeMaxQ][64]
+  static constexpr size_t val = adv + kGaeMaxQ * 64 * 4;              // float [kGaeMaxQ][64]
+  static constexpr size_t norm = val + kGaeMaxQ * 64 * 4;             // float [2]
+  static constexpr size_t last = norm + 8;                            // int
+  static constexpr size_t bytes = last + 8;
+};
+
+// The reverse scan of env group `grp` (one env per lane) from step T-1 down to t_stop;
+// emit(t, advantage, value) at every step, (sum, sum of squares) of the lane's advantages
+// returned through s / s2.  Wave-uniform arguments.
+// Operand loads: what bounds this phase is the NUMBER of vector-memory instructions a CU
+// issues (~22 cycles each, L2-warm), not bytes — one dword per lane and step was 128
+// instructions per wave and 10 us per 8 groups.  So every instruction moves 1 KiB (16 bytes per
+// lane: 4 steps x 64 floats, or 16 steps x 64 flag bytes), 20 instructions per group, all
+// requested before the first is used, and the [step][env] blocks are turned into per-lane
+// columns through a wave-private LDS staging area (sf: 32 x 64 floats, sb: 32 x 64 bytes).
+// Rows start 16-byte aligned (B % 64 == 0, bases checked on the host); steps past T re-read
+// step T-1 (branch-free: behind a per-step predicate the compiler paired each step's loads
+// with the step before's arithmetic — 30 dependent round trips).
+template <bool STATS, typename Emit>
+__device__ __forceinline__ void ws_gae_scan_group(const WsGae& g, const int grp, const int t_stop,
+                                                  const int lane, float* sf, unsigned char* sb,
+                                                  double& s, double& s2, Emit emit) {
+#pragma clang fp contract(off)
+  const int T = g.T;
+  const int64_t B = g.B;
+  const int64_t e0 = (int64_t)grp * 64;
+  u32x4 qr[kGaeMaxT / 4], qv[kGaeMaxT / 4], qd[kGaeMaxT / 16], qt[kGaeMaxT / 16];
+#pragma unroll
+  for (int k = 0; k < kGaeMaxT / 4; ++k) {
+    const int t = 4 * k + (lane >> 4);
+    const int64_t o = (int64_t)(t < T ? t : T - 1) * B + e0 + 4 * (lane & 15);
+    qr[k] = *reinterpret_cast<const u32x4*>(g.rewards + o);
+    qv[k] = *reinterpret_cast<const u32x4*>(g.values + o);
+  }
+#pragma unroll
+  for (int k = 0; k < kGaeMaxT / 16; ++k) {
+    const int t = 16 * k + (lane >> 2);
+    const int64_t o = (int64_t)(t < T ? t : T - 1) * B + e0 + 16 * (lane & 3);
+    qd[k] = *reinterpret_cast<const u32x4*>(g.done + o);
+    qt[k] = *reinterpret_cast<const u32x4*>(g.trunc + o);
+  }
+  float next_v = g.last_value[e0 + lane], next_a = 0.0f;
+  __builtin_amdgcn_sched_barrier(0);
+  float r[kGaeMaxT], v[kGaeMaxT];
+  unsigned char d[kGaeMaxT], tr[kGaeMaxT];
+  u32x4* const sf4 = reinterpret_cast<u32x4*>(sf) + lane;  // (4 k + lane / 16) * 64 + 4 (lane % 16)
+  u32x4* const sb4 = reinterpret_cast<u32x4*>(sb) + lane;  // (16 k + lane / 4) * 64 + 16 (lane % 4)
+#pragma unroll
+  for (int k = 0; k < kGaeMaxT / 4; ++k) sf4[64 * k] = qr[k];
+#pragma unroll
+  for (int t = 0; t < kGaeMaxT; ++t) r[t] = sf[t * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < kGaeMaxT / 4; ++k) sf4[64 * k] = qv[k];
+#pragma unroll
+  for (int t = 0; t < kGaeMaxT; ++t) v[t] = sf[t * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < kGaeMaxT / 16; ++k) sb4[64 * k] = qd[k];
+#pragma unroll
+  for (int t = 0; t < kGaeMaxT; ++t) d[t] = sb[t * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < kGaeMaxT / 16; ++k) sb4[64 * k] = qt[k];
+#pragma unroll
+  for (int t = 0; t < kGaeMaxT; ++t) tr[t] = sb[t * 64 + lane];
+  s = 0.0;
+  s2 = 0.0;
+#pragma unroll
+  for (int t = kGaeMaxT - 1; t >= 0; --t) {
+    if (t < T && t >= t_stop) {
+      const float vt = v[t];
+      const float nv = d[t] ? 0.0f : next_v;
+      float delta = (r[t] + g.gamma * nv) - vt;
+      delta = tr[t] ? 0.0f : delta;
+      const float keep = d[t] ? 0.0f : 1.0f;
+      const float av = delta + ((keep * g.gamma) * g.lambda) * next_a;
+      if constexpr (STATS) {
+        s += (double)av;
+        s2 += (double)av * (double)av;
+      }
+      next_a = av;
+      next_v = vt;
+      emit(t, av, vt);
+    }
+  }
+}
+
+// d loss / d value of one element and its squared error (gae_loss.hip phase 2, critic terms)
+__device__ __forceinline__ float ws_gae_value_grad(const WsGae& g, const float a_raw,
+                                                   const float v, double& sq) {
+#pragma clang fp contract(off)
+  const float inv_n = 1.0f / (float)((int64_t)g.T * (int64_t)g.B);
+  const float target = v + a_raw;  // ppo.py:456-458
+  const float diff = v - target;
+  sq = (double)(diff * diff);
+  return g.critic_weight * diff * inv_n;
+}
+
+// d loss / d log-likelihood of one element and its three actor-side loss terms
+// (gae_loss.hip phase 2: clipped surrogate, regulariser row, clipping indicator)
+__device__ __forceinline__ float ws_gae_actor_grad(const WsGae& g, const float a_raw,
+                                                   const float mean, const float denom,
+                                                   const float lln, const float llo,
+                                                   const float rg, double (&q)[3]) {
+#pragma clang fp contract(off)
+  const float inv_n = 1.0f / (float)((int64_t)g.T * (int64_t)g.B);
+  const float lo = 1.0f - g.clip, hi = 1.0f + g.clip;
+  const float an = g.normalize ? (a_raw - mean) / denom : a_raw;
+  const float rt = expf(lln - llo);
+  const float c1 = rt * an;
+  const float c2 = fminf(fmaxf(rt, lo), hi) * an;
+  q[0] = (double)fminf(c1, c2);
+  q[1] = (double)rg;
+  q[2] = fabsf(rt - 1.0f) > g.clip ? 1.0 : 0.0;
+  return c1 <= c2 ? -(an * rt) * inv_n : 0.0f;
+}
+
 // MASK: relu' comes from the forward's masks — one byte per lane and 16 x 16 tile instead of
 // 8 bytes of the bf16 image; the images are 48 % of this kernel's HBM bytes at BASELINE C2
 // and the kernel waits on exactly those loads (profiles/r02_trace_ws_bwd.txt).
-template <int H, int NH, int RT, bool SAMP, bool MASK = false>
+template <int H, int NH, int RT, bool SAMP, bool MASK = false, bool GAE = false>
 __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, const int nblk,
-                                            unsigned char* smem) {
+                                            unsigned char* smem, const WsGae* gp = nullptr,
+                                            unsigned char* gsm = nullptr) {
+  static_assert(!GAE || (RT == 4 && MASK), "GAE: 64-row tiles, masks");
   using G = WsGeom<H>;
   constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
   constexpr int RTW = RT / RW;
@@ -824,27 +979,156 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
   // ---- the transposed trunk, once -------------------------------------------------------
   bf16x8 WO[TPW];
   bf16x8 WH[NH > 0 ? NH : 1][TPW][KSH];
+  auto load_weights = [&]() {
 #pragma unroll
-  for (int b = 0; b < TPW; ++b) {
-    const unsigned ct = (unsigned)(wc + CW * b);
-    WO[b] = ws_frag(c.layer[0].w, ct, 0, 1, lane);
+    for (int b = 0; b < TPW; ++b) {
+      const unsigned ct = (unsigned)(wc + CW * b);
+      WO[b] = ws_frag(c.layer[0].w, ct, 0, 1, lane);
 #pragma unroll
-    for (int l = 0; l < NH; ++l)
+      for (int l = 0; l < NH; ++l)
 #pragma unroll
-      for (int ks = 0; ks < KSH; ++ks) WH[l][b][ks] = ws_frag(c.layer[1 + l].w, ct, ks, KSH, lane);
-  }
+        for (int ks = 0; ks < KSH; ++ks)
+          WH[l][b][ks] = ws_frag(c.layer[1 + l].w, ct, ks, KSH, lane);
+    }
+  };
+  // GAE: the scan holds ~130 registers of operands in flight; the stationary fragments are
+  // requested after it (with both live the allocator spilled to scratch)
+  if constexpr (!GAE) load_weights();
   // pad columns N_out..31 of the head-gradient rows stay zero for the whole kernel
-  for (int i = tid; i < kStashTiles * ROWS * 32; i += kWsThreads) {
-    const int row = i >> 5, k = i & 31;
-    if (k >= N_out) bufX[row * XROW + k] = (bf16_t)0.0f;
+  auto zero_pad = [&]() {
+    for (int i = tid; i < kStashTiles * ROWS * 32; i += kWsThreads) {
+      const int row = i >> 5, k = i & 31;
+      if (k >= N_out) bufX[row * XROW + k] = (bf16_t)0.0f;
+    }
+  };
+  if constexpr (!GAE) zero_pad();  // GAE: the scan's staging area lies over these buffers
+
+  // ---- GAE: the scan, before anything needs a gradient row (see WsGae) ----------------------
+  float* const s_adv = reinterpret_cast<float*>(gsm + WsGaeLds::adv);
+  float* const s_val = reinterpret_cast<float*>(gsm + WsGaeLds::val);
+  float g_mean = 0.0f, g_denom = 1.0f;
+  float pre_lln = 0.0f, pre_llo = 0.0f, pre_rg = 0.0f;  // SAMP: the first stash round's rows
+  if constexpr (GAE) {
+    const WsGae& g = *gp;
+    const int GB = g.B >> 6;  // env groups = row tiles per step
+    float* const sf = reinterpret_cast<float*>(smem + (size_t)wave * kGaeStageBytes);
+    unsigned char* const sb = smem + (size_t)wave * kGaeStageBytes + kGaeMaxT * 64 * 4;
+    if constexpr (SAMP) {
+      const int64_t t0 = (int64_t)bid + (int64_t)wave * nblk;  // slot = wave, row = lane
+      if (t0 < ntiles) {
+        const int64_t gi = t0 * ROWS + lane;
+        pre_lln = g.ll_new[gi];
+        pre_llo = g.ll_old[gi];
+        if (g.reg) pre_rg = g.reg[gi];
+      }
+      // the statistics: action-trunk workgroup `bid` < GB scans env group `bid` whole (its
+      // last wave, beside the others' own-tile scans) and publishes the group's partial
+      if (g.normalize && wave == kWsThreads / 64 - 1 && bid < GB) {
+        double s1, s2;
+        ws_gae_scan_group<true>(g, bid, 0, lane, sf, sb, s1, s2, [](int, float, float) {});
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          s1 += __shfl_down(s1, off, 64);
+          s2 += __shfl_down(s2, off, 64);
+        }
+        if (lane == 0) {
+          // write-through (sc1) stores, drained, then the arrival (gae_loss.hip's hand-over)
+          __hip_atomic_store(&g.sp[2 * bid], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&g.sp[2 * bid + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(g.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        WS_TR();  // GAE (publishing workgroups only): group partial out
+      }
+    }
+    // the advantages (and values) of this workgroup's own row tiles: tile q = (step t_q, group),
+    // the group's scan from T-1 down to t_q, one wave per tile
+    for (int q = wave; q < kGaeMaxQ; q += 8) {
+      const int64_t tq = (int64_t)bid + (int64_t)q * nblk;
+      if (tq < ntiles) {
+        const int t_q = (int)(tq / GB);
+        const int grp = (int)(tq - (int64_t)t_q * GB);
+        double s1, s2;
+        ws_gae_scan_group<false>(g, grp, t_q, lane, sf, sb, s1, s2,
+                                 [&](int t, float av, float vt) {
+                                   if (t == t_q) {
+                                     s_adv[q * 64 + lane] = av;
+                                     if (!SAMP) s_val[q * 64 + lane] = vt;
+                                   }
+                                 });
+      }
+    }
+    WS_TR();  // GAE: own row tiles scanned
+    if (SAMP && g.normalize) {
+      float* const s_norm = reinterpret_cast<float*>(gsm + WsGaeLds::norm);
+      if (wave == 0) {
+        if (lane == 0) {
+          const unsigned long long t0 = wall_clock64();
+          while (__hip_atomic_load(g.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                 (unsigned)GB) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > kGaeSpinTicks) break;  // never in a healthy launch
+          }
+        }
+        // acquire only: the partials may sit stale in this XCD's L2 from the previous launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // gae_loss_kernel's tree over the group partials: lane-strided, then lane order
+        double t1 = 0.0, t2 = 0.0;
+        for (int gg = lane; gg < GB; gg += 64) {
+          t1 += __hip_atomic_load(&g.sp[2 * gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t2 += __hip_atomic_load(&g.sp[2 * gg + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          t1 += __shfl_down(t1, off, 64);
+          t2 += __shfl_down(t2, off, 64);
+        }
+        if (lane == 0) {
+          const double cnt = (double)g.T * (double)g.B;
+          const double m = t1 / cnt;
+          double var = t2 / cnt - m * m;
+          if (var < 0.0) var = 0.0;
+          s_norm[0] = (float)m;
+          s_norm[1] = (float)sqrt(var) + 1e-8f;
+        }
+      }
+      __syncthreads();
+      g_mean = s_norm[0];
+      g_denom = s_norm[1];
+    } else {
+      __syncthreads();
+    }
+    WS_TR();  // GAE: prologue done
+  }
+
+  if constexpr (GAE) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_weights();
+    zero_pad();  // after the prologue's last barrier: the staging area is free
   }
 
   constexpr int IN_PT = (ROWS * 16 + kWsThreads - 1) / kWsThreads;  // N_out <= 16
   const int nel = ROWS * N_out;
   const float rcpN = 1.0f / (float)N_out;
   float gin[IN_PT];
+  int q_next = 0;  // GAE: ordinal (among this workgroup's) of the tile requested next
   auto request_input = [&](int64_t tile) {
     if (SAMP) return;
+    if constexpr (GAE) {  // N_out == 1: row e of the tile, wave 0
+#pragma unroll
+      for (int u = 0; u < IN_PT; ++u) gin[u] = 0.0f;
+      if (tid < 64) {
+        double sq;
+        gin[0] = ws_gae_value_grad(*gp, s_adv[q_next * 64 + tid], s_val[q_next * 64 + tid], sq);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (tid == 0)
+          __hip_atomic_store(&gp->part[4 * tile + 1], sq, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      ++q_next;
+      return;
+    }
     const int64_t g0 = tile * ROWS * N_out;
 #pragma unroll
     for (int u = 0; u < IN_PT; ++u) {
@@ -856,6 +1140,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
   WS_TR();  // 1: weights requested
   int64_t tile = bid;
   int stash_n = 0, stash_i = 0;  // SAMP: head-gradient rows of `stash_n` row tiles wait in bufX
+  int stash_round = 0;           // GAE: rounds of kStashTiles row tiles done
   if (tile < ntiles) request_input(tile);
   for (; tile < ntiles; tile += nblk) {
     const int64_t i0 = tile * ROWS;
@@ -871,7 +1156,32 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
         if (t < ntiles) {
           bf16_t* dst = bufX + (slot * ROWS + row) * XROW;
           const int64_t gi = t * ROWS + row;
-          if (gi < M) {
+          if constexpr (GAE) {  // whole tiles (M = T B, B % 64 == 0): slot = wave, row = lane
+            const WsGae& g = *gp;
+            float lln = pre_lln, llo = pre_llo, rg = pre_rg;
+            if (stash_round > 0) {
+              lln = g.ll_new[gi];
+              llo = g.ll_old[gi];
+              rg = g.reg ? g.reg[gi] : 0.0f;
+            }
+            double q3[3];
+            const float gl = ws_gae_actor_grad(
+                g, s_adv[(stash_round * kStashTiles + slot) * 64 + row], g_mean, g_denom, lln, llo,
+                rg, q3);
+            mippo_sampler::bwd_row_gl(gi, c.sbwd, gl, [dst](int j, float v) { dst[j] = (bf16_t)v; });
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) q3[k] += __shfl_down(q3[k], off, 64);
+            if (row == 0) {
+              __hip_atomic_store(&g.part[4 * t + 0], q3[0], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&g.part[4 * t + 2], q3[1], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&g.part[4 * t + 3], q3[2], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+          } else if (gi < M) {
             mippo_sampler::bwd_row(gi, c.sbwd, [dst](int j, float v) { dst[j] = (bf16_t)v; });
           } else {
             for (int k = 0; k < N_out; ++k) dst[k] = (bf16_t)0.0f;
@@ -881,6 +1191,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
         for (int q = 0; q < kStashTiles; ++q)
           if (tile + (int64_t)q * nblk < ntiles) ++stash_n;
         stash_i = 0;
+        ++stash_round;
       }
       xin = bufX + stash_i * ROWS * XROW;
       ++stash_i;
@@ -1046,6 +1357,56 @@ policy_ws_bwd_dual_kernel(WsBwdChain a, WsBwdChain v, int n_value) {
   else
     ws_bwd_body<HA, NHA, RT, true, MASK>(a, (int)blockIdx.x - n_value,
                                          (int)gridDim.x - n_value, smem);
+}
+
+// The same launch with the GAE scan and the loss terms inside (WsGae): no g_loglik / g_value
+// operands, the four loss scalars summed from the per-tile partials by the last workgroup.
+template <int HV, int NHV, int HA, int NHA>
+__global__ void __launch_bounds__(kWsThreads, 2)
+policy_ws_bwd_gae_kernel(WsBwdChain a, WsBwdChain v, WsGae g, int n_value) {
+  constexpr size_t nv = WsBwdLds<HV, 4, false>::bytes, na = WsBwdLds<HA, 4, true>::bytes;
+  constexpr size_t nst = (kWsThreads / 64) * kGaeStageBytes;  // the scan's staging, all waves
+  constexpr size_t nb0 = nv > na ? nv : na;
+  constexpr size_t nb = ((nb0 > nst ? nb0 : nst) + 15) / 16 * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[nb + WsGaeLds::bytes];
+  unsigned char* const gsm = smem + nb;
+  if ((int)blockIdx.x < n_value)
+    ws_bwd_body<HV, NHV, 4, false, true, true>(v, (int)blockIdx.x, n_value, smem, &g, gsm);
+  else
+    ws_bwd_body<HA, NHA, 4, true, true, true>(a, (int)blockIdx.x - n_value,
+                                              (int)gridDim.x - n_value, smem, &g, gsm);
+  // this workgroup's partials are out (write-through stores, drained) before it takes a ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* const s_last = reinterpret_cast<int*>(gsm + WsGaeLds::last);
+  const int tid = threadIdx.x;
+  if (tid == 0)
+    *s_last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+              gridDim.x - 1;
+  __syncthreads();
+  if (*s_last && tid < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int64_t ntiles = a.M / 64;
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t t = tid; t < ntiles; t += 64)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        z[k] += __hip_atomic_load(&g.part[4 * t + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] += __shfl_down(z[k], off, 64);
+    if (tid == 0) {
+      const double dn = (double)g.T * (double)g.B;
+      g.loss_out[0] = (float)(-z[0] / dn);
+      g.loss_out[1] = (float)(0.5 * z[1] / dn);
+      g.loss_out[2] = (float)(z[2] / dn);
+      g.loss_out[3] = (float)(z[3] / dn);
+      // every workgroup is past the statistics spin (it finished): re-arm both counters
+      __hip_atomic_store(g.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 int ws_grid(int64_t ntiles) {
@@ -1364,6 +1725,84 @@ extern "C" int mi_policy_ws_bwd_bf16(
   rc = ws_bwd_dispatch(a, a_dims[1], La - 2, st);
   if (rc) return rc;
   return ws_bwd_dispatch(v, c_dims[1], Lc - 2, st);
+}
+
+// ---- mi_policy_ws_bwd_gae_bf16: mi_gae_ppo_loss_f32 + mi_policy_ws_bwd_bf16 in one launch ----
+extern "C" int64_t mi_policy_ws_bwd_gae_workspace_bytes(int64_t M) {
+  return kGaeHeaderBytes + mippo::ceil_div(M, 64) * 4 * (int64_t)sizeof(double);
+}
+
+// 1 if a [T, B] minibatch on these trunks can take the launch with the GAE inside: the
+// one-launch menu at 64-row tiles, a scalar value head, whole (step, env group) row tiles, and
+// no workgroup with more than kGaeMaxQ of them.
+extern "C" int mi_policy_ws_bwd_gae_supported(int64_t T, int64_t B, int64_t La,
+                                              const int64_t* a_dims, const int64_t* a_acts,
+                                              int64_t Lc, const int64_t* c_dims,
+                                              const int64_t* c_acts) {
+  if (!a_dims || !a_acts || !c_dims || !c_acts || La < 2 || Lc < 2) return 0;
+  if (T < 1 || T > kGaeMaxT || B < 64 || B % 64 || B > 64 * kGaeMaxGroups) return 0;
+  if (!mi_policy_ws_supported(La, a_dims, a_acts, Lc, c_dims, c_acts)) return 0;
+  if (c_dims[Lc] != 1 || !ws_dual_has(c_dims[1], Lc - 2, a_dims[1], La - 2)) return 0;
+  const int64_t M = T * B;
+  if (2 * mippo::ceil_div(M, 32) <= ws_grid(1 << 30)) return 0;  // 32-row-tile sizes
+  int64_t nv, na;
+  ws_dual_split(M / 64, M / 64, &nv, &na);
+  return na >= B / 64 &&  // one publishing workgroup per env group
+         mippo::ceil_div(M / 64, nv) <= kGaeMaxQ && mippo::ceil_div(M / 64, na) <= kGaeMaxQ;
+}
+
+extern "C" int mi_policy_ws_bwd_gae_bf16(
+    const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, float g_reg, float min_std, float std_scale,
+    float entropy_weight, const float* rewards, const float* values, const float* last_value,
+    const uint8_t* done, const uint8_t* truncated, const float* ll_new, const float* ll_old,
+    const float* reg, float gamma, float lambda, int normalize, float clip_range,
+    float critic_weight, float* loss_out, void* workspace, int64_t T, int64_t B, int64_t La,
+    const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
+    const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
+    const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
+    const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
+    const void* const* a_mask, const void* const* c_mask, mi_stream_t stream) {
+  MI_REQUIRE(mean_and_std && extras && rewards && values && last_value && done && truncated &&
+                 ll_new && ll_old && loss_out && workspace && a_mask && c_mask,
+             "mi_policy_ws_bwd_gae_bf16: null pointer");
+  MI_REQUIRE(rng_state || eps2, "mi_policy_ws_bwd_gae_bf16: need rng_state or injected eps2");
+  MI_REQUIRE(mi_policy_ws_bwd_gae_supported(T, B, La, a_dims, a_acts, Lc, c_dims, c_acts),
+             "mi_policy_ws_bwd_gae_bf16: [T=%lld, B=%lld] on these trunks is outside the fused "
+             "class (mi_policy_ws_bwd_gae_supported)", (long long)T, (long long)B);
+  MI_REQUIRE(al16(rewards) && al16(values) && al16(done) && al16(truncated),
+             "mi_policy_ws_bwd_gae_bf16: rewards / values / done / truncated must be 16-byte "
+             "aligned");
+  const int64_t M = T * B;
+  hipStream_t st = mippo::as_stream(stream);
+  WsBwdChain a;
+  int rc = ws_bwd_fill(a, "mi_policy_ws_bwd_gae_bf16(action)", nullptr, M, La, a_w, a_dims,
+                       a_acts, a_aux, a_dz_last, a_dz_bf, a_mask);
+  if (rc) return rc;
+  const int64_t A2 = a_dims[La];
+  a.sbwd = {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, nullptr, g_reg,
+            (int)(A2 / 2), min_std, std_scale, entropy_weight};
+  WsBwdChain v;
+  rc = ws_bwd_fill(v, "mi_policy_ws_bwd_gae_bf16(value)", nullptr, M, Lc, c_w, c_dims, c_acts,
+                   c_aux, c_dz_last, c_dz_bf, c_mask);
+  if (rc) return rc;
+  WsGae g = {rewards, values, last_value, done, truncated, ll_new, ll_old, reg, loss_out,
+             reinterpret_cast<double*>(static_cast<char*>(workspace) + kGaeHeaderBytes),
+             reinterpret_cast<double*>(static_cast<char*>(workspace) + 64),
+             static_cast<unsigned int*>(workspace), static_cast<unsigned int*>(workspace) + 1,
+             (int)T, (int)B, gamma, lambda, clip_range, critic_weight, normalize};
+  int64_t nv, na;
+  ws_dual_split(M / 64, M / 64, &nv, &na);
+  const int64_t hv = c_dims[1], nhv = Lc - 2, ha = a_dims[1], nha = La - 2;
+#define X(p, q, r, s_)                                                                     \
+  if (hv == p && nhv == q && ha == r && nha == s_) {                                       \
+    hipLaunchKernelGGL((policy_ws_bwd_gae_kernel<p, q, r, s_>), dim3((unsigned)(nv + na)), \
+                       dim3(kWsThreads), 0, st, a, v, g, (int)nv);                         \
+    return mippo::check_launch("mi_policy_ws_bwd_gae_bf16");                               \
+  }
+  WS_DUAL_MENU(X)
+#undef X
+  MI_REQUIRE(false, "mi_policy_ws_bwd_gae_bf16: no instantiation for these trunks");
 }
 
 // 1 if both trunks of a policy step are in the weights-stationary shape class (and the

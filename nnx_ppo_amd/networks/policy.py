@@ -45,6 +45,9 @@ WS_POLICY_ROLLOUT = os.environ.get("MIPPO_WS_ROLLOUT", "1") != "0"
 WS_MIN_ROWS = 8192
 # MIPPO_WS_MASKS=0: the weights-stationary backward reads relu' from the bf16 images (A/B)
 USE_MASKS = os.environ.get("MIPPO_WS_MASKS", "1") != "0"
+# the GAE scan, the advantage statistics and the loss gradients inside the backward launch
+# (mi_policy_ws_bwd_gae_bf16) instead of a launch of their own between forward and backward
+GAE_IN_BWD = os.environ.get("MIPPO_GAE_IN_BWD", "1") != "0"
 
 
 class MLPActorCritic(Sequential):
@@ -352,6 +355,53 @@ class MLPActorCritic(Sequential):
                                  l.bias.grad if l.bias is not None else None))
         ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
         return None
+
+    def _bwd_desc(self, a_ctx, v_ctx):
+        a_layers, _, c_layers = self._parts()
+        desc = lambda ls, c: ([l._fb for l in ls],
+                              [ls[0].in_features] + [l.out_features for l in ls],
+                              [l.act_code for l in ls], [sv[1] for sv in c[0]])
+        return desc(a_layers, a_ctx), desc(c_layers, v_ctx)
+
+    def gae_backward_supported(self, ctx, T: int, B: int) -> bool:
+        """True when `replay_backward_gae` can take this replay context: the fused class on
+        the weights-stationary backward with masks, and a [T, B] the launch supports."""
+        if not GAE_IN_BWD or ctx[0] != "fused":
+            return False
+        _, s_ctx, a_ctx, v_ctx, squeezed, tb, masks = ctx
+        a_layers, _, c_layers = self._parts()
+        M = T * B
+        if (masks is None or not USE_MASKS or not squeezed or tb != (T, B)
+                or not (WS_POLICY_BWD and M > WS_MIN_ROWS and s_ctx[0].shape[1] <= 64)):
+            return False
+        if not (a_layers[-1].act_code == ops.ACT_NONE and c_layers[-1].act_code == ops.ACT_NONE
+                and len(a_layers) >= 2 and len(c_layers) >= 2):
+            return False
+        da, dc = self._bwd_desc(a_ctx, v_ctx)
+        return ops.policy_bwd_gae_supported(T, B, da, dc)
+
+    def replay_backward_gae(self, ctx, g_reg, rewards, values, last_values, done, truncated,
+                            ll_new, ll_old, reg, gamma, lambda_, normalize, clip_range,
+                            critic_weight, loss_out=None):
+        """`ops.gae_ppo_loss` followed by `replay_backward`, as ONE launch + the dW launch
+        (`gae_backward_supported` must hold).  Returns loss_out[4]."""
+        _, s_ctx, a_ctx, v_ctx, _, (T, B), masks = ctx
+        a_layers, sampler, c_layers = self._parts()
+        ms2, ex2, off, eps2, _ = s_ctx
+        dense_chain.refresh(list(a_layers) + list(c_layers))
+        da, dc = self._bwd_desc(a_ctx, v_ctx)
+        a_dz, c_dz, loss_out = ops.policy_bwd_gae_bf16(
+            ms2, ex2, sampler._state(ms2.device), off, g_reg, da, dc, masks, rewards, values,
+            last_values, done, truncated, ll_new, ll_old, reg, gamma, lambda_, normalize,
+            clip_range, critic_weight, eps2=eps2, loss_out=loss_out, **sampler._kw())
+        problems = []
+        for ls, c, dz in ((c_layers, v_ctx, c_dz), (a_layers, a_ctx, a_dz)):
+            for i in range(len(ls) - 1, -1, -1):
+                l = ls[i]
+                problems.append((c[0][i][0], dz[i], l.kernel.grad,
+                                 l.bias.grad if l.bias is not None else None))
+        ops.dense_bwd_dw_grouped_bf16(problems, accumulate=True)
+        return loss_out
 
     def _backward_per_port(self, s_ctx, a_ctx, v_ctx, g_out, g_reg, g_v, M):
         a_layers, sampler, c_layers = self._parts()

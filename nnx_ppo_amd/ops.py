@@ -833,6 +833,79 @@ def policy_bwd_bf16(mean_and_std, extras, rng_state, offset_add: int, g_ll, g_re
     return a_dz, c_dz
 
 
+def policy_bwd_gae_supported(T: int, B: int, actor, critic) -> bool:
+    """`mi_policy_ws_bwd_gae_supported` for trunks described as in `policy_bwd_bf16`."""
+    (_, a_dims, a_acts, _), (_, c_dims, c_acts, _) = actor, critic
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    return bool(lib().mi_policy_ws_bwd_gae_supported(
+        int(T), int(B), len(a_acts), i64s(a_dims), i64s(a_acts), len(c_acts), i64s(c_dims),
+        i64s(c_acts)))
+
+
+def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg: float, actor,
+                        critic, masks, rewards, values, last_value, done, truncated, ll_new,
+                        ll_old, reg, gamma: float, lambda_: float, normalize: bool,
+                        clip_range: float, critic_weight: float, *, min_std: float,
+                        std_scale: float, entropy_weight: float, eps2=None,
+                        loss_out: torch.Tensor | None = None):
+    """`gae_ppo_loss` + `policy_bwd_bf16(ws=True, masks=...)` in ONE launch
+    (`mi_policy_ws_bwd_gae_bf16`): the GAE scan, the advantage statistics and the loss
+    gradients are evaluated inside the backward's workgroups.  `[T, B]` operands as in
+    `gae_ppo_loss`.  Returns (actor dz list, critic dz list, loss_out[4]); the dz images are
+    bit-identical to the two launches, the four scalars equal up to fp64 summation order."""
+    T, B = rewards.shape
+    M, A2 = mean_and_std.shape
+    dev = mean_and_std.device
+    _need(M == T * B, "policy_bwd_gae_bf16: mean_and_std must have T * B rows")
+    for t in (values, ll_new, ll_old, done, truncated):
+        _need(t.shape == (T, B) and t.is_contiguous(),
+              "policy_bwd_gae_bf16: operands must be contiguous [T, B]")
+    _need(rewards.is_contiguous() and last_value.shape == (B,) and last_value.is_contiguous(),
+          "policy_bwd_gae_bf16: rewards [T, B], last_value [B], contiguous")
+    _need(reg is None or (reg.numel() == M and reg.is_contiguous()),
+          "policy_bwd_gae_bf16: reg must be [T, B]")
+    (a_w, a_dims, a_acts, a_aux), (c_w, c_dims, c_acts, c_aux) = actor, critic
+    La, Lc = len(a_w), len(c_w)
+    _need(extras.shape == (M, A2 // 2), "policy_bwd_gae_bf16: shapes")
+    am, cm = masks
+    _need(len(am) >= La - 1 and len(cm) >= Lc - 1 and all(
+        t is not None and t.dtype == torch.uint8 for t in [*am[:La - 1], *cm[:Lc - 1]]),
+        "policy_bwd_gae_bf16: one uint8 mask per hidden layer")
+    a_dz = [_bf_buf(M, a_dims[l + 1], dev) for l in range(La)]
+    c_dz = [_bf_buf(M, c_dims[l + 1], dev) for l in range(Lc)]
+    if loss_out is None:
+        loss_out = torch.empty(4, dtype=f32, device=dev)
+    arr = lambda ts, n: (ctypes.c_void_p * max(n, 1))(*[ptr(t) for t in ts])
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    if profiler.active:
+        flop = sum(a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
+            + sum(c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
+        profiler.next_flops = 2.0 * M * flop
+        moved = sum(t.numel() * t.element_size()
+                    for t in [*am[:La - 1], *cm[:Lc - 1], *a_dz, *c_dz])
+        w_bytes = sum(2 * a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
+            + sum(2 * c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
+        # sampler rows (mean_and_std, raw action) + the GAE / loss operands, each once
+        # algorithmically: rewards, values, log-likelihoods (x2), regulariser, two flag bytes
+        profiler.next_bytes = (4.0 * M * (A2 + A2 // 2) + M * (4.0 * 5 + 2) + w_bytes + moved)
+    ws = workspace(dev, "policy_bwd_gae", lib().mi_policy_ws_bwd_gae_workspace_bytes(M),
+                   zeroed=True)
+    check(lib().mi_policy_ws_bwd_gae_bf16(
+        ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
+        ptr(eps2, f32), float(g_reg), float(min_std), float(std_scale), float(entropy_weight),
+        ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32), ptr(_as_u8(done), u8),
+        ptr(_as_u8(truncated), u8), ptr(ll_new, f32), ptr(ll_old, f32), ptr(reg, f32),
+        float(gamma), float(lambda_), int(bool(normalize)), float(clip_range),
+        float(critic_weight), ptr(loss_out, f32), ptr(ws), T, B,
+        La, arr(a_w, La), i64s(a_dims), i64s(a_acts), arr(a_aux[:La - 1], La - 1),
+        ptr(a_dz[La - 1], bf16), arr(a_dz[:La - 1], La - 1),
+        Lc, arr(c_w, Lc), i64s(c_dims), i64s(c_acts), arr(c_aux[:Lc - 1], Lc - 1),
+        ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1),
+        arr(am[:La - 1], La - 1), arr(cm[:Lc - 1], Lc - 1), stream()),
+        "mi_policy_ws_bwd_gae_bf16")
+    return a_dz, c_dz, loss_out
+
+
 def mlp_ws_bwd_dx_bf16(g_out: torch.Tensor, w_bfs: list, dims: list, acts: list, auxs: list):
     """`mlp_bwd_dx_bf16(..., need_input_grad=False)` with a linear last layer on the
     weights-stationary kernel.  Returns the dz list."""

@@ -293,3 +293,85 @@ def test_policy_ws_backward_bit_identical(dev, shape, M):
     for name, wl, gl in (("actor", want[0], gotm[0]), ("critic", want[1], gotm[1])):
         for l, (a, b) in enumerate(zip(wl, gl)):
             assert torch.equal(a, b), ("masks", name, l)
+
+
+@pytest.mark.parametrize("shape", [(5, 1, [64] * 4, [256] * 2), (17, 6, [128] * 2, [128] * 2),
+                                   (3, 2, [64] * 3, [64] * 3)])
+@pytest.mark.parametrize("T,B", [(30, 1024), (30, 512), (7, 2048), (32, 1984)])
+@pytest.mark.parametrize("normalize,with_reg", [(True, True), (False, False)])
+def test_policy_ws_backward_with_gae_inside(dev, shape, T, B, normalize, with_reg):
+    """mi_policy_ws_bwd_gae_bf16 == mi_gae_ppo_loss_f32 followed by mi_policy_ws_bwd_bf16
+    (ppo.py:433-503 + the backward): every dz image of both trunks bit for bit, the four
+    loss scalars to fp64 summation order; twice, so the re-armed ticket is exercised."""
+    from nnx_ppo_amd import ops
+
+    O, A, ah, ch = shape
+    M = T * B
+    a_dims, c_dims = [O] + ah + [2 * A], [O] + ch + [1]
+    a_ff, a_fb, a_b, a_acts = _bwd_images(dev, a_dims, seed=M)
+    c_ff, c_fb, c_b, c_acts = _bwd_images(dev, c_dims, seed=M + 1)
+    rng = np.random.default_rng(M + T)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    obs, extras = t(rng.normal(size=(M, O))), t(rng.normal(size=(M, A)))
+    tail = t(rng.normal(size=(B, O)))
+    rng_state = ops.make_rng_state(99, dev, 3)
+    kw = dict(min_std=0.1, std_scale=1.0, entropy_weight=1e-2)
+    rw = ops.policy_fwd_bf16(obs, None, (a_ff, a_b, a_dims, a_acts), (c_ff, c_b, c_dims, c_acts),
+                             rng_state, 2, deterministic=False, extras=extras, train=True,
+                             want_stats=False, ws=True, value_tail=tail, **kw)
+    masks = (rw["actor_masks"], rw["critic_masks"])
+    actor = (a_fb, a_dims, a_acts, [sv[1] for sv in rw["actor_saved"]])
+    critic = (c_fb, c_dims, c_acts, [sv[1] for sv in rw["critic_saved"]])
+    if not ops.policy_bwd_gae_supported(T, B, actor, critic):
+        pytest.skip("outside the fused class on this chip")
+    values = rw["value"].view(T, B).contiguous()
+    last_value = rw["value_tail_out"].view(B).contiguous()
+    ll_new = rw["log_likelihood"].view(T, B).contiguous()
+    ll_old = (ll_new + t(rng.normal(0, 0.3, size=(T, B)))).contiguous()
+    reg = rw["reg"].view(T, B).contiguous() if with_reg else None
+    rewards = t(rng.normal(size=(T, B)))
+    done = torch.tensor(rng.random((T, B)) < 0.15, device=dev)
+    trunc = torch.tensor(rng.random((T, B)) < 0.05, device=dev) & done
+    args = (0.99, 0.95, normalize, 0.2, 0.5)
+    g_ll, g_v, want_loss, _ = ops.gae_ppo_loss(rewards, values, last_value, done, trunc, ll_new,
+                                               ll_old, reg, *args)
+    want = ops.policy_bwd_bf16(rw["mean_and_std"], extras, rng_state, 2, g_ll.view(M), 1.0 / M,
+                               g_v.view(M, 1), actor, critic, ws=True, masks=masks, **kw)
+    for rep in range(2):
+        got_a, got_c, got_loss = ops.policy_bwd_gae_bf16(
+            rw["mean_and_std"], extras, rng_state, 2, 1.0 / M, actor, critic, masks, rewards,
+            values, last_value, done, trunc, ll_new, ll_old, reg, *args, **kw)
+        for name, wl, gl in (("actor", want[0], got_a), ("critic", want[1], got_c)):
+            for l, (a, b) in enumerate(zip(wl, gl)):
+                assert torch.equal(a, b), (rep, name, l,
+                                           float((a.float() - b.float()).abs().max()))
+        assert torch.allclose(got_loss, want_loss, rtol=1e-6, atol=1e-9), (got_loss, want_loss)
+
+
+def test_ppo_step_with_gae_in_backward_equals_separate_launch(dev):
+    """A whole iteration with the GAE / loss inside the backward launch == the same iteration
+    with the mi_gae_ppo_loss_f32 launch: parameters bit for bit, logged losses to 1e-6."""
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.networks import factories, policy
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    outs = []
+    with config.use_compute_dtype("bf16"):
+        for fused in (True, False):
+            policy.GAE_IN_BWD = fused
+            try:
+                env = EpisodeWrapper(cartpole_shaped(max_steps=9), 30)
+                net = factories.make_mlp_actor_critic(5, 1, [64] * 4, [256] * 2, Rngs(17))
+                ts = ppo.new_training_state(env, net, 2048, 17, 1e-3, device=dev)
+                for _ in range(2):  # [T, B] = [30, 1024] per gradient step
+                    ts, m = ppo.ppo_step(env, ts, 2048, 30, 0.95, 0.99, 0.2, True, False, 2, 2)
+                outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()}))
+            finally:
+                policy.GAE_IN_BWD = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys()
+    for k, v in outs[0][1].items():
+        assert v == pytest.approx(outs[1][1][k], rel=1e-6, abs=1e-9), k
