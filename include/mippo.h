@@ -587,7 +587,10 @@ int mi_policy_ws_fwd_bf16(
  * reduction into the gradients.  mi_adam_step_slabs_f32 is mi_adam_step_f32 that sums the
  * slabs itself while it reads the gradient arena (gw_offset / gb_offset: arena index of
  * each problem's kernel / bias gradient, gb < 0: no bias) — bit-identical to reducing
- * first, one launch fewer per gradient step. */
+ * first, one launch fewer per gradient step.  gb_first (nullable: all zero): first bias column
+ * of problem l that has a home in the arena — column j >= gb_first[l] goes to arena element
+ * gb_offset[l] + j - gb_first[l], the columns below are dropped (a GRU's recurrent kernel:
+ * only the n gate's third of the 3H column sums of dgh is a parameter's gradient). */
 int mi_dense_bwd_dw_grouped_slabs_bf16(int64_t n, const void* const* x_bf,
                                        const void* const* dz_bf, const int64_t* K,
                                        const int64_t* N, int64_t M, void* workspace,
@@ -604,7 +607,7 @@ int mi_adam_step_slabs_f32(
     void* const* frag_fwd, void* const* frag_bwd, int64_t n_slab_leaves,
     const void* const* slab_ptr, const int64_t* n_slabs, const int64_t* slab_K,
     const int64_t* slab_N, const int64_t* gw_offset, const int64_t* gb_offset,
-    mi_stream_t stream);
+    const int64_t* gb_first, mi_stream_t stream);
 
 /* One rollout / evaluation step of the recurrent actor-critic of make_gru_actor_critic
  * (normaliser -> Dense(K0 -> H, relu) -> GRU(H -> H) -> Dense(H -> 2A) -> NormalTanhSampler,

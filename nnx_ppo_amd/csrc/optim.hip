@@ -176,7 +176,7 @@ extern "C" int mi_adam_step_slabs_f32(
     void* const* frag_fwd, void* const* frag_bwd, int64_t n_slab_leaves,
     const void* const* slab_ptr, const int64_t* n_slabs, const int64_t* slab_K,
     const int64_t* slab_N, const int64_t* gw_offset, const int64_t* gb_offset,
-    mi_stream_t stream) {
+    const int64_t* gb_first, mi_stream_t stream) {
   mippo_optim::AdamArgs a;
   int rc = mippo_optim::fill_adam_args(a, "mi_adam_step_slabs_f32", params, grads, m, v, n, lr, b1,
                                        b2, eps, weight_decay, step, grad_norm, max_norm,
@@ -192,7 +192,9 @@ extern "C" int mi_adam_step_slabs_f32(
     MI_REQUIRE(slab_ptr && n_slabs && slab_K && slab_N && gw_offset && gb_offset && slab_ptr[l] &&
                    n_slabs[l] >= 1 && slab_K[l] >= 1 && slab_N[l] >= 1 && gw_offset[l] >= 0 &&
                    gw_offset[l] + slab_K[l] * slab_N[l] <= n &&
-                   (gb_offset[l] < 0 || gb_offset[l] + slab_N[l] <= n),
+                   (!gb_first || (gb_first[l] >= 0 && gb_first[l] < slab_N[l])) &&
+                   (gb_offset[l] < 0 ||
+                    gb_offset[l] + slab_N[l] - (gb_first ? gb_first[l] : 0) <= n),
                "mi_adam_step_slabs_f32: bad slab leaf %lld", (long long)l);
     mippo_optim::SlabLeaf& lf = a.slabs.leaf[l];
     lf.slabs = static_cast<const float*>(slab_ptr[l]);
@@ -201,6 +203,7 @@ extern "C" int mi_adam_step_slabs_f32(
     lf.N = (int)slab_N[l];
     lf.gw_off = gw_offset[l];
     lf.gb_off = gb_offset[l];
+    lf.b_lo = gb_first ? (int)gb_first[l] : 0;
   }
   int grid = stream_grid(n);
   if (grid > kAdamBlocksPerCU * num_cus()) grid = kAdamBlocksPerCU * num_cus();

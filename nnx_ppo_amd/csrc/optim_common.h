@@ -28,10 +28,13 @@ struct ShadowTable {
 // Split-M slabs of a grouped dW launch (gemm_bf16.hip) whose reduction rides on the
 // optimiser launch: leaf l adds sum_s slab[s][...] to the gradient of its kernel
 // (arena range [gw_off, gw_off + KN)) and bias ([gb_off, gb_off + N), gb_off < 0: none).
+// b_lo: first bias column that has a home in the arena — column j >= b_lo of the slab's db
+// goes to arena element gb_off + (j - b_lo), columns below it are dropped (a GRU's recurrent
+// kernel: of the 3H column sums of dgh only the n gate's H are a parameter's gradient).
 struct SlabLeaf {
   const float* slabs;  // [S][KN + N]
   int64_t gw_off, gb_off;
-  int S, KN, N;
+  int S, KN, N, b_lo;
 };
 constexpr int kMaxSlabLeaves = 8;
 struct SlabTable {
@@ -117,12 +120,13 @@ __device__ inline float slab_sum(const AdamArgs& a, int64_t i, int64_t pass_begi
     const int64_t stride = (int64_t)lf.KN + lf.N;
     // wave-uniform range tests first (the pass is one contiguous 256-element range)
     const bool w_hit = lf.gw_off < pass_begin + mippo_bf16::kThreads && lf.gw_off + lf.KN > pass_begin;
+    const int nb = lf.N - lf.b_lo;  // bias columns that live in the arena
     const bool b_hit = lf.gb_off >= 0 && lf.gb_off < pass_begin + mippo_bf16::kThreads &&
-                       lf.gb_off + lf.N > pass_begin;
+                       lf.gb_off + nb > pass_begin;
     if (!w_hit && !b_hit) continue;
     int64_t idx = -1;
     if (w_hit && i >= lf.gw_off && i < lf.gw_off + lf.KN) idx = i - lf.gw_off;
-    if (b_hit && i >= lf.gb_off && i < lf.gb_off + lf.N) idx = lf.KN + (i - lf.gb_off);
+    if (b_hit && i >= lf.gb_off && i < lf.gb_off + nb) idx = lf.KN + lf.b_lo + (i - lf.gb_off);
     if (idx < 0) continue;
     float v = 0.0f;
     int s = 0;

@@ -903,8 +903,11 @@ __device__ __forceinline__ void ws_gae_scan_group(const WsGae& g, const int grp,
       const float keep = d[t] ? 0.0f : 1.0f;
       const float av = delta + ((keep * g.gamma) * g.lambda) * next_a;
       if constexpr (STATS) {
-        s += (double)av;
-        s2 += (double)av * (double)av;
+        // gae_loss.hip: s2 += (double)av * (double)av — the product of two fp32 values is exact
+        // in fp64, so the fused form rounds the same sum once: the same bits, one DP op fewer
+        const double ad = (double)av;
+        s += ad;
+        s2 = __builtin_fma(ad, ad, s2);
       }
       next_a = av;
       next_v = vt;
@@ -991,9 +994,10 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           WH[l][b][ks] = ws_frag(c.layer[1 + l].w, ct, ks, KSH, lane);
     }
   };
-  // GAE: the scan holds ~130 registers of operands in flight; the stationary fragments are
-  // requested after it (with both live the allocator spilled to scratch)
-  if constexpr (!GAE) load_weights();
+  // GAE: the scan holds ~130 registers of operands in flight; the value trunk's stationary
+  // fragments (72 registers) are requested after it (with both live the allocator spilled to
+  // scratch), a narrow action trunk's (12) before
+  if constexpr (!GAE || (SAMP && H <= 128)) load_weights();
   // pad columns N_out..31 of the head-gradient rows stay zero for the whole kernel
   auto zero_pad = [&]() {
     for (int i = tid; i < kStashTiles * ROWS * 32; i += kWsThreads) {
@@ -1103,7 +1107,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
 
   if constexpr (GAE) {
     __builtin_amdgcn_sched_barrier(0);
-    load_weights();
+    if constexpr (!(SAMP && H <= 128)) load_weights();
     zero_pad();  // after the prologue's last barrier: the staging area is free
   }
 

@@ -148,10 +148,11 @@ class GRU(StatefulModule):
                 hp_bf = ops.cast_pad_bf16(h_prev.view(T * B, H))
             dgh_bf = dgh if dgh.dtype == torch.bfloat16 else ops.cast_pad_bf16(
                 dgh.view(T * B, 3 * H))
-            gb_h = torch.zeros(3 * H, dtype=torch.float32, device=dgi.device)
-            ops.dense_bwd_dw_grouped_bf16([(hp_bf, dgh_bf, self.w_h.grad, gb_h)],
-                                          accumulate=True)
-            self.b_hn.grad += gb_h[2 * H:]
+            # of the 3H column sums of dgh only the n gate's are a parameter's gradient: they
+            # go straight into b_hn.grad (queued with the step's other dW requests, picked
+            # out of the slabs by the optimiser launch — no launch of its own, no fill, no add)
+            ops.dense_bwd_dw_grouped_bf16([(hp_bf, dgh_bf, self.w_h.grad, self.b_hn.grad)],
+                                          accumulate=True, bias_first=[2 * H])
             if isinstance(pctx, str):  # the projection belongs to the caller's chain
                 return dgi
             g_x = dense_chain.backward([self._proj()], pctx, dgi2)

@@ -369,12 +369,13 @@ class _SlabDefer:
     `flush_pending_slabs`, which launches and reduces everything.  Off by default:
     `.grad` is complete after every backward."""
     arena = None    # float32 [n] while a deferring gradient step is open
-    queue: list = []   # (x_bf, dz_bf, g_w, g_b, gw_off, gb_off) not yet launched
-    pending = None  # (slab_ptrs, S, Ks, Ns, g_w, g_b, gw_off, gb_off, workspace): launched,
-    #                 slabs not yet reduced
+    queue: list = []   # (x_bf, dz_bf, g_w, g_b, gw_off, gb_off, b_lo) not yet launched
+    pending = None  # (slab_ptrs, S, Ks, Ns, g_w, g_b, gw_off, gb_off, workspace, b_lo):
+    #                 launched, slabs not yet reduced
 
-    def offsets(self, g_w, g_b, K, N):
-        """Arena offsets of a problem's gradients, or None if one lies outside the arena."""
+    def offsets(self, g_w, g_b, K, N, b_lo=0):
+        """Arena offsets of a problem's gradients, or None if one lies outside the arena
+        (`b_lo` > 0: g_b holds bias columns b_lo .. N-1 only)."""
         if self.arena is None:
             return None
         base, n = self.arena.data_ptr(), self.arena.numel()
@@ -382,7 +383,8 @@ class _SlabDefer:
         ob = -1 if g_b is None else (g_b.data_ptr() - base) // 4
         if not (g_w.is_contiguous() and 0 <= ow and ow + K * N <= n):
             return None
-        if g_b is not None and not (g_b.is_contiguous() and 0 <= ob and ob + N <= n):
+        if g_b is not None and not (g_b.is_contiguous() and g_b.numel() == N - b_lo
+                                    and 0 <= ob and ob + N - b_lo <= n):
             return None
         return ow, ob
 
@@ -391,10 +393,26 @@ slab_defer = _SlabDefer()
 
 
 def _dw_group(grp: list, accumulate: bool, fold) -> None:
-    """One grouped dW launch of <= 8 problems sharing M.  `fold` = [(gw_off, gb_off)] per
-    problem: leave the slabs pending for the optimiser launch instead of reducing them."""
+    """One grouped dW launch of <= 8 problems sharing M.  `fold` = [(gw_off, gb_off, b_lo)]
+    per problem: leave the slabs pending for the optimiser launch instead of reducing them.
+    A problem may carry a 5th element b_lo > 0 (its g_b holds bias columns b_lo .. N-1 only):
+    folded, the optimiser launch picks those columns out of the slabs; reduced here, the N
+    column sums go to a scratch vector whose tail is then added to g_b."""
     n = len(grp)
     M = grp[0][0].shape[0]
+    tails = []
+    if fold is None:
+        full = []
+        for pr in grp:
+            b_lo = pr[4] if len(pr) > 4 else 0
+            if b_lo and pr[3] is not None:
+                tmp = torch.zeros(pr[2].shape[1], dtype=f32, device=pr[2].device)
+                tails.append((pr[3], tmp, b_lo))
+                pr = (pr[0], pr[1], pr[2], tmp)
+            full.append(tuple(pr[:4]))
+        grp = full
+    else:
+        grp = [tuple(pr[:4]) for pr in grp]
     Ks = [g[2].shape[0] for g in grp]
     Ns = [g[2].shape[1] for g in grp]
     for (x_bf, dz_bf, g_w, g_b), K, N in zip(grp, Ks, Ns):
@@ -421,11 +439,13 @@ def _dw_group(grp: list, accumulate: bool, fold) -> None:
               "mi_dense_bwd_dw_grouped_slabs_bf16")
         slab_defer.pending = (list(sp), list(S), Ks, Ns, [g[2] for g in grp],
                               [g[3] for g in grp], [o[0] for o in fold],
-                              [o[1] for o in fold], ws)
+                              [o[1] for o in fold], ws, [o[2] for o in fold])
         return
     check(lib().mi_dense_bwd_dw_grouped_bf16(
         n, xs, dzs, P(*[ptr(g[2], f32) for g in grp]), P(*[ptr(g[3], f32) for g in grp]),
         Kc, Nc, M, ptr(ws), int(bool(accumulate)), stream()), "mi_dense_bwd_dw_grouped_bf16")
+    for g_b, tmp, b_lo in tails:
+        g_b += tmp[b_lo:]
 
 
 def _reduce_pending() -> None:
@@ -433,12 +453,22 @@ def _reduce_pending() -> None:
     if pend is None:
         return
     sp, S, Ks, Ns, g_w, g_b = pend[:6]
+    b_lo = pend[9]
     n = len(Ks)
     P = ctypes.c_void_p * n
     I = ctypes.c_int64 * n
+    tails = []
+    g_b = list(g_b)
+    for l in range(n):  # a bias tail: the N column sums to scratch, its tail added below
+        if b_lo[l] and g_b[l] is not None:
+            tmp = torch.zeros(Ns[l], dtype=f32, device=g_w[l].device)
+            tails.append((g_b[l], tmp, b_lo[l]))
+            g_b[l] = tmp
     check(lib().mi_reduce_slabs_grouped_f32(
         n, P(*sp), I(*S), I(*Ks), I(*Ns), P(*[ptr(t, f32) for t in g_w]),
         P(*[ptr(t, f32) for t in g_b]), 1, stream()), "mi_reduce_slabs_grouped_f32")
+    for dst, tmp, lo in tails:
+        dst += tmp[lo:]
 
 
 def _run_queue(fold_last: bool) -> None:
@@ -453,7 +483,8 @@ def _run_queue(fold_last: bool) -> None:
     groups = [g[i:i + 8] for g in by_m.values() for i in range(0, len(g), 8)]
     for gi, grp in enumerate(groups):
         last = fold_last and gi == len(groups) - 1
-        _dw_group([pr[:4] for pr in grp], True, [pr[4:6] for pr in grp] if last else None)
+        _dw_group([(*pr[:4], pr[6]) for pr in grp], True,
+                  [(pr[4], pr[5], pr[6]) for pr in grp] if last else None)
 
 
 def flush_pending_slabs() -> None:
@@ -488,14 +519,20 @@ _DW_QUEUE_TILES = 26
 _DW_REQUEST_TILES = 13
 
 
-def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
-    """dW / db of several layers that share M: `problems` = [(x_bf, dz_bf, g_w, g_b)]."""
+def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True,
+                              bias_first: list | None = None) -> None:
+    """dW / db of several layers that share M: `problems` = [(x_bf, dz_bf, g_w, g_b)].
+    `bias_first[i]` = b_lo > 0: problem i's g_b is [N - b_lo] and receives the column sums
+    of dz columns b_lo .. N-1 only (a GRU's recurrent kernel: the n gate's bias)."""
+    bias_first = [0] * len(problems) if bias_first is None else [int(b) for b in bias_first]
+    _need(len(bias_first) == len(problems), "dense_bwd_dw_grouped_bf16: one bias_first each")
+    _need(accumulate or not any(bias_first), "dense_bwd_dw_grouped_bf16: bias tails accumulate")
     tiles = sum(_dw_tiles(g_w.shape[0], g_w.shape[1]) for _, _, g_w, _ in problems)
     queued = sum(_dw_tiles(pr[2].shape[0], pr[2].shape[1]) for pr in slab_defer.queue)
     if (accumulate and slab_defer.arena is not None and tiles <= _DW_REQUEST_TILES
             and tiles + queued <= _DW_QUEUE_TILES):
-        offs = [slab_defer.offsets(g_w, g_b, g_w.shape[0], g_w.shape[1])
-                for _, _, g_w, g_b in problems]
+        offs = [slab_defer.offsets(g_w, g_b, g_w.shape[0], g_w.shape[1], lo)
+                for (_, _, g_w, g_b), lo in zip(problems, bias_first)]
         if all(o is not None for o in offs):
             # one gradient twice in a launch would race in the slab reduction (weight
             # sharing): what is queued goes out first
@@ -506,8 +543,9 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
             elif seen & set(mine):
                 _run_queue(fold_last=False)
             if offs is not None:
-                slab_defer.queue.extend((x, dz, g_w, g_b, o[0], o[1])
-                                        for (x, dz, g_w, g_b), o in zip(problems, offs))
+                slab_defer.queue.extend(
+                    (x, dz, g_w, g_b, o[0], o[1], lo)
+                    for (x, dz, g_w, g_b), o, lo in zip(problems, offs, bias_first))
                 return
     # launched now; what is queued stays queued unless it shares a gradient with this request
     # (the order of the additions into one gradient is then kept)
@@ -516,8 +554,9 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True) -> None:
     if any(pr[2].data_ptr() in mine or (pr[3] is not None and pr[3].data_ptr() in mine)
            for pr in slab_defer.queue):
         _run_queue(fold_last=False)
-    for i in range(0, len(problems), 8):
-        _dw_group(problems[i:i + 8], accumulate, None)
+    full = [(*pr, lo) for pr, lo in zip(problems, bias_first)]
+    for i in range(0, len(full), 8):
+        _dw_group(full[i:i + 8], accumulate, None)
 
 
 def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
@@ -1044,8 +1083,8 @@ def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: floa
     `grads` zeroed (it doubles as the next step's `begin_grad_step`).  `shadows`: up to
     16 tuples (begin, K, N, w_bf, wt_bf, frag_fwd, frag_bwd) of Dense kernels stored in
     `params` whose bf16 images are written by the same launch.  `slabs`: pending dW slabs
-    (slab_ptrs, S, Ks, Ns, gw_offsets, gb_offsets) summed into the gradient as it is read
-    (`mi_adam_step_slabs_f32`)."""
+    (slab_ptrs, S, Ks, Ns, gw_offsets, gb_offsets[, bias_first]) summed into the gradient as it
+    is read (`mi_adam_step_slabs_f32`)."""
     n = params.numel()
     for t in (grads, m, v):
         _need(t.numel() == n, "adam_step: arena sizes differ")
@@ -1069,12 +1108,15 @@ def adam_step(params, grads, m, v, step, *, lr: float, b1: float = 0.9, b2: floa
         check(lib().mi_adam_step_f32(*args, stream()), "mi_adam_step_f32")
         return
     _need(begin_next, "adam_step: pending slabs need begin_next (the launch consumes them)")
-    sp, S, Ks, Ns, gw_off, gb_off = slabs
+    sp, S, Ks, Ns, gw_off, gb_off = slabs[:6]
+    b_lo = slabs[6] if len(slabs) > 6 else None
     nl = len(Ks)
     Pl = ctypes.c_void_p * nl
     Il = ctypes.c_int64 * nl
     check(lib().mi_adam_step_slabs_f32(*args, nl, Pl(*sp), Il(*S), Il(*Ks), Il(*Ns),
-                                       Il(*gw_off), Il(*gb_off), stream()),
+                                       Il(*gw_off), Il(*gb_off),
+                                       Il(*b_lo) if b_lo is not None and any(b_lo) else None,
+                                       stream()),
           "mi_adam_step_slabs_f32")
 
 

@@ -90,8 +90,8 @@ class Optimizer:
         pend = ops.take_pending_slabs()
         if pend is None:
             return None
-        sp, S, Ks, Ns, _, _, gw_off, gb_off, _ = pend
-        return (sp, S, Ks, Ns, gw_off, gb_off)
+        sp, S, Ks, Ns, _, _, gw_off, gb_off, _, b_lo = pend
+        return (sp, S, Ks, Ns, gw_off, gb_off, b_lo)
 
     def compute_grad_norm(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         ops.flush_pending_slabs()
