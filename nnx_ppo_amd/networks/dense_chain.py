@@ -18,6 +18,7 @@ products are bf16 x bf16 with fp32 accumulation, master weights stay fp32.
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -105,6 +106,22 @@ def _fusable(layers, M: int) -> bool:
     return len(layers) <= FUSED_MAX_LAYERS and width <= FUSED_MAX_WIDTH
 
 
+# Training-size chains in the shape class of the weights-stationary kernels (csrc/trunk_ws.hip:
+# K0 <= 32 -> H -> (H -> H) x NH -> N <= 16, relu, linear head) run on them: one persistent
+# 8-wave workgroup per CU with the trunk in registers, bit-identical to the whole-trunk tile
+# kernels (tests/test_trunk_ws_gpu.py), 21 -> 14 us for the 5-256-256-1 critic at M = 30 720.
+# Below WS_MIN_ROWS the tile kernels (one workgroup per 64 rows) fill the chip better.
+WS_CHAIN = os.environ.get("MIPPO_WS_CHAIN", "1") != "0"
+WS_MIN_ROWS = 8192
+
+
+def _ws(layers, M: int, need_input_grad: bool) -> bool:
+    if not WS_CHAIN or need_input_grad or M <= WS_MIN_ROWS or len(layers) < 2:
+        return False
+    dims = [layers[0].in_features] + [l.out_features for l in layers]
+    return ops.mlp_ws_supported(dims, [l.act_code for l in layers])
+
+
 def _chain_args(layers):
     refresh(layers)
     wts = [l._ff for l in layers]  # forward fragment-major images
@@ -137,7 +154,8 @@ def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
     (dW operand), the tensor its act' is evaluated on, and the bf16 W shadow."""
     M = x2.shape[0]
     if _fusable(layers, M):
-        y, sv = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=True)
+        fwd = ops.mlp_ws_fwd_bf16 if _ws(layers, M, need_input_grad) else ops.mlp_fwd_bf16
+        y, sv = fwd(x2, *_chain_args(layers), train=True)
         saved = [(xb, aux, _shadows(l)[0]) for (xb, aux), l in zip(sv, layers)]
         return (saved, M, need_input_grad), y
     refresh(layers)
@@ -171,6 +189,13 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     if _fusable(layers, M) and (L > 1 or need_input_grad):
         dims = [layers[0].in_features] + [l.out_features for l in layers]
         refresh(layers)
+        if _ws(layers, M, need_input_grad):
+            dz = ops.mlp_ws_bwd_dx_bf16(g_out2, [l._fb for l in layers], dims,
+                                        [l.act_code for l in layers], [sv[1] for sv in saved])
+            ops.dense_bwd_dw_grouped_bf16(
+                [(saved[i][0], dz[i], grads[i][0], grads[i][1]) for i in range(L - 1, -1, -1)],
+                accumulate=True)
+            return None
         dz, g_in = ops.mlp_bwd_dx_bf16(
             g_out2, saved[-1][1] if last.act_code != ops.ACT_NONE else None, last.act_code,
             [l._fb for l in layers], dims, [l.act_code for l in layers],
