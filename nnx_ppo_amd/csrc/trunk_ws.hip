@@ -820,6 +820,11 @@ struct WsGae {
   float gamma, lambda, clip, critic_weight;
   int normalize;
 };
+// -DGAE_W_FIRST=1: every trunk's stationary fragments requested before the scan (measured:
+// the 256-wide value trunk then spills 29 registers to scratch, 66.4 -> 64.5 M env-steps/s)
+#ifndef GAE_W_FIRST
+#define GAE_W_FIRST 0
+#endif
 constexpr int kGaeMaxT = 32;
 constexpr int kGaeMaxQ = 16;    // row tiles a workgroup may own
 constexpr int kGaeMaxGroups = 32;  // B <= 2048
@@ -872,7 +877,7 @@ __device__ __forceinline__ void ws_gae_scan_group(const WsGae& g, const int grp,
   float next_v = g.last_value[e0 + lane], next_a = 0.0f;
   __builtin_amdgcn_sched_barrier(0);
   float r[kGaeMaxT], v[kGaeMaxT];
-  unsigned char d[kGaeMaxT], tr[kGaeMaxT];
+  unsigned dm = 0u, tm = 0u;  // bit t: done / truncated at step t (one register each, not 32)
   u32x4* const sf4 = reinterpret_cast<u32x4*>(sf) + lane;  // (4 k + lane / 16) * 64 + 4 (lane % 16)
   u32x4* const sb4 = reinterpret_cast<u32x4*>(sb) + lane;  // (16 k + lane / 4) * 64 + 16 (lane % 4)
 #pragma unroll
@@ -886,21 +891,22 @@ __device__ __forceinline__ void ws_gae_scan_group(const WsGae& g, const int grp,
 #pragma unroll
   for (int k = 0; k < kGaeMaxT / 16; ++k) sb4[64 * k] = qd[k];
 #pragma unroll
-  for (int t = 0; t < kGaeMaxT; ++t) d[t] = sb[t * 64 + lane];
+  for (int t = 0; t < kGaeMaxT; ++t) dm |= (sb[t * 64 + lane] ? 1u : 0u) << t;
 #pragma unroll
   for (int k = 0; k < kGaeMaxT / 16; ++k) sb4[64 * k] = qt[k];
 #pragma unroll
-  for (int t = 0; t < kGaeMaxT; ++t) tr[t] = sb[t * 64 + lane];
+  for (int t = 0; t < kGaeMaxT; ++t) tm |= (sb[t * 64 + lane] ? 1u : 0u) << t;
   s = 0.0;
   s2 = 0.0;
 #pragma unroll
   for (int t = kGaeMaxT - 1; t >= 0; --t) {
     if (t < T && t >= t_stop) {
       const float vt = v[t];
-      const float nv = d[t] ? 0.0f : next_v;
+      const bool dn = (dm >> t) & 1u;
+      const float nv = dn ? 0.0f : next_v;
       float delta = (r[t] + g.gamma * nv) - vt;
-      delta = tr[t] ? 0.0f : delta;
-      const float keep = d[t] ? 0.0f : 1.0f;
+      delta = ((tm >> t) & 1u) ? 0.0f : delta;
+      const float keep = dn ? 0.0f : 1.0f;
       const float av = delta + ((keep * g.gamma) * g.lambda) * next_a;
       if constexpr (STATS) {
         // gae_loss.hip: s2 += (double)av * (double)av — the product of two fp32 values is exact
@@ -997,7 +1003,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
   // GAE: the scan holds ~130 registers of operands in flight; the value trunk's stationary
   // fragments (72 registers) are requested after it (with both live the allocator spilled to
   // scratch), a narrow action trunk's (12) before
-  if constexpr (!GAE || (SAMP && H <= 128)) load_weights();
+  if constexpr (!GAE || GAE_W_FIRST || (SAMP && H <= 128)) load_weights();
   // pad columns N_out..31 of the head-gradient rows stay zero for the whole kernel
   auto zero_pad = [&]() {
     for (int i = tid; i < kStashTiles * ROWS * 32; i += kWsThreads) {
@@ -1107,7 +1113,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
 
   if constexpr (GAE) {
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(SAMP && H <= 128)) load_weights();
+    if constexpr (!(GAE_W_FIRST || (SAMP && H <= 128))) load_weights();
     zero_pad();  // after the prologue's last barrier: the staging area is free
   }
 
@@ -1647,11 +1653,12 @@ namespace {
 
 // The CUs of a two-trunk launch, split in proportion to the tile counts (all of them when
 // both trunks' tiles fit the chip).  MIPPO_WS_DUAL_SPLIT = percent for the value trunk.
-void ws_dual_split(int64_t tv, int64_t ta, int64_t* nv, int64_t* na) {
-  static const int split_pct = [] {
+void ws_dual_split(int64_t tv, int64_t ta, int64_t* nv, int64_t* na, int pct = 0) {
+  static const int env_pct = [] {
     const char* e = getenv("MIPPO_WS_DUAL_SPLIT");
     return e ? atoi(e) : 0;
   }();
+  const int split_pct = pct > 0 ? pct : env_pct;
   const int64_t cus = ws_grid(1 << 30);
   *nv = tv;
   *na = ta;
@@ -1732,6 +1739,18 @@ extern "C" int mi_policy_ws_bwd_bf16(
 }
 
 // ---- mi_policy_ws_bwd_gae_bf16: mi_gae_ppo_loss_f32 + mi_policy_ws_bwd_bf16 in one launch ----
+namespace {
+// percent of the CUs for the value trunk in the launch with the GAE inside (0: in proportion
+// to the tile counts, as the plain launches); MIPPO_WS_GAE_SPLIT: tuning aid
+int ws_gae_split_pct() {
+  static const int pct = [] {
+    const char* e = getenv("MIPPO_WS_GAE_SPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  return pct;
+}
+}  // namespace
+
 extern "C" int64_t mi_policy_ws_bwd_gae_workspace_bytes(int64_t M) {
   return kGaeHeaderBytes + mippo::ceil_div(M, 64) * 4 * (int64_t)sizeof(double);
 }
@@ -1750,7 +1769,7 @@ extern "C" int mi_policy_ws_bwd_gae_supported(int64_t T, int64_t B, int64_t La,
   const int64_t M = T * B;
   if (2 * mippo::ceil_div(M, 32) <= ws_grid(1 << 30)) return 0;  // 32-row-tile sizes
   int64_t nv, na;
-  ws_dual_split(M / 64, M / 64, &nv, &na);
+  ws_dual_split(M / 64, M / 64, &nv, &na, ws_gae_split_pct());
   return na >= B / 64 &&  // one publishing workgroup per env group
          mippo::ceil_div(M / 64, nv) <= kGaeMaxQ && mippo::ceil_div(M / 64, na) <= kGaeMaxQ;
 }
@@ -1796,7 +1815,7 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
              static_cast<unsigned int*>(workspace), static_cast<unsigned int*>(workspace) + 1,
              (int)T, (int)B, gamma, lambda, clip_range, critic_weight, normalize};
   int64_t nv, na;
-  ws_dual_split(M / 64, M / 64, &nv, &na);
+  ws_dual_split(M / 64, M / 64, &nv, &na, ws_gae_split_pct());
   const int64_t hv = c_dims[1], nhv = Lc - 2, ha = a_dims[1], nha = La - 2;
 #define X(p, q, r, s_)                                                                     \
   if (hv == p && nhv == q && ha == r && nha == s_) {                                       \
