@@ -303,6 +303,29 @@ def test_policy_ws_backward_with_gae_inside(dev, shape, T, B, normalize, with_re
     """mi_policy_ws_bwd_gae_bf16 == mi_gae_ppo_loss_f32 followed by mi_policy_ws_bwd_bf16
     (ppo.py:433-503 + the backward): every dz image of both trunks bit for bit, the four
     loss scalars to fp64 summation order; twice, so the re-armed ticket is exercised."""
+    if not _gae_inside_case(dev, shape, T, B, normalize, with_reg):
+        pytest.skip("outside the fused class on this chip")
+
+
+def test_policy_ws_backward_with_gae_inside_many_tiles_per_workgroup():
+    """The same with the action trunk on 38 % of the CUs (MIPPO_WS_GAE_SPLIT, read once per
+    process: a child process): 1024 row tiles over 97 action-trunk workgroups = 11 each, so
+    the sampler backward's second stash round (tiles 9 .. 11 of a workgroup) is exercised."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import sys, torch; sys.path.insert(0, 'tests'); import test_trunk_ws_gpu as t; "
+            "ok = t._gae_inside_case(torch.device('cuda:0'), (5, 1, [64] * 4, [256] * 2), 32, "
+            "2048, True, True); print('CASE', ok)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                       env=dict(os.environ, MIPPO_WS_GAE_SPLIT="62"), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "CASE True" in r.stdout, r.stdout + r.stderr
+
+
+def _gae_inside_case(dev, shape, T, B, normalize, with_reg) -> bool:
     from nnx_ppo_amd import ops
 
     O, A, ah, ch = shape
@@ -323,7 +346,7 @@ def test_policy_ws_backward_with_gae_inside(dev, shape, T, B, normalize, with_re
     actor = (a_fb, a_dims, a_acts, [sv[1] for sv in rw["actor_saved"]])
     critic = (c_fb, c_dims, c_acts, [sv[1] for sv in rw["critic_saved"]])
     if not ops.policy_bwd_gae_supported(T, B, actor, critic):
-        pytest.skip("outside the fused class on this chip")
+        return False
     values = rw["value"].view(T, B).contiguous()
     last_value = rw["value_tail_out"].view(B).contiguous()
     ll_new = rw["log_likelihood"].view(T, B).contiguous()
@@ -346,6 +369,7 @@ def test_policy_ws_backward_with_gae_inside(dev, shape, T, B, normalize, with_re
                 assert torch.equal(a, b), (rep, name, l,
                                            float((a.float() - b.float()).abs().max()))
         assert torch.allclose(got_loss, want_loss, rtol=1e-6, atol=1e-9), (got_loss, want_loss)
+    return True
 
 
 def test_ppo_step_with_gae_in_backward_equals_separate_launch(dev):
