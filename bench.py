@@ -69,6 +69,7 @@ GEMM_SYMBOLS = {
     "mi_policy_bwd_bf16": None,
     "mi_policy_ws_fwd_bf16": None,
     "mi_policy_ws_bwd_bf16": None,
+    "mi_policy_ws_bwd_gae_bf16": None,
     "mi_dense_bwd_dw_grouped_bf16": None,
     "mi_dense_bwd_dw_grouped_slabs_bf16": None,
 }
@@ -170,6 +171,11 @@ def roofline_of_dominant_kernel(env, ts):
         if name == "mi_policy_ws_bwd_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("policy_ws_bwd_dual_kernel<256, 1, 64, 3, 4>", t_ms, work)
+        if name == "mi_policy_ws_bwd_gae_bf16":
+            # the same launch with the GAE scan, the advantage statistics and the loss
+            # gradients inside (no mi_gae_ppo_loss_f32 launch in front of it)
+            for (ints, t_ms), work in zip(d["args"], d["work"]):
+                add("policy_ws_bwd_gae_kernel<256, 1, 64, 3>", t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_bf16":
             for (ints, t_ms), work in zip(d["args"], d["work"]):
                 add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",
