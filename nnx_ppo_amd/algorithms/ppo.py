@@ -409,8 +409,10 @@ def ppo_loss(
     stateless = not any(isinstance(t, torch.Tensor) for t in tree_leaves(network_state))
     fork = None
     fused = None
-    if stateless and hasattr(networks, "replay_with_bootstrap"):
-        # the bootstrap rows ride along in the replay launch (networks/policy.py)
+    if hasattr(networks, "replay_with_bootstrap"):
+        # the bootstrap rows ride along in the replay launch (networks/policy.py for the
+        # fused MLP class, containers.Sequential for a stateless Dense value port beside any
+        # action port)
         fused = networks.replay_with_bootstrap(network_state, rollout_data.obs, done,
                                                rollout_data.rollout_extras, last_obs)
     if fused is not None:

@@ -144,13 +144,18 @@ class PPOAdapter(StatefulModule):
         self.value.update_statistics(rollout_extras["value"])
 
     # ---- training protocol ------------------------------------------------------
-    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True):
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, x_value=None):
+        """`x_value` (containers.Sequential.replay_with_bootstrap): the value port's input when
+        it is longer than the action port's — `[T + 1, B, ...]`, step T being the bootstrap
+        observation, for a stateless row-wise value port; its output keeps the extra step and
+        the caller splits it."""
         a_re = None if extras_seq is None else extras_seq["action"]
         v_re = None if extras_seq is None else extras_seq["value"]
+        xv = x_seq if x_value is None else x_value
         if _can_fork(x_seq, self._wide):
-            fork = _Fork(x_seq, state0["value"], v_re, done_seq)
+            fork = _Fork(xv, state0["value"], v_re, done_seq)
             with fork:
-                v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], x_seq, done_seq,
+                v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], xv, done_seq,
                                                               v_re, need_input_grad)
             a_ctx, a_out, a_reg, a_fs = self.action.replay(state0["action"], x_seq, done_seq,
                                                            a_re, need_input_grad)
@@ -158,7 +163,7 @@ class PPOAdapter(StatefulModule):
         else:
             a_ctx, a_out, a_reg, a_fs = self.action.replay(state0["action"], x_seq, done_seq,
                                                            a_re, need_input_grad)
-            v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], x_seq, done_seq, v_re,
+            v_ctx, v_out, v_reg, v_fs = self.value.replay(state0["value"], xv, done_seq, v_re,
                                                           need_input_grad)
         actions = tree_map(lambda d: d["action"], a_out, is_leaf=_is_sampler_dict)
         loglik = tree_map(lambda d: d["log_likelihood"], a_out, is_leaf=_is_sampler_dict)

@@ -2,6 +2,7 @@
 `nnx_ppo/networks/containers.py`; `Sequential` 14-52 is on the hot path)."""
 from __future__ import annotations
 
+import os
 from collections.abc import Sequence
 from typing import Any
 
@@ -14,6 +15,11 @@ def _device_of(x):
 
     leaves = tree_leaves(x)
     return leaves[0].device if leaves else "cpu"
+
+
+# the bootstrap observation as step T of a stateless value chain's replay
+# (Sequential.replay_with_bootstrap); MIPPO_BOOTSTRAP_IN_CHAIN=0: a forward_value launch
+BOOTSTRAP_IN_CHAIN = os.environ.get("MIPPO_BOOTSTRAP_IN_CHAIN", "1") != "0"
 
 
 class Sequential(StatefulModule):
@@ -156,6 +162,57 @@ class Sequential(StatefulModule):
             upstream_needs = upstream_needs or bool(layer.parameters())
             i += 1
         return ctxs, x, reg, final_state
+
+    def replay_with_bootstrap(self, state0, x_seq, done_seq, extras_seq, last_obs):
+        """`replay` plus the value estimate of `last_obs` (the bootstrap V(s_T) of
+        ppo.py:433-437) for the network `[Normalizer, PPOAdapter]` whose VALUE port is a
+        stateless chain of Dense layers (the action port may be recurrent): the bootstrap
+        observation is the value port's step T — normalised into the same buffer as the
+        sequence, it rides in the value chain's launch instead of costing a chain launch of its
+        own on the critical path (`forward_value` after the replay: at C4 a 1024-row launch
+        per gradient step).  The chain's backward then covers the first T steps' rows only.
+        Returns (ctx, out, reg, final_state, last_values), or None when the pattern does
+        not apply (the caller then takes `replay` + `forward_value`)."""
+        import torch
+
+        from . import dense_chain
+        from .adapter import PPOAdapter
+        from .feedforward import Dense
+        from .normalizer import Normalizer
+        from ..tree import tree_leaves
+
+        if not BOOTSTRAP_IN_CHAIN or config.compute_dtype() != "bf16" or len(self.layers) != 2:
+            return None
+        norm, adapter = self.layers
+        if not (type(norm) is Normalizer and isinstance(adapter, PPOAdapter)
+                and type(adapter.value) is Sequential and adapter.value.layers
+                and all(type(l) is Dense for l in adapter.value.layers)):
+            return None
+        if not (isinstance(x_seq, torch.Tensor) and x_seq.dim() == 3 and x_seq.is_cuda
+                and isinstance(last_obs, torch.Tensor) and last_obs.dim() == 2
+                and last_obs.shape == x_seq.shape[1:] and isinstance(norm.mean.value, torch.Tensor)
+                and x_seq.dtype == torch.float32 and extras_seq is not None):
+            return None
+        if any(isinstance(t, torch.Tensor) for t in tree_leaves(state0[1]["value"])):
+            return None
+        if not dense_chain._fusable(adapter.value.layers, x_seq.shape[0] * x_seq.shape[1]):
+            return None
+        T, B, K = x_seq.shape
+        x_ext = torch.empty(T + 1, B, K, dtype=torch.float32, device=x_seq.device)
+        cnt = norm.counter.value
+        from .. import ops
+
+        ops.normalize_fwd(x_seq if x_seq.is_contiguous() else x_seq.contiguous(),
+                          norm.mean.value, norm.M2.value, cnt, norm.epsilon, out=x_ext[:T])
+        ops.normalize_fwd(last_obs if last_obs.is_contiguous() else last_obs.contiguous(),
+                          norm.mean.value, norm.M2.value, cnt, norm.epsilon, out=x_ext[T])
+        a_ctx, out, reg, fs = adapter.replay(state0[1], x_ext[:T], done_seq, extras_seq[1],
+                                             need_input_grad=False, x_value=x_ext)
+        v_ext = out.value_estimates  # [T + 1, B(, n)]: the value port saw the extra step
+        out = type(out)(actions=out.actions, loglikelihoods=out.loglikelihoods,
+                        value_estimates=v_ext[:T])
+        ctxs = [("layer", 0, False), ("layer", 1, a_ctx)]
+        return ctxs, out, reg, [(), fs], v_ext[T]
 
     def replay_backward(self, ctxs, g_out, g_reg):
         g = g_out

@@ -182,14 +182,21 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     The dX chain runs first (it is sequential by nature: one fused launch when the
     trunk fits the whole-trunk kernel) and keeps every dz; the dW / db of ALL
     layers then go out as one grouped launch per tile class."""
-    saved, M, need_input_grad = ctx
+    saved, M_fwd, need_input_grad = ctx
+    M = g_out2.shape[0]
+    if M != M_fwd:
+        # the backward may cover a PREFIX of the rows the forward saw (bootstrap rows that rode
+        # along in a value chain's launch carry no gradient): row-prefix views of the images
+        assert M < M_fwd, "dense_chain.backward: more gradient rows than forward rows"
+        saved = [tuple(None if t is None else t[:M] for t in sv[:2]) + tuple(sv[2:])
+                 for sv in saved]
     L = len(layers)
     last = layers[-1]
     grads = [(l.kernel.grad, l.bias.grad if l.bias is not None else None) for l in layers]
     if _fusable(layers, M) and (L > 1 or need_input_grad):
         dims = [layers[0].in_features] + [l.out_features for l in layers]
         refresh(layers)
-        if _ws(layers, M, need_input_grad):
+        if _ws(layers, M_fwd, need_input_grad):
             dz = ops.mlp_ws_bwd_dx_bf16(g_out2, [l._fb for l in layers], dims,
                                         [l.act_code for l in layers], [sv[1] for sv in saved])
             ops.dense_bwd_dw_grouped_bf16(

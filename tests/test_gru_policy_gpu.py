@@ -116,3 +116,35 @@ def test_gru_step_support_query(dev):
     assert not ops.gru_policy_step_supported(5, 96, 2, [5, 256, 256, 1], [R, R, N])   # width
     assert not ops.gru_policy_step_supported(40, 64, 2, [40, 256, 256, 1], [R, R, N])  # K0 <= 32
     assert not ops.gru_policy_step_supported(5, 64, 2, [5, 512, 1], [R, N])           # value trunk
+
+
+@pytest.mark.parametrize("n_envs,T", [(256, 10), (2048, 30)])
+def test_bootstrap_rows_in_the_value_chain_equal_forward_value(dev, bf16, n_envs, T):
+    """`Sequential.replay_with_bootstrap` (the bootstrap observation as step T of the
+    stateless value chain's replay, ppo.py:433-437) == `replay` + `forward_value`: a row of a
+    Dense chain does not depend on its neighbours, so two whole iterations — parameters,
+    metrics, carries — must be BIT-identical.  (2048 x 30: the value chain on the
+    weights-stationary kernels, its backward over a row prefix of the forward's images.)"""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import containers, factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    outs = []
+    for on in (True, False):
+        containers.BOOTSTRAP_IN_CHAIN = on
+        try:
+            env = EpisodeWrapper(MockEnv(5, 1, max_steps=5), 40)
+            net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(17))
+            ts = ppo.new_training_state(env, net, n_envs, 17, 1e-3, device=dev)
+            for _ in range(2):
+                ts, m = ppo.ppo_step(env, ts, n_envs, T, 0.95, 0.99, 0.2, True, False, 2, 2)
+            outs.append((ts.optimizer.params.clone(), {k: float(v) for k, v in m.items()},
+                         [t.clone() for t in _leaves(ts.network_states)]))
+        finally:
+            containers.BOOTSTRAP_IN_CHAIN = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
