@@ -916,6 +916,9 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
         loss_out = torch.empty(4, dtype=f32, device=dev)
     arr = lambda ts, n: (ctypes.c_void_p * max(n, 1))(*[ptr(t) for t in ts])
     i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    # (before the work annotation: the size query is a recorded C-ABI call of its own)
+    ws = workspace(dev, "policy_bwd_gae", lib().mi_policy_ws_bwd_gae_workspace_bytes(M),
+                   zeroed=True)
     if profiler.active:
         flop = sum(a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
             + sum(c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
@@ -927,8 +930,6 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
         # sampler rows (mean_and_std, raw action) + the GAE / loss operands, each once
         # algorithmically: rewards, values, log-likelihoods (x2), regulariser, two flag bytes
         profiler.next_bytes = (4.0 * M * (A2 + A2 // 2) + M * (4.0 * 5 + 2) + w_bytes + moved)
-    ws = workspace(dev, "policy_bwd_gae", lib().mi_policy_ws_bwd_gae_workspace_bytes(M),
-                   zeroed=True)
     check(lib().mi_policy_ws_bwd_gae_bf16(
         ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
         ptr(eps2, f32), float(g_reg), float(min_std), float(std_scale), float(entropy_weight),
