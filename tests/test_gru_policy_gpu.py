@@ -148,3 +148,29 @@ def test_bootstrap_rows_in_the_value_chain_equal_forward_value(dev, bf16, n_envs
     assert outs[0][1] == outs[1][1]
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, b)
+
+
+def test_gru_bias_tail_gradient_folded_equals_reduced(dev, bf16):
+    """The GRU recurrent kernel's dW request names `b_hn.grad` with `bias_first = 2H`.  With
+    the step's slabs folded into the optimiser launch the n gate's column sums are picked out
+    of the slabs (`mi_adam_step_slabs_f32`, gb_first); when something reads the gradient first
+    (GRAD_NORM logging: `flush_pending_slabs`) the 3H sums go to a scratch vector whose tail
+    is added.  Same summation order: two iterations must leave BIT-identical parameters."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.config import LoggingLevel
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    outs = []
+    for level in (LoggingLevel.LOSSES, LoggingLevel.LOSSES | LoggingLevel.GRAD_NORM):
+        env = EpisodeWrapper(MockEnv(5, 1, max_steps=5), 40)
+        net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(17))
+        ts = ppo.new_training_state(env, net, 256, 17, 1e-3, device=dev)
+        for _ in range(2):
+            ts, m = ppo.ppo_step(env, ts, 256, 10, 0.95, 0.99, 0.2, True, False, 2, 2,
+                                 logging_level=level)
+        outs.append(ts.optimizer.params.clone())
+        assert all(torch.isfinite(torch.as_tensor(v)).all() for v in m.values())
+    assert torch.equal(outs[0], outs[1])
