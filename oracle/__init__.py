@@ -19,6 +19,10 @@ Pinning status:
     (`normalizer_test.py:33-65`, `adapter_test.py:61-75`,
     `rollout_test.py:121-222`, `ppo_test.py:38-62,340-349`), re-run here on
     numpy-generated data because the reference's data come from JAX's RNG.
+  * The key scheme (`oracle.keys`: reset keys, minibatch permutations, observation
+    noise) is a numpy uint64 restatement independent of the product, PINNED by the
+    published SplitMix64 outputs (`tests/test_oracle_keys.py`); the product's CPU and
+    HIP statements are checked against it bit for bit.
   * Adam / AdamW / global-norm clip (optax), Linear init (flax), LSTM / GRU cell
     arithmetic (flax) and all RNG streams (jax.random) live in third-party
     dependencies that are absent from the reference tree and from this image:

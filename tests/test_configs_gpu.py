@@ -17,6 +17,7 @@ import pytest
 import torch
 
 from nnx_ppo_amd import random as keys
+from oracle import keys as okeys  # the oracle's own key scheme (numpy; tests/test_oracle_keys.py)
 from oracle import networks as on
 from oracle import ppo as op
 
@@ -68,11 +69,11 @@ def test_c3_shape_ppo_step_vs_oracle(dev, build):
         net = _c3_net() if build == "by_hand" else _c3_net_factory()
         ts = ppo.new_training_state(env, net, N, 18, 3e-4, device=dev)
         onet = on.from_product(net)
-        ots = op.new_training_state(oenv, onet, N, 18, keys, 3e-4)
+        ots = op.new_training_state(oenv, onet, N, 18, okeys, 3e-4)
         for k in range(2):
             with _lib.profiler as prof:
                 ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 2, 1)
-            ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 1, keys)
+            ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 1, okeys)
             # the kernels this shape is meant to exercise: whole-trunk forward / dX chain
             # at M > 8192 and the grouped dW
             used = _called(prof)
@@ -116,11 +117,11 @@ def test_c4_gru_bf16_mfma_ppo_step_vs_oracle(dev):
         env, oenv = cartpole_shaped(max_steps=5), cartpole_shaped(max_steps=5)
         ts = ppo.new_training_state(env, net, N, 42, 3e-4, 1.0, device=dev)
         onet = on.from_product(net)
-        ots = op.new_training_state(oenv, onet, N, 42, keys, 3e-4, 1.0)
+        ots = op.new_training_state(oenv, onet, N, 42, okeys, 3e-4, 1.0)
         for k in range(2):
             with _lib.profiler as prof:
                 ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 2, 2)
-            ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 2, keys)
+            ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 2, okeys)
             used = _called(prof)
             assert {"mi_gru_seq_fwd_bf16", "mi_gru_seq_bwd_bf16"} <= used, used
             assert "mi_gru_seq_fwd_f32" not in used   # the matrix-core recurrence, not VALU

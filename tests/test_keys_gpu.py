@@ -293,3 +293,36 @@ def test_mock_env_step_inside_the_episode_launch(dev, obs_size):
         seen_trunc |= bool(stepped_a.info["truncated"].any())
         sa, sb = after_a, after_b
     assert seen_done and seen_trunc
+
+
+@pytest.mark.parametrize("seed", [0, 17, 2**63 + 12345])
+def test_key_kernels_equal_the_independent_restatement(dev, seed):
+    """csrc/keys.hip against `oracle/keys.py` — the scheme restated in numpy uint64 with none
+    of the product's code and pinned by the published SplitMix64 outputs
+    (tests/test_oracle_keys.py): every key function the iteration uses (`ppo.py:271,284-294`,
+    `rollout.py:57-59`, the synthetic envs' observation noise), bit for bit."""
+    from oracle import keys as ok
+
+    k = ok.key(seed)
+    assert int(keys.key(seed, device=dev)) == int(k)
+    kg = k.to(dev)
+    assert torch.equal(keys.split(kg).cpu(), ok.split(k))
+    kids = ok.split(k, (30, 257))                                     # [T, B] reset keys
+    assert torch.equal(keys.split(kg, (30, 257)).cpu(), kids)
+    kidg = kids.to(dev)
+    a, b = keys.split2(kidg)
+    assert torch.equal(torch.stack([a, b], -1).cpu(), ok.split(kids, 2))
+    assert torch.equal(keys.split(kidg, 3).cpu(), ok.split(kids, 3))
+    for data in (0, 3, 2**40 + 9):
+        assert torch.equal(keys.fold_in(kidg, data).cpu(), ok.fold_in(kids, data))
+    steps = (torch.arange(kids.numel(), dtype=torch.int64) * 977 - 3).reshape(kids.shape)
+    assert torch.equal(keys.fold_key(kidg, steps.to(dev)).cpu(), ok.fold_key(kids, steps))
+    assert torch.equal(keys.bits(kidg, (3,)).cpu(), ok.bits(kids, (3,)))
+    assert torch.equal(keys.randint(kidg, (2,), -3, 10).cpu(), ok.randint(kids, (2,), -3, 10))
+    assert torch.equal(keys.uniform(kidg, (5,)).cpu(), ok.uniform(kids, (5,)))
+    assert torch.equal(keys.unit_uniform(kidg, (5,)).cpu(), ok.unit_uniform(kids, (5,)))
+    assert torch.equal(keys.unit_uniform(kidg, (17,), fold=steps.to(dev)).cpu(),
+                       ok.unit_uniform(kids, (17,), fold=steps))
+    for n in (64, 1024, 4096, 8192):                                  # one launch for all 4
+        assert torch.equal(keys.permutations(kg, 4, n).cpu(), ok.permutations(k, 4, n))
+    assert torch.equal(keys.permutation(kg, 10000).cpu(), ok.permutation(k, 10000))

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from nnx_ppo_amd import random as keys
+from oracle import keys as okeys  # the oracle's own key scheme (numpy; tests/test_oracle_keys.py)
 from oracle import networks as on
 from oracle import ppo as op
 
@@ -100,11 +101,11 @@ def _run_both(dev, env_fn, net_fn, N, T, n_epochs, n_mb, iters, **kw):
     ts = ppo.new_training_state(env, net, N, 18, 1e-3, kw.get("clip"), kw.get("wd"), device=dev)
     onet = on.from_product(net)
     oenv = env_fn()
-    ots = op.new_training_state(oenv, onet, N, 18, keys, 1e-3, kw.get("clip"), kw.get("wd"))
+    ots = op.new_training_state(oenv, onet, N, 18, okeys, 1e-3, kw.get("clip"), kw.get("wd"))
     out = []
     for _ in range(iters):
         ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, n_epochs, n_mb)
-        ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, n_epochs, n_mb, keys)
+        ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, n_epochs, n_mb, okeys)
         out.append((ts, m, ots, info))
     return net, onet, out
 
@@ -268,9 +269,9 @@ def test_pytree_obs_network(dev):
     ts = ppo.new_training_state(env, net, 64, 3, device=dev)
     onet = on.from_product(net)
     oenv = cheetah_shaped(max_steps=6)
-    ots = op.new_training_state(oenv, onet, 64, 3, keys)
+    ots = op.new_training_state(oenv, onet, 64, 3, okeys)
     ts, m = ppo.ppo_step(env, ts, 64, 10, 0.95, 0.99, 0.2, True, False, 2, 2)
-    ots, info = op.ppo_step(oenv, ots, 64, 10, 0.95, 0.99, 0.2, True, 2, 2, keys)
+    ots, info = op.ppo_step(oenv, ots, 64, 10, 0.95, 0.99, 0.2, True, 2, 2, okeys)
     assert int(ts.steps_taken) == 640
     assert np.allclose(m["losses/critic/mean"].item(), info["critic"].numpy().mean(), rtol=1e-3)
     assert np.allclose(m["losses/actor/mean"].item(), info["actor"].numpy().mean(), rtol=1e-3,
