@@ -65,7 +65,11 @@ def test_c3_shape_ppo_step_vs_oracle(dev, build):
     N, T = 512, 30                       # one minibatch: M = 15 360 rows per gradient step
     mk_env = lambda: EpisodeWrapper(cheetah_shaped(max_steps=11), 40)
     with config.use_compute_dtype("bf16"):
-        env, oenv = mk_env(), mk_env()
+        from oracle import envs as oe
+
+        # the oracle side on the oracle's own env / wrapper / keys (oracle/envs.py, keys.py)
+        env = mk_env()
+        oenv = oe.EpisodeWrapper(oe.MockEnv({"position": 8, "velocity": 9}, 6, max_steps=11), 40)
         net = _c3_net() if build == "by_hand" else _c3_net_factory()
         ts = ppo.new_training_state(env, net, N, 18, 3e-4, device=dev)
         onet = on.from_product(net)
@@ -114,7 +118,9 @@ def test_c4_gru_bf16_mfma_ppo_step_vs_oracle(dev):
     N, T = 256, 30
     with config.use_compute_dtype("bf16"):
         net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(42))
-        env, oenv = cartpole_shaped(max_steps=5), cartpole_shaped(max_steps=5)
+        from oracle import envs as oe
+
+        env, oenv = cartpole_shaped(max_steps=5), oe.MockEnv(5, 1, max_steps=5)
         ts = ppo.new_training_state(env, net, N, 42, 3e-4, 1.0, device=dev)
         onet = on.from_product(net)
         ots = op.new_training_state(oenv, onet, N, 42, okeys, 3e-4, 1.0)

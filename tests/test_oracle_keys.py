@@ -69,3 +69,40 @@ def test_minibatch_indices_follow_the_reference_structure():
     want = torch.cat([ok.permutation(ok.fold_in(new_key, e), n_envs).reshape(n_mb, -1)
                       for e in range(n_epochs)], 0)
     assert torch.equal(minibatch_indices(new_key, n_envs, n_epochs, n_mb), want)
+
+
+@pytest.mark.parametrize("obs_size", [5, {"position": 8, "velocity": 9}])
+def test_product_envs_on_cpu_equal_the_oracle_envs(obs_size):
+    """`oracle/envs.py` (MockEnv `mock_env.py:25-63`, EpisodeWrapper
+    `episode_wrapper.py:8-44`, restated with the oracle's keys) against the product's env
+    classes on CPU tensors: every leaf of the state after reset and after each of 14 steps,
+    resets applied the rollout's way (`rollout.py:39-44`) — bit for bit."""
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.tree import tree_leaves
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+    from oracle import envs as oe
+    from oracle import ppo as op
+
+    pe = EpisodeWrapper(MockEnv(obs_size, 1, max_steps=4), 9)
+    qe = oe.EpisodeWrapper(oe.MockEnv(obs_size, 1, max_steps=4), 9)
+    k0 = ok.split(ok.key(3), 64)
+    ps, qs = pe.reset(k0), qe.reset(k0)
+
+    def same(a, b):
+        la = [a.obs, a.reward, a.done, a.info["step_counter"], a.info["truncated"],
+              a.data["key"], a.data["step_count"]]
+        lb = [b.obs, b.reward, b.done, b.info["step_counter"], b.info["truncated"],
+              b.data["key"], b.data["step_count"]]
+        for x, y in zip(tree_leaves(la), tree_leaves(lb)):
+            assert x.dtype == y.dtype and torch.equal(x, y)
+
+    same(ps, qs)
+    reset_keys = ok.split(ok.key(4), (14, 64))
+    for t in range(14):
+        a = torch.zeros(64, 1)
+        ps, qs = pe.step(ps, a), qe.step(qs, a)
+        same(ps, qs)
+        done = qs.done != 0
+        ps = op.tree_where(done, pe.reset(reset_keys[t]), ps)
+        qs = op.tree_where(done, qe.reset(reset_keys[t]), qs)
+        same(ps, qs)

@@ -93,14 +93,16 @@ def _extras_for(net, rng, O, dev):
     return [x, {"action": [None] * len(ad.action.layers), "value": [None] * len(ad.value.layers)}]
 
 
-def _run_both(dev, env_fn, net_fn, N, T, n_epochs, n_mb, iters, **kw):
+def _run_both(dev, env_fn, net_fn, N, T, n_epochs, n_mb, iters, oenv_fn=None, **kw):
+    """`oenv_fn`: the oracle's own env (oracle/envs.py) where one exists; otherwise the
+    product's env class on CPU tensors."""
     from nnx_ppo_amd.algorithms import ppo
 
     env = env_fn()
     net = net_fn()
     ts = ppo.new_training_state(env, net, N, 18, 1e-3, kw.get("clip"), kw.get("wd"), device=dev)
     onet = on.from_product(net)
-    oenv = env_fn()
+    oenv = (oenv_fn or env_fn)()
     ots = op.new_training_state(oenv, onet, N, 18, okeys, 1e-3, kw.get("clip"), kw.get("wd"))
     out = []
     for _ in range(iters):
@@ -119,9 +121,13 @@ def test_ppo_step_trace_vs_oracle(dev):
     from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
 
     N, T = 64, 12
+    from oracle import envs as oe
+
     env_fn = lambda: EpisodeWrapper(MockEnv(5, 1, max_steps=5), 40)
+    # the oracle side runs on the oracle's own env, wrapper and keys (oracle/envs.py, keys.py)
+    oenv_fn = lambda: oe.EpisodeWrapper(oe.MockEnv(5, 1, max_steps=5), 40)
     net_fn = lambda: _make(5, 1, [64, 64, 64, 64], [256, 256])
-    net, onet, out = _run_both(dev, env_fn, net_fn, N, T, 2, 4, iters=2)
+    net, onet, out = _run_both(dev, env_fn, net_fn, N, T, 2, 4, iters=2, oenv_fn=oenv_fn)
     for k, (ts, m, ots, info) in enumerate(out):
         assert int(ts.steps_taken) == (k + 1) * N * T == ots.steps_taken
         assert torch.equal(_cpu(ts.rng_key), ots.rng_key)
