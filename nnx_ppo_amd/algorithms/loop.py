@@ -189,15 +189,22 @@ def should_run(steps: int, last_step: int, every_steps: int) -> bool:
 
 def health_check(device) -> None:
     """Raise if a bounded in-kernel wait has run out since the last check: a peer that never
-    delivered its chunks to a one-shot exchange (`comm.PeerComm.check`).  Reads device
+    delivered its chunks to a one-shot exchange (`comm.PeerComm.check`), or a workgroup of the
+    backward-with-GAE launch that never published its statistics partial.  Reads device
     words (it synchronises), so the loop calls it where it is synchronised anyway — eval,
     checkpoint, the end of training."""
-    from .. import parallel
+    from .. import ops, parallel
 
     del device
     comm = parallel.peer_comm()
     if comm is not None:
         comm.check()
+    n = ops.policy_bwd_gae_timeouts()
+    if n:
+        raise RuntimeError(
+            f"{n} advantage-statistics hand-over(s) inside mi_policy_ws_bwd_gae_bf16 timed out: "
+            "a workgroup of the launch was not resident within 2 s (another kernel holding the "
+            "CUs?); MIPPO_GAE_IN_BWD=0 keeps the GAE / loss launch of its own")
 
 
 def run_training_loop(

@@ -815,7 +815,8 @@ struct WsGae {
   float* loss_out;                             // [4] actor, critic, regularisation, clip fraction
   double* part;                                // workspace: [ntiles][4] partial sums
   double* sp;                                  // workspace: [groups][2] statistics partials
-  unsigned int *ticket, *arrive;               // workspace header (zero between launches)
+  unsigned int *ticket, *arrive;               // workspace header (zero between launches);
+                                               // arrive[1]: sticky count of timed-out waits
   int T, B;
   float gamma, lambda, clip, critic_weight;
   int normalize;
@@ -1077,7 +1078,13 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           while (__hip_atomic_load(g.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
                  (unsigned)GB) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > kGaeSpinTicks) break;  // never in a healthy launch
+            if (wall_clock64() - t0 > kGaeSpinTicks) {  // never in a healthy launch
+              // sticky word the host reads at its next synchronisation point
+              // (ops.policy_bwd_gae_timeouts, loop.health_check): the statistics are wrong
+              __hip_atomic_fetch_add(g.arrive + 1, 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
           }
         }
         // acquire only: the partials may sit stale in this XCD's L2 from the previous launch

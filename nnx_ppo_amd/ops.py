@@ -946,6 +946,19 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
     return a_dz, c_dz, loss_out
 
 
+def policy_bwd_gae_timeouts() -> int:
+    """How many bounded in-kernel waits of `mi_policy_ws_bwd_gae_bf16` (the advantage-statistics
+    hand-over between its workgroups) have run out since the workspaces were created.  Reads
+    device words (it synchronises): the training loop calls it where it is synchronised
+    anyway (`algorithms/loop.py:health_check`).  Non-zero = some gradient step normalised its
+    advantages with incomplete statistics."""
+    total = 0
+    for key, ws in _workspaces.items():
+        if key[2] == "policy_bwd_gae":
+            total += int(ws[8:12].view(torch.int32).item())
+    return total
+
+
 def mlp_ws_bwd_dx_bf16(g_out: torch.Tensor, w_bfs: list, dims: list, acts: list, auxs: list):
     """`mlp_bwd_dx_bf16(..., need_input_grad=False)` with a linear last layer on the
     weights-stationary kernel.  Returns the dz list."""

@@ -399,3 +399,6 @@ def test_ppo_step_with_gae_in_backward_equals_separate_launch(dev):
     assert outs[0][1].keys() == outs[1][1].keys()
     for k, v in outs[0][1].items():
         assert v == pytest.approx(outs[1][1][k], rel=1e-6, abs=1e-9), k
+    from nnx_ppo_amd import ops
+
+    assert ops.policy_bwd_gae_timeouts() == 0  # no statistics hand-over ever timed out
