@@ -676,12 +676,21 @@ int mi_policy_ws_bwd_gae_bf16(
     float entropy_weight, const float* rewards, const float* values, const float* last_value,
     const uint8_t* done, const uint8_t* truncated, const float* ll_new, const float* ll_old,
     const float* reg, float gamma, float lambda, int normalize, float clip_range,
-    float critic_weight, float* loss_out, void* workspace, int64_t T, int64_t B, int64_t La,
+    float critic_weight, float* loss_out, double* partials_out, void* workspace, int64_t T,
+    int64_t B, int64_t La,
     const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
     const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
     const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
     const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
     const void* const* a_mask, const void* const* c_mask, mi_stream_t stream);
+/* Exactly one of loss_out / partials_out above is given.  With partials_out (double
+ * [T * B / 64][4], caller-owned) the launch leaves its per-tile fp64 partials there and does
+ * not sum them — the sum at the tail of the launch is 2.5-3 us on its critical path for four
+ * scalars that are read at the end of the iteration; mi_policy_loss_finalize_f32 sums the
+ * partials of up to 32 such launches (M[s] = T * B of launch s) in one launch, in the
+ * in-kernel order: the same bits. */
+int mi_policy_loss_finalize_f32(int64_t n, const void* const* partials, const int64_t* M,
+                                float* const* loss_out, mi_stream_t stream);
 
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
  * MockEnv, restating `nnx_ppo/test_dummies/mock_env.py:25-63`): step' = step + 1,

@@ -278,6 +278,7 @@ def ppo_step(
         grad_norms = torch.empty(total_iterations, dtype=torch.float32, device=device)
 
     critic_extra: dict = {}
+    pending_losses: list = []
     # minibatch gather x[:, inds] (ppo.py:297-300).  The indices of every gradient step are
     # known before the first one, and the gathered leaves (rollout data, pre-rollout
     # carry) do not change during the update: ONE launch gathers all n_epochs *
@@ -306,7 +307,7 @@ def ppo_step(
         _, lm = ppo_loss(networks, net_state_subset, minibatch, clip_range,
                          normalize_advantages, combine_advantages, discounting_factor,
                          gae_lambda, critic_loss_weight, logging_level, loss_out=loss_rows[i],
-                         want_total=False)
+                         want_total=False, defer_loss=pending_losses)
         for k, v in lm.items():
             # per-step diagnostics that are not columns of `loss_rows`: CRITIC_EXTRA, and
             # the per-key trees of a PyTree reward / value / log-likelihood setup
@@ -316,6 +317,7 @@ def ppo_step(
         # written straight into its row (sharded: taken after the all-reduce)
         optimizer.update(norm_out=None if grad_norms is None else grad_norms[i:i + 1])
 
+    ops.policy_loss_finalize(pending_losses)  # the loss rows left as per-tile partials
     scale = 1.0
     if parallel.is_distributed():
         parallel.allreduce_sum_(loss_rows)
@@ -393,12 +395,16 @@ def ppo_loss(
     loss_out: Optional[torch.Tensor] = None,
     backward: bool = True,
     want_total: bool = True,
+    defer_loss: Optional[list] = None,
 ) -> tuple[Optional[torch.Tensor], dict]:
     """ppo.py:397-531.  Evaluates the loss on one minibatch (`[T, mb, ...]` leaves)
     and — where the reference returns gradients from `nnx.grad` — ACCUMULATES the
     parameter gradients into `Parameter.grad`.  Returns (total_loss, loss_metrics);
     `loss_out` (float32 [4]) receives (actor, critic, regularization,
-    clipping_fraction) without a host sync."""
+    clipping_fraction) without a host sync.  `defer_loss` (a list, with `loss_out` and
+    `want_total=False`): a path that can leave the four scalars as partial sums does so and
+    appends to the list; they are filled by `ops.policy_loss_finalize(defer_loss)` — `ppo_step`
+    does that once per iteration instead of 16 times at the tail of a launch."""
     done = rollout_data.done
     truncated = rollout_data.truncated
     T, B = done.shape
@@ -468,7 +474,8 @@ def ppo_loss(
                 ll_new.contiguous(), ll_old.contiguous(),
                 None if reg_seq is None else reg_seq.contiguous(), discounting_factor,
                 gae_lambda, normalize_advantages, clip_range, critic_loss_weight,
-                loss_out=loss_out)
+                loss_out=loss_out,
+                defer=defer_loss if (loss_out is not None and not want_total) else None)
             backward = False
         elif fused_loss:
             # GAE, advantage statistics, loss terms and gradients in ONE launch (the

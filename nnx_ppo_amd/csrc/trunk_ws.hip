@@ -1401,6 +1401,17 @@ policy_ws_bwd_gae_kernel(WsBwdChain a, WsBwdChain v, WsGae g, int n_value) {
     *s_last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
               gridDim.x - 1;
   __syncthreads();
+  if (*s_last && !g.loss_out) {
+    // deferred: the per-tile partials stay where they are for mi_policy_loss_finalize_f32 (the
+    // sum below, with its acquire and its load round trip, is 2.5-3 us at the END of the
+    // launch's critical path — for four scalars nobody reads before the iteration's metrics);
+    // every workgroup is past the statistics spin: re-arm both counters
+    if (tid == 0) {
+      __hip_atomic_store(g.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (*s_last && tid < 64) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int64_t ntiles = a.M / 64;
@@ -1423,6 +1434,36 @@ policy_ws_bwd_gae_kernel(WsBwdChain a, WsBwdChain v, WsGae g, int n_value) {
       __hip_atomic_store(g.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(g.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+}
+
+// The four loss scalars of up to kLossFinalMax deferred launches from their per-tile partials:
+// one wave per launch, the in-kernel sum's order (lane-strided, then the shuffle tree) — the
+// same bits.
+constexpr int kLossFinalMax = 32;
+struct LossFinal {
+  const double* part[kLossFinalMax];
+  float* out[kLossFinalMax];
+  long long ntiles[kLossFinalMax];
+  double dn[kLossFinalMax];
+};
+__global__ void __launch_bounds__(64) policy_loss_finalize_kernel(LossFinal f) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const double* part = f.part[s];
+  double z[4] = {0.0, 0.0, 0.0, 0.0};
+  for (long long t = tid; t < f.ntiles[s]; t += 64)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] += part[4 * t + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] += __shfl_down(z[k], off, 64);
+  if (tid == 0) {
+    const double dn = f.dn[s];
+    f.out[s][0] = (float)(-z[0] / dn);
+    f.out[s][1] = (float)(0.5 * z[1] / dn);
+    f.out[s][2] = (float)(z[2] / dn);
+    f.out[s][3] = (float)(z[3] / dn);
   }
 }
 
@@ -1787,15 +1828,19 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
     float entropy_weight, const float* rewards, const float* values, const float* last_value,
     const uint8_t* done, const uint8_t* truncated, const float* ll_new, const float* ll_old,
     const float* reg, float gamma, float lambda, int normalize, float clip_range,
-    float critic_weight, float* loss_out, void* workspace, int64_t T, int64_t B, int64_t La,
+    float critic_weight, float* loss_out, double* partials_out, void* workspace, int64_t T,
+    int64_t B, int64_t La,
     const void* const* a_w, const int64_t* a_dims, const int64_t* a_acts,
     const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
     const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
     const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
     const void* const* a_mask, const void* const* c_mask, mi_stream_t stream) {
   MI_REQUIRE(mean_and_std && extras && rewards && values && last_value && done && truncated &&
-                 ll_new && ll_old && loss_out && workspace && a_mask && c_mask,
+                 ll_new && ll_old && workspace && a_mask && c_mask,
              "mi_policy_ws_bwd_gae_bf16: null pointer");
+  MI_REQUIRE((loss_out != nullptr) != (partials_out != nullptr),
+             "mi_policy_ws_bwd_gae_bf16: exactly one of loss_out (summed in the launch) and "
+             "partials_out (deferred: mi_policy_loss_finalize_f32)");
   MI_REQUIRE(rng_state || eps2, "mi_policy_ws_bwd_gae_bf16: need rng_state or injected eps2");
   MI_REQUIRE(mi_policy_ws_bwd_gae_supported(T, B, La, a_dims, a_acts, Lc, c_dims, c_acts),
              "mi_policy_ws_bwd_gae_bf16: [T=%lld, B=%lld] on these trunks is outside the fused "
@@ -1817,7 +1862,9 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
                    c_aux, c_dz_last, c_dz_bf, c_mask);
   if (rc) return rc;
   WsGae g = {rewards, values, last_value, done, truncated, ll_new, ll_old, reg, loss_out,
-             reinterpret_cast<double*>(static_cast<char*>(workspace) + kGaeHeaderBytes),
+             partials_out ? partials_out
+                          : reinterpret_cast<double*>(static_cast<char*>(workspace) +
+                                                      kGaeHeaderBytes),
              reinterpret_cast<double*>(static_cast<char*>(workspace) + 64),
              static_cast<unsigned int*>(workspace), static_cast<unsigned int*>(workspace) + 1,
              (int)T, (int)B, gamma, lambda, clip_range, critic_weight, normalize};
@@ -1833,6 +1880,27 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
   WS_DUAL_MENU(X)
 #undef X
   MI_REQUIRE(false, "mi_policy_ws_bwd_gae_bf16: no instantiation for these trunks");
+}
+
+extern "C" int mi_policy_loss_finalize_f32(int64_t n, const void* const* partials,
+                                           const int64_t* M, float* const* loss_out,
+                                           mi_stream_t stream) {
+  MI_REQUIRE(n >= 0 && n <= kLossFinalMax, "mi_policy_loss_finalize_f32: 0 <= n <= %d",
+             kLossFinalMax);
+  if (n == 0) return 0;
+  MI_REQUIRE(partials && M && loss_out, "mi_policy_loss_finalize_f32: null pointer");
+  LossFinal f = {};
+  for (int64_t s = 0; s < n; ++s) {
+    MI_REQUIRE(partials[s] && loss_out[s] && M[s] >= 64 && M[s] % 64 == 0,
+               "mi_policy_loss_finalize_f32: bad entry %lld", (long long)s);
+    f.part[s] = static_cast<const double*>(partials[s]);
+    f.out[s] = loss_out[s];
+    f.ntiles[s] = M[s] / 64;
+    f.dn[s] = (double)M[s];
+  }
+  hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3((unsigned)n), dim3(64), 0,
+                     mippo::as_stream(stream), f);
+  return mippo::check_launch("mi_policy_loss_finalize_f32");
 }
 
 // 1 if both trunks of a policy step are in the weights-stationary shape class (and the

@@ -382,9 +382,10 @@ class MLPActorCritic(Sequential):
 
     def replay_backward_gae(self, ctx, g_reg, rewards, values, last_values, done, truncated,
                             ll_new, ll_old, reg, gamma, lambda_, normalize, clip_range,
-                            critic_weight, loss_out=None):
+                            critic_weight, loss_out=None, defer=None):
         """`ops.gae_ppo_loss` followed by `replay_backward`, as ONE launch + the dW launch
-        (`gae_backward_supported` must hold).  Returns loss_out[4]."""
+        (`gae_backward_supported` must hold).  Returns loss_out[4] — with `defer` (a list)
+        filled only by `ops.policy_loss_finalize(defer)`."""
         _, s_ctx, a_ctx, v_ctx, _, (T, B), masks = ctx
         a_layers, sampler, c_layers = self._parts()
         ms2, ex2, off, eps2, _ = s_ctx
@@ -393,7 +394,8 @@ class MLPActorCritic(Sequential):
         a_dz, c_dz, loss_out = ops.policy_bwd_gae_bf16(
             ms2, ex2, sampler._state(ms2.device), off, g_reg, da, dc, masks, rewards, values,
             last_values, done, truncated, ll_new, ll_old, reg, gamma, lambda_, normalize,
-            clip_range, critic_weight, eps2=eps2, loss_out=loss_out, **sampler._kw())
+            clip_range, critic_weight, eps2=eps2, loss_out=loss_out, defer=defer,
+            **sampler._kw())
         problems = []
         for ls, c, dz in ((c_layers, v_ctx, c_dz), (a_layers, a_ctx, a_dz)):
             for i in range(len(ls) - 1, -1, -1):

@@ -886,12 +886,15 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
                         ll_old, reg, gamma: float, lambda_: float, normalize: bool,
                         clip_range: float, critic_weight: float, *, min_std: float,
                         std_scale: float, entropy_weight: float, eps2=None,
-                        loss_out: torch.Tensor | None = None):
+                        loss_out: torch.Tensor | None = None, defer: list | None = None):
     """`gae_ppo_loss` + `policy_bwd_bf16(ws=True, masks=...)` in ONE launch
     (`mi_policy_ws_bwd_gae_bf16`): the GAE scan, the advantage statistics and the loss
     gradients are evaluated inside the backward's workgroups.  `[T, B]` operands as in
     `gae_ppo_loss`.  Returns (actor dz list, critic dz list, loss_out[4]); the dz images are
-    bit-identical to the two launches, the four scalars equal up to fp64 summation order."""
+    bit-identical to the two launches, the four scalars equal up to fp64 summation order.
+    `defer` (a list): the launch leaves its per-tile partials in a buffer of their own and
+    appends (partials, T * B, loss_out) to the list instead of summing them at its tail;
+    `policy_loss_finalize(defer)` fills every pending `loss_out` in one launch (same bits)."""
     T, B = rewards.shape
     M, A2 = mean_and_std.shape
     dev = mean_and_std.device
@@ -919,6 +922,10 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
     # (before the work annotation: the size query is a recorded C-ABI call of its own)
     ws = workspace(dev, "policy_bwd_gae", lib().mi_policy_ws_bwd_gae_workspace_bytes(M),
                    zeroed=True)
+    part = None
+    if defer is not None:
+        part = torch.empty(M // 64 * 4, dtype=f64, device=dev)
+        defer.append((part, M, loss_out))
     if profiler.active:
         flop = sum(a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
             + sum(c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
@@ -936,7 +943,8 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
         ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32), ptr(_as_u8(done), u8),
         ptr(_as_u8(truncated), u8), ptr(ll_new, f32), ptr(ll_old, f32), ptr(reg, f32),
         float(gamma), float(lambda_), int(bool(normalize)), float(clip_range),
-        float(critic_weight), ptr(loss_out, f32), ptr(ws), T, B,
+        float(critic_weight), None if part is not None else ptr(loss_out, f32), ptr(part, f64),
+        ptr(ws), T, B,
         La, arr(a_w, La), i64s(a_dims), i64s(a_acts), arr(a_aux[:La - 1], La - 1),
         ptr(a_dz[La - 1], bf16), arr(a_dz[:La - 1], La - 1),
         Lc, arr(c_w, Lc), i64s(c_dims), i64s(c_acts), arr(c_aux[:Lc - 1], Lc - 1),
@@ -944,6 +952,19 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
         arr(am[:La - 1], La - 1), arr(cm[:Lc - 1], Lc - 1), stream()),
         "mi_policy_ws_bwd_gae_bf16")
     return a_dz, c_dz, loss_out
+
+
+def policy_loss_finalize(pending: list) -> None:
+    """Sum the per-tile loss partials of deferred `policy_bwd_gae_bf16` launches
+    (`mi_policy_loss_finalize_f32`): `pending` = [(partials, T * B, loss_out[4])], cleared."""
+    for i in range(0, len(pending), 32):
+        chunk = pending[i:i + 32]
+        n = len(chunk)
+        P = ctypes.c_void_p * n
+        check(lib().mi_policy_loss_finalize_f32(
+            n, P(*[ptr(c[0], f64) for c in chunk]), (ctypes.c_int64 * n)(*[int(c[1]) for c in chunk]),
+            P(*[ptr(c[2], f32) for c in chunk]), stream()), "mi_policy_loss_finalize_f32")
+    pending.clear()
 
 
 def policy_bwd_gae_timeouts() -> int:

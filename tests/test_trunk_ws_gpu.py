@@ -369,6 +369,26 @@ def _gae_inside_case(dev, shape, T, B, normalize, with_reg) -> bool:
                 assert torch.equal(a, b), (rep, name, l,
                                            float((a.float() - b.float()).abs().max()))
         assert torch.allclose(got_loss, want_loss, rtol=1e-6, atol=1e-9), (got_loss, want_loss)
+    # deferred: the launch leaves its per-tile partials, mi_policy_loss_finalize_f32 sums them
+    # (two pending launches in one finalize): the same bits as the sum at the launch's tail
+    pending: list = []
+    outs = []
+    for rep in range(2):
+        lo = torch.full((4,), float("nan"), device=dev)
+        d_a, d_c, lo2 = ops.policy_bwd_gae_bf16(
+            rw["mean_and_std"], extras, rng_state, 2, 1.0 / M, actor, critic, masks, rewards,
+            values, last_value, done, trunc, ll_new, ll_old, reg, *args, loss_out=lo,
+            defer=pending, **kw)
+        assert lo2 is lo
+        outs.append((d_a, d_c, lo))
+    assert len(pending) == 2
+    ops.policy_loss_finalize(pending)
+    assert not pending
+    for d_a, d_c, lo in outs:
+        assert torch.equal(lo, got_loss), (lo, got_loss)
+        for wl, gl in ((got_a, d_a), (got_c, d_c)):
+            for a, b in zip(wl, gl):
+                assert torch.equal(a, b)
     return True
 
 
