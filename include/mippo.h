@@ -687,9 +687,11 @@ int mi_policy_ws_bwd_gae_bf16(
  * [T * B / 64][4], caller-owned) the launch leaves its per-tile fp64 partials there and does
  * not sum them — the sum at the tail of the launch is 2.5-3 us on its critical path for four
  * scalars that are read at the end of the iteration; mi_policy_loss_finalize_f32 sums the
- * partials of up to 32 such launches (M[s] = T * B of launch s) in one launch, in the
- * in-kernel order: the same bits. */
-int mi_policy_loss_finalize_f32(int64_t n, const void* const* partials, const int64_t* M,
+ * partials of up to 32 deferred launches in one launch, in the in-kernel order (the same
+ * bits): launch s left n_partials[s] rows of 4 doubles (T * B / 64 here; N / 64 for
+ * mi_gae_ppo_loss_f32's partials_out) over n_elements[s] = T * B elements. */
+int mi_policy_loss_finalize_f32(int64_t n, const void* const* partials,
+                                const int64_t* n_partials, const int64_t* n_elements,
                                 float* const* loss_out, mi_stream_t stream);
 
 /* The synthetic benchmark env's whole step in one launch (`nnx_ppo_amd/envs/synthetic.py`
@@ -719,8 +721,12 @@ int mi_gae_ppo_loss_f32(const float* rewards, const float* values, const float* 
                         const float* ll_old, const float* reg, float gamma, float lambda,
                         int normalize, float clip_range, float critic_weight,
                         float* advantages, double* adv_stats, float* g_ll, float* g_v,
-                        float* loss_out, void* workspace, int64_t T, int64_t N,
-                        mi_stream_t stream);
+                        float* loss_out, double* partials_out, void* workspace, int64_t T,
+                        int64_t N, mi_stream_t stream);
+/* Exactly one of loss_out / partials_out: with partials_out (double [ceil(N / 64)][4],
+ * caller-owned) the launch leaves its per-workgroup partials there instead of summing them
+ * at its tail; mi_policy_loss_finalize_f32 (n_partials = ceil(N / 64), n_elements = T * N)
+ * sums them later, in the same order. */
 
 /* ---- e: one-shot peer exchange (new; the reference is single-device) -------- */
 

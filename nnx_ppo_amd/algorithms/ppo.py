@@ -486,7 +486,10 @@ def ppo_loss(
                 truncated.contiguous(), ll_new.contiguous(), ll_old.contiguous(),
                 None if reg_seq is None else reg_seq.contiguous(), discounting_factor,
                 gae_lambda, normalize_advantages, clip_range, critic_loss_weight,
-                loss_out=loss_out, want_adv=LoggingLevel.CRITIC_EXTRA in logging_level)
+                loss_out=loss_out, want_adv=LoggingLevel.CRITIC_EXTRA in logging_level,
+                defer=defer_loss if (loss_out is not None and not want_total
+                                     and LoggingLevel.CRITIC_EXTRA not in logging_level)
+                else None)
         else:
             stats = None
             if normalize_advantages:

@@ -28,7 +28,8 @@ struct Args {
   const uint8_t *done, *trunc;
   const float *ll_new, *ll_old, *reg;  // reg nullable
   float *adv_out;                      // nullable
-  float *g_ll, *g_v, *loss_out;
+  float *g_ll, *g_v, *loss_out;        // loss_out null: deferred (partials_out)
+  double* partials_out;                // nullable: [G][4] loss partials left for a later sum
   double* stats_out;                   // nullable: the (sum, sum sq, count) triple
   void* ws;
   int64_t T, N;
@@ -56,7 +57,7 @@ gae_loss_kernel(Args a) {
   unsigned int* arrive = static_cast<unsigned int*>(a.ws);
   unsigned int* ticket = arrive + 1;
   double* sp = reinterpret_cast<double*>(static_cast<char*>(a.ws) + kHeaderBytes);  // [G][2]
-  double* lp = sp + 2 * kMaxBlocks;                                                 // [G][4]
+  double* lp = a.partials_out ? a.partials_out : sp + 2 * kMaxBlocks;               // [G][4]
   const int G = (int)gridDim.x;
   __shared__ float s_r[kMaxT][kEnvs], s_v[kMaxT][kEnvs], s_adv[kMaxT][kEnvs];
   __shared__ uint8_t s_d[kMaxT][kEnvs], s_tr[kMaxT][kEnvs];
@@ -221,6 +222,14 @@ gae_loss_kernel(Args a) {
               (unsigned)G - 1;
   }
   __syncthreads();
+  if (is_last && !a.loss_out) {
+    // deferred (mi_policy_loss_finalize_f32 sums the partials): only re-arm the counters
+    if (tid == 0) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (is_last && tid < 64) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double z[4] = {0.0, 0.0, 0.0, 0.0};
@@ -259,16 +268,19 @@ extern "C" int mi_gae_ppo_loss_f32(const float* rewards, const float* values,
                                    const float* ll_old, const float* reg, float gamma,
                                    float lambda, int normalize, float clip_range,
                                    float critic_weight, float* advantages, double* adv_stats,
-                                   float* g_ll, float* g_v, float* loss_out, void* workspace,
-                                   int64_t T, int64_t N, mi_stream_t stream) {
+                                   float* g_ll, float* g_v, float* loss_out,
+                                   double* partials_out, void* workspace, int64_t T, int64_t N,
+                                   mi_stream_t stream) {
   MI_REQUIRE(mi_gae_ppo_loss_supported(T, N),
              "mi_gae_ppo_loss_f32: 1 <= T <= %d and 1 <= N <= %d (got T=%lld N=%lld)", kMaxT,
              64 * kMaxBlocks, (long long)T, (long long)N);
   MI_REQUIRE(rewards && values && last_value && done && truncated && ll_new && ll_old && g_ll &&
-                 g_v && loss_out && workspace,
+                 g_v && workspace,
              "mi_gae_ppo_loss_f32: null pointer");
+  MI_REQUIRE((loss_out != nullptr) != (partials_out != nullptr),
+             "mi_gae_ppo_loss_f32: exactly one of loss_out and partials_out");
   Args a = {rewards, values,  last_value, done,      truncated, ll_new, ll_old,     reg,
-            advantages, g_ll, g_v,        loss_out,  adv_stats, workspace, T,       N,
+            advantages, g_ll, g_v,        loss_out,  partials_out, adv_stats, workspace, T, N,
             gamma,   lambda,  clip_range, critic_weight, normalize};
   hipLaunchKernelGGL(gae_loss_kernel, dim3((unsigned)mippo::ceil_div(N, kEnvs)), dim3(kThreads),
                      0, mippo::as_stream(stream), a);

@@ -1883,20 +1883,21 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
 }
 
 extern "C" int mi_policy_loss_finalize_f32(int64_t n, const void* const* partials,
-                                           const int64_t* M, float* const* loss_out,
-                                           mi_stream_t stream) {
+                                           const int64_t* n_partials, const int64_t* n_elements,
+                                           float* const* loss_out, mi_stream_t stream) {
   MI_REQUIRE(n >= 0 && n <= kLossFinalMax, "mi_policy_loss_finalize_f32: 0 <= n <= %d",
              kLossFinalMax);
   if (n == 0) return 0;
-  MI_REQUIRE(partials && M && loss_out, "mi_policy_loss_finalize_f32: null pointer");
+  MI_REQUIRE(partials && n_partials && n_elements && loss_out,
+             "mi_policy_loss_finalize_f32: null pointer");
   LossFinal f = {};
   for (int64_t s = 0; s < n; ++s) {
-    MI_REQUIRE(partials[s] && loss_out[s] && M[s] >= 64 && M[s] % 64 == 0,
+    MI_REQUIRE(partials[s] && loss_out[s] && n_partials[s] >= 1 && n_elements[s] >= 1,
                "mi_policy_loss_finalize_f32: bad entry %lld", (long long)s);
     f.part[s] = static_cast<const double*>(partials[s]);
     f.out[s] = loss_out[s];
-    f.ntiles[s] = M[s] / 64;
-    f.dn[s] = (double)M[s];
+    f.ntiles[s] = n_partials[s];
+    f.dn[s] = (double)n_elements[s];
   }
   hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3((unsigned)n), dim3(64), 0,
                      mippo::as_stream(stream), f);

@@ -893,7 +893,7 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
     `gae_ppo_loss`.  Returns (actor dz list, critic dz list, loss_out[4]); the dz images are
     bit-identical to the two launches, the four scalars equal up to fp64 summation order.
     `defer` (a list): the launch leaves its per-tile partials in a buffer of their own and
-    appends (partials, T * B, loss_out) to the list instead of summing them at its tail;
+    appends (partials, rows, T * B, loss_out) to the list instead of summing them at its tail;
     `policy_loss_finalize(defer)` fills every pending `loss_out` in one launch (same bits)."""
     T, B = rewards.shape
     M, A2 = mean_and_std.shape
@@ -925,7 +925,7 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
     part = None
     if defer is not None:
         part = torch.empty(M // 64 * 4, dtype=f64, device=dev)
-        defer.append((part, M, loss_out))
+        defer.append((part, M // 64, M, loss_out))
     if profiler.active:
         flop = sum(a_dims[l] * a_dims[l + 1] for l in range(1, La)) \
             + sum(c_dims[l] * c_dims[l + 1] for l in range(1, Lc))
@@ -956,14 +956,17 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
 
 def policy_loss_finalize(pending: list) -> None:
     """Sum the per-tile loss partials of deferred `policy_bwd_gae_bf16` launches
-    (`mi_policy_loss_finalize_f32`): `pending` = [(partials, T * B, loss_out[4])], cleared."""
+    or `gae_ppo_loss` launches (`mi_policy_loss_finalize_f32`): `pending` = [(partials, rows of
+    partials, T * B, loss_out[4])], cleared."""
     for i in range(0, len(pending), 32):
         chunk = pending[i:i + 32]
         n = len(chunk)
         P = ctypes.c_void_p * n
+        I = ctypes.c_int64 * n
         check(lib().mi_policy_loss_finalize_f32(
-            n, P(*[ptr(c[0], f64) for c in chunk]), (ctypes.c_int64 * n)(*[int(c[1]) for c in chunk]),
-            P(*[ptr(c[2], f32) for c in chunk]), stream()), "mi_policy_loss_finalize_f32")
+            n, P(*[ptr(c[0], f64) for c in chunk]), I(*[int(c[1]) for c in chunk]),
+            I(*[int(c[2]) for c in chunk]), P(*[ptr(c[3], f32) for c in chunk]), stream()),
+            "mi_policy_loss_finalize_f32")
     pending.clear()
 
 
@@ -1070,10 +1073,13 @@ def gae_ppo_loss_supported(T: int, N: int) -> bool:
 
 def gae_ppo_loss(rewards, values, last_value, done, truncated, ll_new, ll_old, reg, gamma: float,
                  lambda_: float, normalize: bool, clip_range: float, critic_weight: float,
-                 loss_out: torch.Tensor | None = None, want_adv: bool = False):
+                 loss_out: torch.Tensor | None = None, want_adv: bool = False,
+                 defer: list | None = None):
     """GAE + advantage statistics + loss terms and gradients in one launch
     (`mi_gae_ppo_loss_f32`).  All operands `[T, N]` (last_value `[N]`), reg may be None.
-    Returns (g_ll [T,N], g_v [T,N], loss_out [4], advantages | None)."""
+    Returns (g_ll [T,N], g_v [T,N], loss_out [4], advantages | None).  `defer` (a list): the
+    four scalars are left as per-workgroup partials and `loss_out` is filled by
+    `policy_loss_finalize(defer)` (same bits)."""
     T, N = rewards.shape
     for t in (values, ll_new, ll_old, done, truncated):
         _need(t.shape == (T, N), "gae_ppo_loss: operands must be [T, N]")
@@ -1086,12 +1092,18 @@ def gae_ppo_loss(rewards, values, last_value, done, truncated, ll_new, ll_old, r
     if loss_out is None:
         loss_out = torch.empty(4, dtype=f32, device=dev)
     ws = workspace(dev, "gae_loss", lib().mi_gae_ppo_loss_workspace_bytes(), zeroed=True)
+    part = None
+    if defer is not None:
+        rows = (N + 63) // 64
+        part = torch.empty(rows * 4, dtype=f64, device=dev)
+        defer.append((part, rows, T * N, loss_out))
     check(lib().mi_gae_ppo_loss_f32(
         ptr(rewards, f32), ptr(values, f32), ptr(last_value, f32), ptr(_as_u8(done), u8),
         ptr(_as_u8(truncated), u8), ptr(ll_new, f32), ptr(ll_old, f32), ptr(reg, f32),
         float(gamma), float(lambda_), int(bool(normalize)), float(clip_range),
         float(critic_weight), ptr(adv, f32), None, ptr(g_ll, f32), ptr(g_v, f32),
-        ptr(loss_out, f32), ptr(ws), T, N, stream()), "mi_gae_ppo_loss_f32")
+        None if part is not None else ptr(loss_out, f32), ptr(part, f64), ptr(ws), T, N,
+        stream()), "mi_gae_ppo_loss_f32")
     return g_ll, g_v, loss_out, adv
 
 

@@ -161,6 +161,17 @@ def test_fused_gae_loss_equals_two_launches(dev, T, N, normalize, with_reg):
         assert torch.equal(g_ll.reshape(-1), g_ll0), float((g_ll.reshape(-1) - g_ll0).abs().max())
         assert torch.equal(g_v.reshape(-1), g_v0)
         assert torch.allclose(lo, lo0, rtol=1e-6, atol=1e-7), (lo, lo0)
+        # deferred: the launch leaves its per-workgroup partials, mi_policy_loss_finalize_f32
+        # sums them later in the same order — the same bits as the sum at the launch's tail
+        pending: list = []
+        lo_d = torch.full((4,), float("nan"), device=dev)
+        g_ll2, g_v2, lo_d2, _ = ops.gae_ppo_loss(r, v, lv, done, trunc, ll_new, ll_old, reg, 0.99,
+                                                 0.95, normalize, 0.2, 0.7, loss_out=lo_d,
+                                                 defer=pending)
+        assert lo_d2 is lo_d and len(pending) == 1
+        ops.policy_loss_finalize(pending)
+        assert not pending and torch.equal(lo_d, lo)
+        assert torch.equal(g_ll2, g_ll) and torch.equal(g_v2, g_v)
     assert not ops.gae_ppo_loss_supported(33, 64) and not ops.gae_ppo_loss_supported(8, 16385)
 
 
