@@ -363,6 +363,72 @@ def train_ppo_throughput(device, compute: str, iterations: int = 45):
                     "first 5 iterations (eager + capture) dropped"}
 
 
+def _self_launch(args) -> int:
+    """`python3 bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks
+    here, BEFORE anything in this process touches the GPU (a process that has initialised
+    HIP must never be replaced or forked into GPU work).  One child per GPU with the
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment `torch.distributed.run` would
+    give it; rank 0's stdout (the ONE JSON line) is relayed, every child's stderr is
+    inherited, and the exit code is non-zero if any rank's is.  A rank that fails takes
+    the others down (their exact PIDs) instead of leaving them in a collective."""
+    import socket
+    import subprocess
+    import tempfile
+
+    n = args.gpus
+    single = os.environ.get("MIPPO_SINGLE_DEVICE") == "1"
+    n_dev = torch.cuda.device_count()  # counts devices without initialising the runtime
+    if n_dev < n and not single:
+        raise SystemExit(
+            f"[bench] --gpus {n} but only {n_dev} GPU(s) are visible.  For a rehearsal of "
+            "the N > 1 path on fewer GPUs (every rank on cuda:0, rendezvous over gloo) set "
+            "MIPPO_SINGLE_DEVICE=1")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL, peer regions)
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    if single:
+        base.setdefault("MIPPO_DIST_BACKEND", "gloo")  # RCCL cannot put two ranks on one GPU
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), MIPPO_SELF_LAUNCHED="1")
+    cmd = [sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]]
+    out0 = tempfile.TemporaryFile(mode="w+")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else sys.stderr))
+    _log(f"self-launched {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    deadline = time.monotonic() + float(os.environ.get("MIPPO_BENCH_TIMEOUT_S", "1500"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = bad or [("timeout", None)]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 15
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(0.2)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    out0.seek(0)
+    text = out0.read()
+    if failed or any(codes):
+        sys.stderr.write(f"[bench] ranks exited with {codes} (first failure: {failed})\n")
+        sys.stderr.write(text)
+        return next((c for c in codes if c), 1) or 1
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,7 +450,14 @@ def main():
                          "auto = oneshot if its self-check against RCCL passes, else rccl")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process only starts the ranks and relays rank 0's line
+        raise SystemExit(_self_launch(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank "
+                         "per GPU (or run `python3 bench.py --gpus N`, which starts them itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal on a one-GPU box: MIPPO_DIST_BACKEND=gloo MIPPO_SINGLE_DEVICE=1 runs the
@@ -395,6 +468,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     transport = "none"
+    oneshot_check = "n/a (one rank)"
     if world > 1:
         import datetime
 
@@ -406,8 +480,11 @@ def main():
                                 timeout=datetime.timedelta(seconds=180), **kw)
         from nnx_ppo_amd import parallel
 
+        oneshot_check = "not attempted (--transport rccl)"
         if args.transport in ("auto", "oneshot"):
             ok, why = parallel.enable_oneshot(device)
+            oneshot_check = "passed (bit-identical to torch.distributed on every rank)" if ok \
+                else f"failed: {why}"
             if not ok:
                 if args.transport == "oneshot":
                     raise SystemExit(f"[bench] one-shot transport unavailable: {why}")
@@ -415,8 +492,6 @@ def main():
                     print(f"[bench] one-shot transport not used ({why}); RCCL collectives "
                           "between graph segments", file=sys.stderr)
         transport = parallel.transport()
-    elif args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
 
     from nnx_ppo_amd import config as mi_config
     from nnx_ppo_amd.algorithms.loop import IterationRunner
@@ -467,6 +542,7 @@ def main():
         # steady-state intervals are host sync to host sync
         iter_ms += [(b - a) * 1e3 for a, b in zip(stamps[1:-1], stamps[2:])]
     metrics = run_window.metrics
+    own_windows = list(windows)  # this rank's own clock, before the MAX over ranks
     wt = torch.tensor(windows, dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
@@ -476,6 +552,27 @@ def main():
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
     windows = [float(x) for x in wt.cpu()]
     elapsed = _pct(windows, 0.5)
+    # one line per rank: what it ran on, how its exchanges travel, its own clock
+    props = torch.cuda.get_device_properties(device)
+    comm = None
+    if world > 1:
+        from nnx_ppo_amd import parallel
+
+        comm = parallel.peer_comm()
+    me = {
+        "rank": rank, "device": str(device), "gpu": props.name,
+        "gcn_arch": getattr(props, "gcnArchName", None),
+        "pid": os.getpid(), "world_seen": world if world == 1 else dist.get_world_size(),
+        "dist_backend": None if world == 1 else dist.get_backend(),
+        "transport": transport, "oneshot_self_check": oneshot_check,
+        "oneshot_timeouts": None if comm is None else comm.status()[1],
+        "ms_per_step_own_clock": round(_pct(own_windows, 0.5) / args.steps * 1e3, 4),
+        "iteration_ms_p50_own_clock": round(_pct(iter_ms, 0.5), 4),
+    }
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     _log(f"timed: median window {elapsed * 1e3:.2f} ms")
     # the same graph replayed back to back, no host read in between (round 1's number)
@@ -504,6 +601,11 @@ def main():
             "steps": args.steps,
             "warmup": warm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "per_gpu": {"value": round(total_env_steps / elapsed / world, 1),
+                        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                        "note": "weak scaling: every GPU runs the N = 1 workload, so this "
+                                "ms_per_step compares directly with the N = 1 line's"},
+            "ranks": ranks,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

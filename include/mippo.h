@@ -753,12 +753,22 @@ int mi_gae_ppo_loss_f32(const float* rewards, const float* values, const float* 
  *   mi_comm_status   synchronise and report (collectives completed, spins that timed out);
  *   mi_comm_destroy  unmap and free.
  * `timeout_seconds` bounds every wait inside a kernel: a peer that never arrives makes
- * the kernel count an error and finish instead of hanging the device. */
+ * the kernel count an error and finish (with NaN / no update, see mi_comm_set_error_word)
+ * instead of hanging the device. */
 int64_t mi_comm_handle_bytes(void);
 int mi_comm_create(int rank, int world, int64_t slot_bytes, double timeout_seconds,
                    void** comm_out, void* handle_out);
 int mi_comm_connect(void* comm, const void* all_handles);
 int mi_comm_status(void* comm, int64_t* seq_out, int64_t* errors_out);
+/* Mirror the sticky timeout count into a caller-owned, zero-initialised 4-byte device word
+ * (NULL: stop mirroring): every kernel launched afterwards adds to it whenever it adds to
+ * the region's own error count, so the caller can copy it to the host together with its
+ * other per-iteration scalars instead of synchronising on mi_comm_status — the training
+ * loop's one host sync per iteration (`ppo.py:209`) then also carries "a peer did not
+ * arrive".  After a timeout the collectives never hand back a partial result: the
+ * all-reduce / all-gather write NaN for the chunk, mi_adam_step_allreduce_f32 applies no
+ * update (this launch and every later one: the count is sticky). */
+int mi_comm_set_error_word(void* comm, void* device_word);
 int64_t mi_comm_slot_bytes(void* comm);
 int mi_comm_destroy(void* comm);
 

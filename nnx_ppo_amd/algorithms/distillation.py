@@ -365,7 +365,9 @@ def _train_distillation(env, teacher, student, config, log_fn, checkpoint_fn, ev
         metrics = loop_metrics
     distillation_state = runner.state
     device_steps = int(distillation_state.steps_taken)
-    assert device_steps == steps, (device_steps, steps)
+    if device_steps != steps:  # the host counted the iterations; the device counted the steps
+        raise RuntimeError(f"the device's step counter ({device_steps}) differs from the "
+                           f"host's count ({steps}): an iteration was lost or ran twice")
     return DistillationTrainResult(
         training_state=distillation_state,
         final_metrics=metrics,

@@ -82,6 +82,13 @@ class MetricPack:
         return out
 
 
+_HEALTH_KEY = "_health/"
+
+
+class InKernelTimeout(RuntimeError):
+    """A bounded wait inside a kernel ran out during this iteration."""
+
+
 class IterationRunner:
     """Runs `fn(state) -> (state, metrics)` once per `launch()`.
 
@@ -107,6 +114,7 @@ class IterationRunner:
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._graph = None
         self._pack: Optional[MetricPack] = None
+        self._health: list = []
         self._n = 0
         self._events: list = [None, None]
         self.launch_mode = "eager"
@@ -116,6 +124,14 @@ class IterationRunner:
         return self._state
 
     def _after(self, metrics: dict) -> None:
+        if self._pack is None:
+            # the sticky timeout words of every bounded in-kernel wait that exists after the
+            # first (eager) iteration ride in the same copy as the metrics: `collect` raises
+            # in the iteration one of them turns non-zero
+            self._health = ops.health_words(self.device) if self.device.type == "cuda" else []
+        metrics = dict(metrics)
+        for i, w in enumerate(self._health):
+            metrics[f"{_HEALTH_KEY}{i}"] = w
         if self._pack is None:
             self._pack = MetricPack(metrics, self.device)
         self._pack.pack(metrics)
@@ -177,7 +193,16 @@ class IterationRunner:
             raise RuntimeError("metrics of an iteration older than the previous one are gone")
         if self.device.type == "cuda":
             self._events[slot].synchronize()
-        return self._pack.decode(slot)
+        metrics = self._pack.decode(slot)
+        bad = sum(int(metrics.pop(k)) for k in list(metrics) if k.startswith(_HEALTH_KEY))
+        if bad:
+            raise InKernelTimeout(
+                f"iteration {ticket}: {bad} bounded in-kernel wait(s) ran out (an advantage-"
+                "statistics hand-over between the workgroups of mi_policy_ws_bwd_gae_bf16 / "
+                "mi_gae_ppo_loss_f32, or a peer that never delivered its chunk to a one-shot "
+                "exchange).  The step that saw it was poisoned (NaN statistics / no optimiser "
+                "update), nothing after it can be trusted: the run stops here")
+        return metrics
 
 
 def should_run(steps: int, last_step: int, every_steps: int) -> bool:
@@ -189,22 +214,24 @@ def should_run(steps: int, last_step: int, every_steps: int) -> bool:
 
 def health_check(device) -> None:
     """Raise if a bounded in-kernel wait has run out since the last check: a peer that never
-    delivered its chunks to a one-shot exchange (`comm.PeerComm.check`), or a workgroup of the
-    backward-with-GAE launch that never published its statistics partial.  Reads device
-    words (it synchronises), so the loop calls it where it is synchronised anyway — eval,
-    checkpoint, the end of training."""
+    delivered its chunks to a one-shot exchange (`comm.PeerComm.check`), or a workgroup that
+    never published its advantage-statistics partial.  `IterationRunner.collect` already sees
+    the words that existed when its metric pack was built, every iteration; this reads EVERY
+    word (it synchronises), so the loop calls it where it is synchronised anyway — BEFORE an
+    eval, a video or a checkpoint may use the parameters, and at the end of training."""
     from .. import ops, parallel
 
     del device
     comm = parallel.peer_comm()
     if comm is not None:
         comm.check()
-    n = ops.policy_bwd_gae_timeouts()
+    n = ops.handover_timeouts()
     if n:
-        raise RuntimeError(
-            f"{n} advantage-statistics hand-over(s) inside mi_policy_ws_bwd_gae_bf16 timed out: "
-            "a workgroup of the launch was not resident within 2 s (another kernel holding the "
-            "CUs?); MIPPO_GAE_IN_BWD=0 keeps the GAE / loss launch of its own")
+        raise InKernelTimeout(
+            f"{n} advantage-statistics hand-over(s) inside mi_policy_ws_bwd_gae_bf16 / "
+            "mi_gae_ppo_loss_f32 timed out: a workgroup of the launch was not resident within "
+            "2 s (another kernel holding the CUs?); MIPPO_GAE_IN_BWD=0 keeps the GAE / loss "
+            "launch of its own")
 
 
 def run_training_loop(
@@ -249,11 +276,16 @@ def run_training_loop(
         next_ticket = None
         if overlap and more and not (eval_due or video_due or ckpt_due):
             next_ticket = runner.launch()  # iteration i+1 queued behind iteration i
-        metrics = runner.collect(ticket)   # the host sync of iteration i
-        metrics["total_steps"] = steps
+        metrics = runner.collect(ticket)   # the host sync of iteration i (raises on a timeout)
+        # the host's count, as a 0-d tensor like every other logged scalar (the device
+        # counter is checked against it once, at the end of train_*)
+        metrics["total_steps"] = torch.tensor(steps, dtype=torch.int64)
         if measure_throughput:
             now = time.perf_counter()
             metrics["throughput/train_sps"] = local_steps_per_iteration / (now - t_prev)
+        if eval_due or video_due or ckpt_due or not more:
+            # before anything evaluates, renders or SAVES these parameters
+            health_check(runner.device)
         if eval_due:
             eval_metrics = run_eval(steps)
             metrics.update(eval_metrics)
@@ -265,12 +297,15 @@ def run_training_loop(
         if ckpt_due:
             checkpoint_fn(runner.state, steps)
             last_checkpoint_step = steps
-        if eval_due or ckpt_due or not more:
-            health_check(runner.device)
         if log_fn is not None:
             log_fn(metrics, steps)
         if not more:
             break
+        if (eval_due or video_due or ckpt_due) and parallel.transport() == "oneshot":
+            # callbacks often do rank-0-only work (rendering, uploads, file writes); the
+            # one-shot exchange waits for a peer only `MIPPO_COMM_TIMEOUT_S` inside a kernel,
+            # so the ranks meet on the host before any of them launches into it again
+            parallel.host_barrier()
         # the clock of the next iteration starts where this one's was read, so callback
         # time that the GPU spent computing the next iteration is not counted twice
         t_prev = time.perf_counter() if (eval_due or video_due or ckpt_due or not overlap) \

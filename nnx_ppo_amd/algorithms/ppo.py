@@ -187,7 +187,9 @@ def _train_ppo(env, networks, config, log_fn, video_fn, checkpoint_fn, eval_env,
         metrics = loop_metrics
     training_state = runner.state
     device_steps = int(training_state.steps_taken)  # the one host read of the counter
-    assert device_steps == steps, (device_steps, steps)
+    if device_steps != steps:  # the host counted the iterations; the device counted the steps
+        raise RuntimeError(f"the device's step counter ({device_steps}) differs from the "
+                           f"host's count ({steps}): an iteration was lost or ran twice")
     return TrainResult(
         training_state=training_state,
         final_metrics=metrics,

@@ -47,6 +47,11 @@ class PeerComm:
                 raise MippoError("PeerComm: handle exchange returned the wrong size")
             check(lib().mi_comm_connect(self._h, ctypes.create_string_buffer(blob, len(blob))),
                   "mi_comm_connect")
+            # the sticky timeout count, mirrored into a word the training loop copies to the
+            # host with every iteration's metrics (ops.health_words)
+            self.error_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+            check(lib().mi_comm_set_error_word(self._h, ptr(self.error_word)),
+                  "mi_comm_set_error_word")
         dist.barrier(group=group)  # every rank has mapped every peer before anyone launches
 
     # ---- collectives (one launch each; capturable) -------------------------------------
@@ -118,6 +123,7 @@ class PeerComm:
 
     def close(self) -> None:
         if self._h:
+            lib().mi_comm_set_error_word(self._h, None)
             lib().mi_comm_destroy(self._h)
             self._h = ctypes.c_void_p()
 

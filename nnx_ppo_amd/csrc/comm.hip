@@ -48,11 +48,13 @@ struct Comm {                  // host object behind the opaque handle
   char* local;                 // this rank's region
   char* peer[kMaxWorld];       // every rank's region as mapped here (peer[rank] == local)
   bool opened[kMaxWorld];
+  unsigned int* error_word;    // caller-owned device word that mirrors hdr->errors (nullable)
 };
 
 struct CommDev {               // by value in the kernel arguments
   int rank, world;
   int64_t slot_bytes, chunks;
+  unsigned int* error_word;    // nullable: bumped with hdr->errors (mi_comm_set_error_word)
   char* peer[kMaxWorld];
 };
 
@@ -74,6 +76,7 @@ CommDev dev_view(const Comm* c) {
   d.world = c->world;
   d.slot_bytes = c->slot_bytes;
   d.chunks = c->chunks;
+  d.error_word = c->error_word;
   for (int r = 0; r < kMaxWorld; ++r) d.peer[r] = r < c->world ? c->peer[r] : nullptr;
   return d;
 }
@@ -110,10 +113,15 @@ __device__ inline void push_chunk(const CommDev& c, int parity, unsigned int seq
 }
 
 // Wait until every peer has raised this chunk's flag for `seq` (bounded), then make the
-// payload they wrote visible to every wave of the workgroup.
-__device__ inline void wait_chunk(const CommDev& c, CommHeader* hdr, int parity,
+// payload they wrote visible to every wave of the workgroup.  Returns false (to every
+// thread of the workgroup) if a wait ran out — the chunk's slots then hold garbage and the
+// caller must not use them: the all-reduce / all-gather write NaN, the fused optimiser
+// skips the update.  The error is sticky (hdr->errors, mirrored into the caller's error
+// word that travels to the host with every iteration's metrics).
+__device__ inline bool wait_chunk(const CommDev& c, CommHeader* hdr, int parity,
                                   unsigned int seq, int64_t chunk) {
   const int tid = threadIdx.x;
+  int bad = 0;
   if (tid < c.world && tid != c.rank) {
     const unsigned int* flag = reinterpret_cast<const unsigned int*>(
         c.peer[c.rank] + flags_off(c.chunks, c.world, parity, tid)) + chunk;
@@ -123,15 +131,25 @@ __device__ inline void wait_chunk(const CommDev& c, CommHeader* hdr, int parity,
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > limit) {
         atomicAdd(&hdr->errors, 1u);
+        if (c.error_word) atomicAdd(c.error_word, 1u);
+        bad = 1;
         break;
       }
     }
   }
-  __syncthreads();
+  bad = __syncthreads_or(bad);
   // every wave invalidates for itself (an acquire only covers the issuing wave's later
   // loads); system scope: the payload was written by another device
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  return !bad;
 }
+
+template <typename T>
+__device__ inline T poison();
+template <>
+__device__ inline float poison<float>() { return __builtin_nanf(""); }
+template <>
+__device__ inline double poison<double>() { return __builtin_nan(""); }
 
 // The collective counts itself once every block has finished (so a block that starts late
 // still reads the old `seq`).
@@ -156,13 +174,14 @@ allreduce_kernel(CommDev c, T* __restrict__ buf, int64_t n, T scale) {
   const int parity = (int)(seq64 & 1);
   constexpr int kPer = (int)(kChunkBytes / sizeof(T));  // elements per chunk
   const int64_t nchunks = mippo::ceil_div(n, (int64_t)kPer);
+  const bool failed = hdr->errors != 0;  // sticky: after one lost peer nothing is trusted
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t e0 = ch * kPer;
     const int64_t cnt = n - e0 < kPer ? n - e0 : kPer;
     push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(buf + e0), cnt * (int64_t)sizeof(T));
-    wait_chunk(c, hdr, parity, seq, ch);
+    const bool ok = wait_chunk(c, hdr, parity, seq, ch) && !failed;
     for (int64_t i = threadIdx.x; i < cnt; i += kThreads) {
-      T s = T(0);
+      T s = ok ? T(0) : poison<T>();  // a peer never arrived: NaN, never a partial sum
       for (int r = 0; r < c.world; ++r) {  // fixed rank order: identical on every rank
         const T v = r == c.rank
                         ? buf[e0 + i]
@@ -189,13 +208,15 @@ allgather_kernel(CommDev c, const char* __restrict__ src, int64_t nbytes, char* 
     const int64_t b0 = ch * kChunkBytes;
     const int64_t cnt = nbytes - b0 < kChunkBytes ? nbytes - b0 : kChunkBytes;
     push_chunk(c, parity, seq, ch, src + b0, cnt);
-    wait_chunk(c, hdr, parity, seq, ch);
+    const bool ok = wait_chunk(c, hdr, parity, seq, ch);
     for (int r = 0; r < c.world; ++r) {
       const char* from = r == c.rank
                              ? src + b0
                              : c.peer[c.rank] +
                                    slot_off(c.chunks, c.world, c.slot_bytes, parity, r) + b0;
-      for (int64_t i = threadIdx.x; i < cnt; i += kThreads) dst[(int64_t)r * nbytes + b0 + i] = from[i];
+      // a peer never arrived: all-ones bytes (NaN as fp32 / fp64) instead of its stale slot
+      for (int64_t i = threadIdx.x; i < cnt; i += kThreads)
+        dst[(int64_t)r * nbytes + b0 + i] = (ok || r == c.rank) ? from[i] : (char)0xFF;
     }
     __syncthreads();
   }
@@ -215,12 +236,16 @@ adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
   constexpr int kPer = (int)(kChunkBytes / sizeof(float));  // 1024 elements = 4 passes of 256
   const int64_t nchunks = mippo::ceil_div(a.n, (int64_t)kPer);
   const float inv_world = 1.0f / (float)c.world;
+  // Sticky: once a peer has failed to arrive (this launch or an earlier one) no update is
+  // applied any more — parameters, moments and bf16 images keep their last good values and
+  // the error word stops the run at this iteration's host sync (loop.IterationRunner.collect)
+  const bool failed = hdr->errors != 0;
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t e0 = ch * kPer;
     const int64_t cnt = a.n - e0 < kPer ? a.n - e0 : kPer;
     push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(a.g + e0), cnt * 4);
-    wait_chunk(c, hdr, parity, seq, ch);
-    for (int64_t pass = 0; pass < cnt; pass += kThreads) {
+    const bool ok = wait_chunk(c, hdr, parity, seq, ch) && !failed;
+    for (int64_t pass = 0; pass < cnt && ok; pass += kThreads) {
       const int64_t i = e0 + pass + threadIdx.x;
       if (i < a.n && pass + threadIdx.x < cnt) {
         float s = 0.0f;
@@ -271,6 +296,7 @@ extern "C" int mi_comm_create(int rank, int world, int64_t slot_bytes, double ti
     c->peer[r] = nullptr;
     c->opened[r] = false;
   }
+  c->error_word = nullptr;
   void* p = nullptr;
   // uncached (fine-grained) device memory: peers' stores and this device's loads meet in
   // memory, not in an L2 that the other side cannot see
@@ -351,6 +377,14 @@ extern "C" int mi_comm_status(void* comm, int64_t* seq_out, int64_t* errors_out)
   }
   if (seq_out) *seq_out = (int64_t)h.seq;
   if (errors_out) *errors_out = (int64_t)h.errors;
+  return 0;
+}
+
+extern "C" int mi_comm_set_error_word(void* comm, void* device_word) {
+  MI_REQUIRE(comm, "mi_comm_set_error_word: null comm");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(device_word) & 3) == 0,
+             "mi_comm_set_error_word: the word must be 4-byte aligned");
+  static_cast<Comm*>(comm)->error_word = static_cast<unsigned int*>(device_word);
   return 0;
 }
 

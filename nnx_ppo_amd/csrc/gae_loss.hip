@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kMaxT = 32;
 constexpr int kMaxBlocks = 256;          // N <= 16384
-constexpr int kHeaderBytes = 64;         // [arrive counter | finish ticket | pad]
+constexpr int kHeaderBytes = 64;         // [arrive | finish ticket | sticky timeouts | test hook: us, extra | pad]
 constexpr unsigned long long kSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 
 struct Args {
@@ -121,6 +121,7 @@ gae_loss_kernel(Args a) {
       s_adv[t][tid] = av;
     }
     if (a.normalize) {
+      bool timed_out = false;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_down(s, off, 64);
@@ -134,11 +135,22 @@ gae_loss_kernel(Args a) {
                            __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // header words 3, 4 (zero in production): the test hook of trunk_ws.hip's hand-over
+        const unsigned int hook_us = __builtin_nontemporal_load(arrive + 3);
+        const unsigned int hook_extra = __builtin_nontemporal_load(arrive + 4);
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-               (unsigned)G) {
+               (unsigned)G + hook_extra) {
           __builtin_amdgcn_s_sleep(1);
-          if (wall_clock64() - t0 > kSpinTicks) break;  // never in a healthy launch
+          const unsigned long long limit =
+              hook_us ? (unsigned long long)hook_us * 100ull : kSpinTicks;
+          if (wall_clock64() - t0 > limit) {  // never in a healthy launch
+            // sticky word 2 of the header, read with the iteration's metrics
+            // (ops.health_words) and by loop.health_check
+            __hip_atomic_fetch_add(arrive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            timed_out = true;
+            break;
+          }
         }
       }
       // acquire only (invalidate; nothing of this wave needs writing back here): the
@@ -167,7 +179,8 @@ gae_loss_kernel(Args a) {
         const double m = t1 / cnt;
         double var = t2 / cnt - m * m;
         if (var < 0.0) var = 0.0;
-        s_norm[0] = (float)m;
+        // incomplete partials after a timed-out hand-over: poison the normalisation
+        s_norm[0] = timed_out ? __builtin_nanf("") : (float)m;
         s_norm[1] = (float)sqrt(var) + 1e-8f;
       }
     }

@@ -816,7 +816,9 @@ struct WsGae {
   double* part;                                // workspace: [ntiles][4] partial sums
   double* sp;                                  // workspace: [groups][2] statistics partials
   unsigned int *ticket, *arrive;               // workspace header (zero between launches);
-                                               // arrive[1]: sticky count of timed-out waits
+                                               // arrive[1]: sticky count of timed-out waits;
+                                               // arrive[2], [3]: test hook (spin limit in us,
+                                               // extra arrivals), zero in production
   int T, B;
   float gamma, lambda, clip, critic_weight;
   int normalize;
@@ -1073,16 +1075,26 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
     if (SAMP && g.normalize) {
       float* const s_norm = reinterpret_cast<float*>(gsm + WsGaeLds::norm);
       if (wave == 0) {
+        bool timed_out = false;
         if (lane == 0) {
+          // header words 3, 4 (zero in production): a spin limit in microseconds and a number
+          // of arrivals to wait for beyond the real ones — the test hook that forces the
+          // timeout branch (ops.set_handover_test_hook); requested with the first poll
+          const unsigned int hook_us = __builtin_nontemporal_load(g.arrive + 2);
+          const unsigned int hook_extra = __builtin_nontemporal_load(g.arrive + 3);
           const unsigned long long t0 = wall_clock64();
           while (__hip_atomic_load(g.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                 (unsigned)GB) {
+                 (unsigned)GB + hook_extra) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > kGaeSpinTicks) {  // never in a healthy launch
-              // sticky word the host reads at its next synchronisation point
-              // (ops.policy_bwd_gae_timeouts, loop.health_check): the statistics are wrong
+            const unsigned long long limit =
+                hook_us ? (unsigned long long)hook_us * 100ull : kGaeSpinTicks;
+            if (wall_clock64() - t0 > limit) {  // never in a healthy launch
+              // sticky word: it travels to the host with the iteration's metrics
+              // (ops.health_words -> loop.MetricPack; IterationRunner.collect raises in the
+              // iteration it happens) and is read again by loop.health_check
               __hip_atomic_fetch_add(g.arrive + 1, 1u, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
+              timed_out = true;
               break;
             }
           }
@@ -1105,7 +1117,9 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           const double m = t1 / cnt;
           double var = t2 / cnt - m * m;
           if (var < 0.0) var = 0.0;
-          s_norm[0] = (float)m;
+          // a hand-over that ran out has incomplete partials: poison the normalisation so
+          // that a missed host check cannot train on wrong statistics silently
+          s_norm[0] = timed_out ? __builtin_nanf("") : (float)m;
           s_norm[1] = (float)sqrt(var) + 1e-8f;
         }
       }

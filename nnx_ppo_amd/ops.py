@@ -970,17 +970,63 @@ def policy_loss_finalize(pending: list) -> None:
     pending.clear()
 
 
-def policy_bwd_gae_timeouts() -> int:
-    """How many bounded in-kernel waits of `mi_policy_ws_bwd_gae_bf16` (the advantage-statistics
-    hand-over between its workgroups) have run out since the workspaces were created.  Reads
-    device words (it synchronises): the training loop calls it where it is synchronised
-    anyway (`algorithms/loop.py:health_check`).  Non-zero = some gradient step normalised its
-    advantages with incomplete statistics."""
+# workspaces whose header carries a sticky count of timed-out in-kernel hand-overs (header
+# word 2) and the test hook (words 3, 4): csrc/trunk_ws.hip policy_ws_bwd_gae_kernel,
+# csrc/gae_loss.hip gae_loss_kernel
+_HANDOVER_TAGS = ("policy_bwd_gae", "gae_loss")
+
+
+def health_words(device=None) -> list:
+    """One 1-element int32 view per sticky timeout word that exists on `device` (all devices
+    if None): the advantage-statistics hand-overs of `mi_policy_ws_bwd_gae_bf16` and
+    `mi_gae_ppo_loss_f32`, and the one-shot peer exchange's error word.  The training loop
+    copies them to the host with every iteration's metrics (`loop.MetricPack`) and raises in
+    the iteration a word turns non-zero."""
+    out = []
+    for key, ws in _workspaces.items():
+        if key[2] in _HANDOVER_TAGS and (device is None or key[0] == str(device)):
+            out.append(ws[8:12].view(torch.int32))
+    from . import parallel
+
+    comm = parallel.peer_comm()
+    if comm is not None and (device is None or str(comm.device) == str(device)):
+        out.append(comm.error_word)
+    return out
+
+
+def handover_timeouts() -> int:
+    """How many bounded in-kernel waits of the advantage-statistics hand-overs
+    (`mi_policy_ws_bwd_gae_bf16`, `mi_gae_ppo_loss_f32`) have run out since the workspaces
+    were created.  Reads device words (it synchronises).  Non-zero = some gradient step saw
+    incomplete statistics (the kernels poison that step's normalisation with NaN)."""
     total = 0
     for key, ws in _workspaces.items():
-        if key[2] == "policy_bwd_gae":
+        if key[2] in _HANDOVER_TAGS:
             total += int(ws[8:12].view(torch.int32).item())
     return total
+
+
+policy_bwd_gae_timeouts = handover_timeouts  # round-2 name
+
+
+def set_handover_test_hook(limit_us: int = 0, extra_arrivals: int = 0) -> int:
+    """TEST HOOK.  Make the hand-over waits of every existing workspace give up after
+    `limit_us` microseconds and wait for `extra_arrivals` arrivals that never come (0, 0
+    restores production behaviour: 2 s, none).  Returns the number of workspaces touched."""
+    n = 0
+    for key, ws in _workspaces.items():
+        if key[2] in _HANDOVER_TAGS:
+            ws[12:20].view(torch.int32).copy_(
+                torch.tensor([int(limit_us), int(extra_arrivals)], dtype=torch.int32))
+            n += 1
+    return n
+
+
+def clear_handover_timeouts() -> None:
+    """TEST HOOK: zero the sticky words (after a test that forced a timeout)."""
+    for key, ws in _workspaces.items():
+        if key[2] in _HANDOVER_TAGS:
+            ws[8:12].zero_()
 
 
 def mlp_ws_bwd_dx_bf16(g_out: torch.Tensor, w_bfs: list, dims: list, acts: list, auxs: list):

@@ -126,6 +126,12 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def host_barrier() -> None:
+    """Host-side rendezvous of all ranks (no-op without a process group)."""
+    if is_distributed():
+        dist.barrier()
+
+
 def chan_merge(stats_list: list[torch.Tensor]) -> torch.Tensor:
     """Merge per-shard `[3, F]` = (n, mean, M2) statistics pairwise in list order
     (Chan et al.; the same formula as `normalizer.py:118-133`)."""
