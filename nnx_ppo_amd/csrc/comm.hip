@@ -174,12 +174,17 @@ allreduce_kernel(CommDev c, T* __restrict__ buf, int64_t n, T scale) {
   const int parity = (int)(seq64 & 1);
   constexpr int kPer = (int)(kChunkBytes / sizeof(T));  // elements per chunk
   const int64_t nchunks = mippo::ceil_div(n, (int64_t)kPer);
-  const bool failed = hdr->errors != 0;  // sticky: after one lost peer nothing is trusted
+  // Sticky: after one lost peer this rank neither pushes nor waits any more (it would run
+  // ahead of the two-parity protocol and overwrite slots a late peer is still reading) and
+  // hands back NaN; its peers then time out on IT, so the failure reaches every rank
+  const bool failed = hdr->errors != 0;
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t e0 = ch * kPer;
     const int64_t cnt = n - e0 < kPer ? n - e0 : kPer;
-    push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(buf + e0), cnt * (int64_t)sizeof(T));
-    const bool ok = wait_chunk(c, hdr, parity, seq, ch) && !failed;
+    if (!failed)
+      push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(buf + e0),
+                 cnt * (int64_t)sizeof(T));
+    const bool ok = !failed && wait_chunk(c, hdr, parity, seq, ch);  // lost peer: no more waits
     for (int64_t i = threadIdx.x; i < cnt; i += kThreads) {
       T s = ok ? T(0) : poison<T>();  // a peer never arrived: NaN, never a partial sum
       for (int r = 0; r < c.world; ++r) {  // fixed rank order: identical on every rank
@@ -204,11 +209,12 @@ allgather_kernel(CommDev c, const char* __restrict__ src, int64_t nbytes, char* 
   const unsigned int seq = (unsigned int)seq64;
   const int parity = (int)(seq64 & 1);
   const int64_t nchunks = mippo::ceil_div(nbytes, kChunkBytes);
+  const bool failed = hdr->errors != 0;
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t b0 = ch * kChunkBytes;
     const int64_t cnt = nbytes - b0 < kChunkBytes ? nbytes - b0 : kChunkBytes;
-    push_chunk(c, parity, seq, ch, src + b0, cnt);
-    const bool ok = wait_chunk(c, hdr, parity, seq, ch);
+    if (!failed) push_chunk(c, parity, seq, ch, src + b0, cnt);
+    const bool ok = !failed && wait_chunk(c, hdr, parity, seq, ch);
     for (int r = 0; r < c.world; ++r) {
       const char* from = r == c.rank
                              ? src + b0
@@ -243,8 +249,8 @@ adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t e0 = ch * kPer;
     const int64_t cnt = a.n - e0 < kPer ? a.n - e0 : kPer;
-    push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(a.g + e0), cnt * 4);
-    const bool ok = wait_chunk(c, hdr, parity, seq, ch) && !failed;
+    if (!failed) push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(a.g + e0), cnt * 4);
+    const bool ok = !failed && wait_chunk(c, hdr, parity, seq, ch);  // lost peer: no more waits
     for (int64_t pass = 0; pass < cnt && ok; pass += kThreads) {
       const int64_t i = e0 + pass + threadIdx.x;
       if (i < a.n && pass + threadIdx.x < cnt) {

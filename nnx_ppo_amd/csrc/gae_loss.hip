@@ -180,8 +180,11 @@ gae_loss_kernel(Args a) {
         double var = t2 / cnt - m * m;
         if (var < 0.0) var = 0.0;
         // incomplete partials after a timed-out hand-over: poison the normalisation
-        s_norm[0] = timed_out ? __builtin_nanf("") : (float)m;
-        s_norm[1] = (float)sqrt(var) + 1e-8f;
+        s_norm[0] = (float)m;
+        // (a zero denominator, not a NaN mean: the surrogate's `c1 <= c2` select would turn a
+        // NaN advantage into a ZERO gradient; +-inf advantages go through it and reach the
+        // parameters as NaN)
+        s_norm[1] = timed_out ? 0.0f : (float)sqrt(var) + 1e-8f;
       }
     }
   }

@@ -1119,8 +1119,11 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           if (var < 0.0) var = 0.0;
           // a hand-over that ran out has incomplete partials: poison the normalisation so
           // that a missed host check cannot train on wrong statistics silently
-          s_norm[0] = timed_out ? __builtin_nanf("") : (float)m;
-          s_norm[1] = (float)sqrt(var) + 1e-8f;
+          s_norm[0] = (float)m;
+          // (a zero denominator, not a NaN mean: the surrogate's `c1 <= c2` select would turn a
+          // NaN advantage into a ZERO gradient; +-inf advantages go through it and reach the
+          // parameters as NaN)
+          s_norm[1] = timed_out ? 0.0f : (float)sqrt(var) + 1e-8f;
         }
       }
       __syncthreads();

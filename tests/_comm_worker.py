@@ -201,8 +201,25 @@ def scenario_timeout(rank, world, dev, comm, out_dir):
             assert "timed out" in str(exc)
         else:
             raise AssertionError("check() did not raise")
+        # never a partial sum: the chunk whose peer did not arrive comes back as NaN, and
+        # the count is mirrored into the word the training loop reads every iteration
+        assert bool(torch.isnan(x).all()), x[:4]
+        assert int(comm.error_word.item()) == err
+        from nnx_ppo_amd import ops
+        assert any(w.data_ptr() == comm.error_word.data_ptr() for w in ops.health_words(dev))
+        # sticky: the fused optimiser applies no update once a peer has been lost
+        n = 5000
+        p, m, v = (torch.full((n,), c, device=dev) for c in (1.0, 0.5, 0.25))
+        g = torch.ones(n, device=dev)
+        step = torch.full((1,), 4, dtype=torch.int64, device=dev)
+        assert comm.adam_step_allreduce(p, g, m, v, step, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8,
+                                        weight_decay=0.0, shadows=[])
+        torch.cuda.synchronize()
+        assert float(p.min()) == float(p.max()) == 1.0
+        assert float(m.min()) == float(m.max()) == 0.5
+        assert float(v.min()) == float(v.max()) == 0.25
     else:
-        time.sleep(4.0)
+        time.sleep(9.0)
 
 
 def scenario_sharded_ppo(rank, world, dev, comm, out_dir):
