@@ -51,7 +51,7 @@ FWD_FLOP_PER_SAMPLE = 2 * (OBS * 64 + 3 * 64 * 64 + 64 * 2 * ACT + OBS * 256 + 2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16
 PEAK_HBM_GBPS = 8000.0          # HBM3E, MI355X_MICROARCH.md
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"  # HBM bytes per launch from the PMC passes
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"  # HBM bytes per launch from the PMC passes
 
 
 # symbol -> (M, K, N) from the integer arguments of a recorded call (in call order;
@@ -205,10 +205,21 @@ def roofline_of_dominant_kernel(env, ts):
         "flop_per_iter": flops,
         "note": "every dense launch (trunk fwd, dX chain, dW): SURVEY 8(d)'s 2*M*K*N count",
     }
-    traffic_db = {}
-    pmc = Path(__file__).resolve().parent / "profiles" / PMC_TRAFFIC_FILE
+    traffic_db, traffic_meta = {}, {}
+    prof_dir = Path(__file__).resolve().parent / "profiles"
+    # the newest traffic file (rNN_pmc_traffic.json), unless the named one exists
+    pmc = prof_dir / PMC_TRAFFIC_FILE
+    if not pmc.exists():
+        older = sorted(prof_dir.glob("r*_pmc_traffic.json"))
+        pmc = older[-1] if older else pmc
     if pmc.exists():
-        traffic_db = json.loads(pmc.read_text()).get("kernels", {})
+        traffic_meta = json.loads(pmc.read_text())
+        traffic_db = traffic_meta.get("kernels", {})
+    from nnx_ppo_amd.csrc.build import source_signature
+
+    sig_now = source_signature()
+    sig_file = traffic_meta.get("kernel_signature")
+    traffic_stale = sig_file != sig_now  # a file without a signature is stale by definition
     trunk = {k: v for k, v in classes.items()
              if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel",
                               "trunk_ws_", "policy_ws_", "tn_gemm_dw", "dW group"))}
@@ -231,8 +242,13 @@ def roofline_of_dominant_kernel(env, ts):
             "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5),
             "traffic": None if t is None else t["hbm_bytes_per_launch"],
             "traffic_source": None if t is None else
-            f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+            f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
             "this command; FETCH_SIZE x2 on gfx950)",
+            # the PMC passes are a separate run: this says whether they were taken on the
+            # kernels that are being timed now (sha256 over csrc/ + include/)
+            "traffic_stale": None if t is None else traffic_stale,
+            "traffic_kernel_signature": sig_file, "kernel_signature": sig_now,
+            "traffic_git_head": traffic_meta.get("git_head"),
             "launches_per_iter": c["launches"],
             "avg_launch_us": round(c["ms"] / c["launches"] * 1e3, 2),
             "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
@@ -363,6 +379,91 @@ def train_ppo_throughput(device, compute: str, iterations: int = 45):
                     "first 5 iterations (eager + capture) dropped"}
 
 
+# The other single-GPU configs of BASELINE.json (SURVEY 8's C3 and C4), timed for a short
+# window each AFTER the headline measurement and reported under "configs" — the headline
+# `value` / `config` stay C2's.  FLOPs per iteration: SURVEY 8(d) (forward FLOPs per sample x
+# [rollout + n_epochs x (3 x replay + bootstrap)]).
+OTHER_CONFIGS = {
+    "C3": {"n_envs": 8192, "flop_per_iter": 3.069e12,
+           "workload": "BASELINE configs[2]: CheetahRun-shaped dict obs {position 8, velocity "
+                       "9}, act 6, MLP actor 4x256 / critic 2x512, normalize_obs, n_envs=8192"},
+    "C4": {"n_envs": 4096, "flop_per_iter": 2.973e11,
+           "workload": "BASELINE configs[3]: CartpoleBalance-shaped, actor Dense-GRU(64)-Dense "
+                       "/ critic 2x256, carry through rollout + replay, max_steps=5 "
+                       "(reset-on-done on ~20 % of the steps), n_envs=4096"},
+}
+
+
+def build_config(name: str, n_envs: int, device):
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import cartpole_shaped, cheetah_shaped
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    rngs = Rngs(SEED)
+    if name == "C3":
+        env = EpisodeWrapper(cheetah_shaped(max_steps=1000), 1000)
+        net = factories.make_mlp_actor_critic({"position": 8, "velocity": 9}, 6, [256] * 4,
+                                              [512] * 2, rngs)
+    elif name == "C4":
+        env = EpisodeWrapper(cartpole_shaped(max_steps=5), 1000)
+        net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], rngs)
+    else:
+        raise ValueError(name)
+    ts = ppo.new_training_state(env, net, n_envs, SEED, 1e-4, device=device)
+    return env, net, ts
+
+
+def other_configs(device, compute: str, iters: int = 12, windows: int = 3) -> dict:
+    """C3 and C4 by the headline's own definition (train_ppo's loop: one graph launch + one
+    host sync per iteration), `windows` windows of `iters` iterations each, median window."""
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.loop import IterationRunner
+
+    peak = (PEAK_BF16_MFMA_TFLOPS if compute == "bf16" else PEAK_F32_MFMA_TFLOPS) * 1e12
+    out = {}
+    for name, c in OTHER_CONFIGS.items():
+        n = c["n_envs"]
+        env, net, ts = build_config(name, n, device)
+        runner = IterationRunner(
+            lambda st, env=env, n=n: ppo.ppo_step(env, st, n, T, 0.95, 0.99, 0.2, True, False,
+                                                  N_EPOCHS, N_MB), ts)
+
+        def window(k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ticket = runner.launch()
+            for i in range(k):
+                nxt = runner.launch() if i + 1 < k else None
+                m = runner.collect(ticket)
+                ticket = nxt
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, m
+
+        window(3)  # eager, recorded, replayed
+        times = []
+        for _ in range(windows):
+            dt, m = window(iters)
+            times.append(dt)
+        times.sort()
+        dt = times[len(times) // 2]
+        tf = c["flop_per_iter"] * iters / dt
+        out[name] = {
+            "value": round(n * T * iters / dt, 1), "unit": "env-steps/s",
+            "ms_per_step": round(dt / iters * 1e3, 3), "n_envs": n, "steps": iters,
+            "windows": windows, "mfma_tflops": round(tf / 1e12, 1),
+            "mfma_frac": round(tf / peak, 5), "launch_mode": runner.launch_mode,
+            "workload": c["workload"],
+            "final_losses": {k: float(v) for k, v in m.items() if k.startswith("losses/")},
+        }
+        _log(f"  {name}: {out[name]['value'] / 1e6:.2f} M env-steps/s, "
+             f"{out[name]['ms_per_step']} ms/iteration")
+        del runner, ts, env, net
+        torch.cuda.empty_cache()
+    return out
+
+
 def _self_launch(args) -> int:
     """`python3 bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks
     here, BEFORE anything in this process touches the GPU (a process that has initialised
@@ -435,6 +536,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short C3 / C4 windows reported under `configs`")
     ap.add_argument("--no-train-ppo", action="store_true",
                     help="skip the cross-check run of train_ppo itself")
     ap.add_argument("--min-timed-seconds", type=float, default=1.0)
@@ -646,6 +749,9 @@ def main():
         if world == 1 and not args.no_train_ppo and not args.eager:
             _log("train_ppo cross-check")
             line["train_ppo"] = train_ppo_throughput(device, args.compute)
+        if world == 1 and not args.no_other_configs and not args.eager:
+            _log("other configs (C3, C4): short windows, same timing definition")
+            line["configs"] = other_configs(device, args.compute)
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (oracle on the host cores)")
             line["cpu_baseline"] = cpu_baseline()

@@ -56,6 +56,21 @@ def _compile(src: Path, force: bool, hdr_mtime: float) -> Path:
     return obj
 
 
+def source_signature() -> str:
+    """sha256 over every kernel source and header (sorted by name): the identity of the
+    kernels a profile was taken on.  `tools/pmc_summary.py` stamps it into the PMC traffic
+    file; `bench.py` marks `roofline.traffic` stale when it no longer matches."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) +
+                   list((ROOT / "include").glob("*.h")), key=lambda f: f.name)
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, jobs: int | None = None) -> Path:
     OBJ.mkdir(exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))

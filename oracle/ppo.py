@@ -178,8 +178,10 @@ def ppo_loss(networks: Module, network_state, mb: Transition, clip_range, normal
         c2 = torch.clamp(ratio, 1 - clip_range, 1 + clip_range) * ad
         return -torch.mean(torch.minimum(c1, c2))
 
-    actor = sum(_leaves(_map(clipped, ll_new, mb.loglikelihoods, a)))
-    critic = sum(_leaves(_map(lambda v, t: 0.5 * torch.mean((v - t) ** 2), values, target)))
+    actor_tree = _map(clipped, ll_new, mb.loglikelihoods, a)        # ppo.py:494-499
+    critic_tree = _map(lambda v, t: 0.5 * torch.mean((v - t) ** 2), values, target)
+    actor = sum(_leaves(actor_tree))                                # ppo.py:505-507
+    critic = sum(_leaves(critic_tree))
     regl = reg.mean()
     total = actor + critic_loss_weight * critic + regl
     clip_leaves = _leaves(_map(
@@ -188,7 +190,10 @@ def ppo_loss(networks: Module, network_state, mb: Transition, clip_range, normal
     clipfrac = sum(clip_leaves) / len(clip_leaves)
     return total, dict(actor=actor.detach(), critic=critic.detach(),
                        regularization=regl.detach(), clipping_fraction=clipfrac,
-                       advantages=adv, values=det(values), ll_new=det(ll_new))
+                       advantages=adv, values=det(values), ll_new=det(ll_new),
+                       # the trees the reference logs under losses/actor, losses/critic
+                       # (ppo.py:509-513): one entry per policy term / reward key
+                       actor_tree=det(actor_tree), critic_tree=det(critic_tree))
 
 
 # ------------------------------------------------------------------ optimiser
@@ -273,6 +278,7 @@ def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discoun
     rows_out = {k: [] for k in ("actor", "critic", "regularization", "clipping_fraction")}
     diag: dict = {"grad_norm": [], "advantages": [], "critic_R^2": []}
     grads_first = None
+    trees: dict = {}
     for i in range(n_epochs * n_minibatches):
         inds = minibatch_inds[i]
         mb = Transition(**{k: _tmap(lambda x: x[:, inds], v) for k, v in ro.__dict__.items()})
@@ -293,11 +299,15 @@ def ppo_step(env, ts: TrainingState, n_envs, rollout_length, gae_lambda, discoun
         ts.optimizer.update(grads)
         for k in rows_out:
             rows_out[k].append(lm[k])
+        for k in ("actor_tree", "critic_tree"):
+            trees.setdefault(k, []).append(lm[k])
     networks.update_statistics(ro.rollout_extras)  # ppo.py:336 — after all updates
     new = TrainingState(networks, next_net, next_env, ts.optimizer, new_key,
                         ts.steps_taken + rollout_length * n_envs)
     info = {k: torch.stack(v) for k, v in rows_out.items()}
     info["rollout"] = ro
+    for k, v in trees.items():  # stacked over the gradient steps, per key
+        info[k] = _map(lambda *xs: torch.stack(xs), v[0], *v[1:])
     for k, v in diag.items():  # rows behind GRAD_NORM / CRITIC_EXTRA (ppo.py:313-315,520-528)
         if v:
             info[k] = torch.stack(v)

@@ -93,6 +93,15 @@ def test_pytree_loss_vs_oracle(dev, combine, joint, normalize):
                                else 2), ks
             got, want = sum(m[k].item() for k in ks), info[name].numpy().mean()
             assert np.isfinite(got) and np.allclose(got, want, rtol=2e-3, atol=2e-5), (k, name)
+            # ... and each key's own entry against the oracle's tree of the same term
+            tree = info.get(f"{name}_tree")
+            if isinstance(tree, dict):
+                assert {f"losses/{name}/{key}/mean" for key in tree} == set(ks), (ks, list(tree))
+                for key, rows in tree.items():
+                    for stat, want_k in (("mean", rows.numpy().mean()), ("std", rows.numpy().std())):
+                        got_k = m[f"losses/{name}/{key}/{stat}"].item()
+                        assert np.allclose(got_k, want_k, rtol=2e-3, atol=2e-5), \
+                            (name, key, stat, got_k, want_k)
     for p, q in zip(net.parameters(), onet.parameters()):
         assert torch.isfinite(p.data).all()
         assert float((p.data.cpu() - q.detach()).abs().max()) < 5e-4

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the judged artifacts of one build on a GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh <tag>
+#   GIT_HEAD=$(git rev-parse --short HEAD) gpurun ... "GIT_HEAD=$GIT_HEAD tools/collect_profiles.sh <tag>"
 # -> gpurun_out/<tag>/{bench.json, stats/, fetch/, write/, kernel_stats.csv, pmc_traffic.json}
 # Kernel timing and PMC counters are separate rocprofv3 runs, and FETCH_SIZE / WRITE_SIZE
 # separate passes (MI355X_MICROARCH.md, rocprofv3 PMC slots).

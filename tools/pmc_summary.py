@@ -45,7 +45,22 @@ def main():
             "write_bytes_per_launch": round(w_kib * 1024),
             "hbm_bytes_per_launch": round(2.0 * f_kib * 1024 + w_kib * 1024),
         }
-    json.dump({"_note": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), KiB -> bytes; "
+    import os
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    from nnx_ppo_amd.csrc.build import source_signature
+
+    # the GPU box has no .git: the caller exports GIT_HEAD (tools/collect_profiles.sh)
+    head = os.environ.get("GIT_HEAD")
+    if not head:
+        r = subprocess.run(["git", "-C", str(root), "rev-parse", "--short", "HEAD"],
+                           capture_output=True, text=True)
+        head = r.stdout.strip() if r.returncode == 0 else None
+    json.dump({"git_head": head, "kernel_signature": source_signature(),
+               "_note": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), KiB -> bytes; "
                         "separate --pmc passes; Infinity-Cache hits are counted",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
