@@ -728,6 +728,45 @@ int mi_gae_ppo_loss_f32(const float* rewards, const float* values, const float* 
  * at its tail; mi_policy_loss_finalize_f32 (n_partials = ceil(N / 64), n_elements = T * N)
  * sums them later, in the same order. */
 
+/* ---- a6 / a7 / a18: the whole rollout of a device-steppable env in ONE launch ---------- */
+
+/* `unroll_env` (`rollout.py:48-73`) for EpisodeWrapper(MockEnv) (`episode_wrapper.py:7-39`
+ * around `test_dummies/mock_env.py:25-63`) and the fused MLP actor-critic of
+ * `factories.py:88-146`: T x {`single_transition` (`rollout.py:11-45`): network forward
+ * (normaliser `normalizer.py:63-96`, Dense trunks `feedforward.py:42-51`, sampler
+ * `sampling_layers.py:82-147`, adapter `adapter.py:75-117`) -> env.step -> EpisodeWrapper
+ * counter / truncation / done -> record -> reset-on-done select (`tree_where`,
+ * `rollout.py:270-279`, with env.reset(split(reset_key, (T, N))[t][n]), `rollout.py:57-59`)}.
+ * A workgroup owns a 32-env tile for all T steps (envs never interact: `rollout.py:21,39`
+ * vmaps over them); weights stay in registers, env state in LDS, every Transition leaf goes
+ * straight into its time-major [T, N, ...] buffer (`rollout.py:61-66`).  Replaces 2 T + 2
+ * launches of the stepwise form (mi_policy_ws_fwd_bf16 + mi_mock_episode_step_select per
+ * step, the batched reset, mi_stack_multi) and is BIT-IDENTICAL to it in every leaf.
+ *   env state in (read only; [N] int64 / [N][K0] fp32): MockEnv key and step count, the
+ *     wrapper's step counter, the current observation; reset_key: DEVICE scalar;
+ *   network: as mi_policy_ws_fwd_bf16 (trunk pairs of mi_rollout_mock_ws_supported);
+ *     step t draws its noise at offset_add + t;
+ *   Transition out: obs / next_obs [T][N][K0], reward [T][N], done / truncated [T][N] (0/1
+ *     bytes), raw action / action / mu / sigma [T][N][A] (mu, sigma nullable), log-likelihood
+ *     [T][N], value [T][N][N_value];
+ *   final state out (reset select applied; must NOT alias the inputs): key, step count,
+ *     step counter, obs, reward (0 where the last step ended an episode, else 1). */
+int mi_rollout_mock_ws_supported(int64_t La, const int64_t* a_dims, const int64_t* a_acts,
+                                 int64_t Lc, const int64_t* c_dims, const int64_t* c_acts);
+int mi_rollout_mock_ws_bf16(
+    const int64_t* env_key, const int64_t* env_step_count, const int64_t* wrap_step_counter,
+    const float* obs0, const int64_t* reset_key, int64_t max_steps, int64_t max_len, int64_t T,
+    int64_t N, const float* norm_mean, const float* norm_m2, const float* norm_count,
+    float norm_eps, int64_t La, const void* const* a_w, const float* const* a_bias,
+    const int64_t* a_dims, const int64_t* a_acts, int64_t Lc, const void* const* c_w,
+    const float* const* c_bias, const int64_t* c_dims, const int64_t* c_acts,
+    const uint64_t* rng_state, uint64_t offset_add, float min_std, float std_scale,
+    float entropy_weight, int deterministic, float* obs_seq, float* next_obs_seq,
+    float* reward_seq, uint8_t* done_seq, uint8_t* trunc_seq, float* raw_seq, float* action_seq,
+    float* loglik_seq, float* mu_seq, float* sigma_seq, float* value_seq, int64_t* env_key_out,
+    int64_t* env_step_count_out, int64_t* wrap_step_counter_out, float* obs_out,
+    float* reward_out, mi_stream_t stream);
+
 /* ---- e: one-shot peer exchange (new; the reference is single-device) -------- */
 
 /* Env-sharded data parallelism (BASELINE.json north_star): one process per

@@ -138,6 +138,14 @@ def unroll_env(env, env_state, networks: StatefulModule, network_state, unroll_l
                rng_key_for_env_reset: torch.Tensor):
     """rollout.py:48-73 — returns (final_network_state, final_env_state, Transition
     with time-major `[T, N, ...]` leaves)."""
+    # a network / env pair that can run the whole scan in one launch (networks/policy.py:
+    # MLPActorCritic.unroll_fused over EpisodeWrapper(MockEnv)) — every leaf bit-identical to
+    # the steps below
+    fused = getattr(networks, "unroll_fused", None)
+    if fused is not None:
+        res = fused(env, env_state, network_state, unroll_length, rng_key_for_env_reset)
+        if res is not None:
+            return res
     batch_size = env_state.done.shape[0]
     keys = rnd.split(rng_key_for_env_reset, (unroll_length, batch_size))
     # The reset state of step t is a function of keys[t] alone (rollout.py:57-59

@@ -1,0 +1,492 @@
+// a6 / a7 / a18 — the WHOLE rollout of a device-steppable env in ONE launch.
+//
+// `unroll_env` (nnx_ppo/algorithms/rollout.py:48-73) scans `single_transition` (rollout.py:11-45)
+// T times: network forward -> env.step -> record the Transition -> reset-on-done select of env
+// state and carry.  The stepwise form of this package is two launches per step (policy step:
+// trunk_ws.hip policy_ws_dual_kernel; env step + EpisodeWrapper + reset select:
+// misc.hip episode_select_kernel), i.e. 60 dependent launches of 5-7 us for T = 30 — 0.38 ms,
+// a fifth of BASELINE C2's iteration — plus one launch for all T x N reset states and one to
+// stack the per-step leaves.  But envs are row-independent (rollout.py:21,39 vmaps over them),
+// so nothing in a rollout crosses rows: a workgroup can own a 32-row tile of envs for ALL T
+// steps.  Here
+//   * the trunk's weight fragments are loaded ONCE and stay in registers for the T steps
+//     (the stepwise launch spends ~40 % of its life on that prologue, every step);
+//   * the env state of the tile (MockEnv key + step count, the wrapper's step counter, the
+//     observation) lives in LDS / registers between steps; the step, the wrapper's counter /
+//     truncation / done arithmetic and the reset-on-done select are evaluated by the threads
+//     that stage the next observation — between the input stage and the first barrier of the
+//     trunk, i.e. beside the MFMAs, with no barrier of their own;
+//   * the reset state of (step t, env n) is a function of the reset key alone
+//     (rollout.py:57-59: keys[t][n] = split(reset_key, (T, N))[t][n]); it is derived where a
+//     done flag asks for it instead of for all T x N up front;
+//   * every Transition leaf is written straight into its [T, N, ...] buffer (rollout.py:61-66).
+// As in policy_ws_dual_kernel, value-trunk workgroups and action-trunk (+ sampler) workgroups
+// run side by side; both step the env of their tile (integer hashing: cheaper than handing the
+// observation over), the action-trunk workgroup writes the env's Transition leaves and the
+// final state.  That needs an env whose step does not read the action — true of the synthetic
+// benchmark env (test_dummies/mock_env.py:25-63 ignores it), which is the only env with a
+// device-side step so far.
+//
+// Arithmetic: ws_fwd_body's, MFMA for MFMA (same tiles, same k order, same epilogues, the same
+// normaliser expression and sampler row function with the step's noise offset), and the env /
+// wrapper / key expressions of keys.hip / misc.hip — every leaf is BIT-IDENTICAL to the stepwise
+// rollout (tests/test_rollout_fused_gpu.py), so the dispatch in algorithms/rollout.py is
+// invisible.
+#include "keys_common.h"
+#include "trunk_ws_fwd.h"
+
+namespace {
+
+using mippo_keys::kGolden;
+using mippo_keys::kM2;
+using mippo_keys::mix;
+
+// EpisodeWrapper(MockEnv) — wrappers/episode_wrapper.py, envs/synthetic.py
+struct RolloutEnv {
+  // state at step 0 (read only)
+  const int64_t* key;      // [N] MockEnv data["key"]
+  const int64_t* count;    // [N] MockEnv data["step_count"]
+  const int64_t* counter;  // [N] wrapper info["step_counter"]
+  const float* obs;        // [N][K0]
+  const int64_t* reset_key;  // device scalar: rng_key_for_env_reset (rollout.py:54)
+  int64_t max_steps, max_len;
+  int T;
+  int64_t N;
+  // Transition leaves (written by the action-trunk workgroups)
+  float* obs_seq;       // [T][N][K0]
+  float* next_obs_seq;  // [T][N][K0]  (before the reset select, rollout.py:33)
+  float* reward_seq;    // [T][N]
+  uint8_t* done_seq;    // [T][N]
+  uint8_t* trunc_seq;   // [T][N]
+  // state after T steps, reset select applied (rollout.py:41-44)
+  int64_t* key_out;
+  int64_t* count_out;
+  int64_t* counter_out;
+  float* obs_out;     // [N][K0]
+  float* reward_out;  // [N] select(done, reset.reward = 0, stepped.reward = 1)
+};
+
+template <int H, int RT, bool SAMP>
+struct RolloutLds {
+  using F = WsFwdLds<H, RT, SAMP>;
+  static constexpr size_t key = (F::bytes + 15) / 16 * 16;
+  static constexpr size_t count = key + 16 * RT * 8;
+  static constexpr size_t counter = count + 16 * RT * 8;
+  static constexpr size_t bytes = counter + 16 * RT * 8;
+};
+
+// One trunk of the policy for all T steps of the row tiles bid, bid + nblk, ...
+// `c`: the chain as mi_policy_ws_fwd_bf16 fills it for ONE step, except that `c.x` is unused,
+// `c.out` (value trunk: [T][N][N_out], may be null) and the sampler's output pointers
+// ([T][N][A] / [T][N]) address step 0 and advance by N rows per step; `c.M` = N.
+template <int H, int NH, int RT, bool SAMP>
+__device__ __forceinline__ void ws_rollout_body(const WsChain& c, const RolloutEnv& env,
+                                                const int bid, const int nblk,
+                                                unsigned char* smem) {
+  using G = WsGeom<H>;
+  constexpr int CW = G::CW, RW = G::RW, TPW = G::TPW;
+  static_assert(RT % RW == 0 && RT <= 8, "row tiles must split over the row groups");
+  constexpr int RTW = RT / RW;
+  constexpr int ROWS = 16 * RT;
+  constexpr int KSH = H / 32;
+  constexpr int AROW = H + 8;
+  constexpr int XROW = 32 + 8;
+  using Lds = WsFwdLds<H, RT, SAMP>;
+  using RL = RolloutLds<H, RT, SAMP>;
+  bf16_t* const bufX = reinterpret_cast<bf16_t*>(smem + Lds::bufX);
+  bf16_t* const bufA = reinterpret_cast<bf16_t*>(smem + Lds::bufA);
+  bf16_t* const bufB = reinterpret_cast<bf16_t*>(smem + Lds::bufB);
+  int64_t* const s_key = reinterpret_cast<int64_t*>(smem + RL::key);        // [ROWS]
+  int64_t* const s_count = reinterpret_cast<int64_t*>(smem + RL::count);
+  int64_t* const s_counter = reinterpret_cast<int64_t*>(smem + RL::counter);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % CW, wr = wave / CW;
+  const int li = lane & 15, lq = lane >> 4;
+  const int64_t N = env.N;
+  const int T = env.T;
+  const int K0 = c.K0, N_out = c.N_out;
+  const int64_t ntiles = (N + ROWS - 1) / ROWS;
+
+  constexpr int IN_PT = (ROWS * 32 + kWsThreads - 1) / kWsThreads;  // K0 <= 32
+  const int nel = ROWS * K0;
+  const float rcpK0 = 1.0f / (float)K0;
+
+  float* const s_mean = reinterpret_cast<float*>(smem + Lds::mean);
+  float* const s_sd = reinterpret_cast<float*>(smem + Lds::sd);
+  const bool norm = c.norm_mean != nullptr;
+  if (norm && tid < K0) {  // frozen for the whole rollout (ppo.py:336 updates them afterwards)
+    const float cnt = *c.norm_count;
+    s_mean[tid] = c.norm_mean[tid];
+    s_sd[tid] = cnt > 0.0f ? sqrtf(fmaxf(c.norm_m2[tid] / cnt, c.norm_eps)) : 10.0f;
+  }
+  const uint64_t reset_key = (uint64_t)*env.reset_key;
+  const uint64_t span = env.max_len / 2 > 0 ? (uint64_t)(env.max_len / 2) : 0;
+
+  // ---- the trunk, once for all tiles and steps (ws_fwd_body's prologue) --------------------
+  bf16x8 W0[TPW];
+  bf16x8 WH[NH > 0 ? NH : 1][TPW][KSH];
+  f32x4 B0[TPW], BH[NH > 0 ? NH : 1][TPW], BO;
+  bf16_t* const wo_s = reinterpret_cast<bf16_t*>(smem + Lds::wo);
+  if (tid < KSH * 64)
+    *reinterpret_cast<u32x4*>(wo_s + tid * 8) =
+        *reinterpret_cast<const u32x4*>(c.layer[NH + 1].w + tid * 8);
+#pragma unroll
+  for (int b = 0; b < TPW; ++b) {
+    const unsigned ct = (unsigned)(wc + CW * b);
+    W0[b] = ws_frag(c.layer[0].w, ct, 0, 1, lane);
+    B0[b] = c.layer[0].bias
+                ? *reinterpret_cast<const f32x4*>(c.layer[0].bias + ct * 16 + 4 * lq)
+                : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int b = 0; b < TPW; ++b) {
+    const unsigned ct = (unsigned)(wc + CW * b);
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) WH[l][b][ks] = ws_frag(c.layer[1 + l].w, ct, ks, KSH, lane);
+      BH[l][b] = c.layer[1 + l].bias
+                     ? *reinterpret_cast<const f32x4*>(c.layer[1 + l].bias + ct * 16 + 4 * lq)
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  BO = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c.layer[NH + 1].bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * lq + e < N_out) BO[e] = c.layer[NH + 1].bias[4 * lq + e];
+  }
+  for (int row = tid >> 5; row < ROWS; row += kWsThreads >> 5)
+    for (int k = K0 + (tid & 31); k < 32; k += 32) bufX[row * XROW + k] = (bf16_t)0.0f;
+
+  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);  // [ROWS][N_out]
+
+  for (int64_t tile = bid; tile < ntiles; tile += nblk) {
+    const int64_t i0 = tile * ROWS;
+    // ---- the tile's env state at step 0 ---------------------------------------------------
+    if (tid < ROWS) {
+      const int64_t gi = i0 + tid < N ? i0 + tid : N - 1;  // clamped rows are never written out
+      s_key[tid] = env.key[gi];
+      s_count[tid] = env.count[gi];
+      s_counter[tid] = env.counter[gi];
+    }
+    float xin[IN_PT];  // the raw observation elements this thread stages (element e = tid + 512 u)
+#pragma unroll
+    for (int u = 0; u < IN_PT; ++u) {
+      const int e = tid + u * kWsThreads;
+      const int row = (int)(((float)e + 0.5f) * rcpK0);
+      const int64_t gi = i0 + row;
+      xin[u] = (e < nel && gi < N) ? env.obs[gi * K0 + (e - row * K0)] : 0.0f;
+    }
+    __syncthreads();  // s_* (and, first tile, s_mean / s_sd and the pad columns)
+
+    for (int t = 0; t < T; ++t) {
+      const int64_t tN = (int64_t)t * N;
+      // stage 0: the observation -> bf16 in bufX (normalizer.py:76-96); its raw value is the
+      // Transition's `obs` (and the normaliser's rollout extras)
+      // env step of the element's row, in registers (nothing of step t + 1 is published before
+      // the barrier below: every thread still reads the state of step t)
+      float xnext[IN_PT];
+      int64_t nkey = 0, ncount = 0, ncounter = 0;
+      bool owner = false, m_row = false;
+      int owner_row = 0;
+#pragma unroll
+      for (int u = 0; u < IN_PT; ++u) {
+        const int e = tid + u * kWsThreads;
+        xnext[u] = 0.0f;
+        if (e < nel) {
+          const int row = (int)(((float)e + 0.5f) * rcpK0);
+          const int k = e - row * K0;
+          const int64_t gi = i0 + row;
+          const bool live = gi < N;
+          float v = xin[u];
+          if (SAMP && live) env.obs_seq[(tN + gi) * K0 + k] = v;
+          if (norm && live) v = (v - s_mean[k]) / s_sd[k];
+          bufX[row * XROW + k] = (bf16_t)v;
+          if (live) {
+            const int64_t key = s_key[row];
+            const int64_t step = s_count[row] + 1;               // MockEnv.step
+            const bool d = step >= env.max_steps;
+            const int64_t cw = s_counter[row] + 1;               // EpisodeWrapper.step
+            const bool tr = cw >= env.max_len;
+            const bool m = d || tr;
+            float nobs = mippo_keys::mock_obs(key, step, k);
+            if (SAMP) {
+              env.next_obs_seq[(tN + gi) * K0 + k] = nobs;
+              if (k == 0) {
+                env.reward_seq[tN + gi] = 1.0f;
+                env.done_seq[tN + gi] = m ? 1 : 0;
+                env.trunc_seq[tN + gi] = tr ? 1 : 0;
+              }
+            }
+            int64_t k2 = key, s2 = step, c2 = cw;
+            if (m) {
+              // env.reset(keys[t][gi]) — rollout.py:41-44,57-59; EpisodeWrapper.reset:
+              // (base, counter key) = split(rng); MockEnv.reset(base); counter =
+              // randint(counter key, 0, max_len // 2)
+              const uint64_t rk = mix(reset_key + (uint64_t)(tN + gi + 1) * kGolden);
+              const uint64_t base = mix(rk + kGolden);
+              k2 = (int64_t)base;
+              s2 = 0;
+              nobs = mippo_keys::mock_obs(k2, 0, k);
+              if (k == 0) {
+                const uint64_t ck = mix(rk + 2 * kGolden);
+                const uint64_t bits = mix(mix(ck) ^ kM2);
+                c2 = span ? (int64_t)((bits >> 1) % span) : 0;
+              }
+            }
+            xnext[u] = nobs;
+            if (k == 0) {
+              owner = true;
+              owner_row = row;
+              nkey = k2;
+              ncount = s2;
+              ncounter = c2;
+              m_row = m;
+            }
+          }
+        }
+      }
+      __syncthreads();  // bufX staged; every read of the step-t state is done
+      if (owner) {
+        s_key[owner_row] = nkey;
+        s_count[owner_row] = ncount;
+        s_counter[owner_row] = ncounter;
+      }
+
+      f32x4 acc[RTW][TPW];
+      // ---- layer 0 ---------------------------------------------------------------------
+      {
+        bf16x8 af[RTW];
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+          af[r] = *reinterpret_cast<const bf16x8*>(bufX + ((wr * RTW + r) * 16 + li) * XROW + 8 * lq);
+#pragma unroll
+        for (int b = 0; b < TPW; ++b)
+#pragma unroll
+          for (int r = 0; r < RTW; ++r)
+            acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                W0[b], af[r], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+      auto epilogue_hidden = [&](const f32x4(&bias)[TPW], bf16_t* nbuf) {
+#pragma unroll
+        for (int b = 0; b < TPW; ++b) {
+          const int col = (wc + CW * b) * 16 + 4 * lq;
+#pragma unroll
+          for (int r = 0; r < RTW; ++r) {
+            bf16x4 vo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vo[e] = (bf16_t)fmaxf(acc[r][b][e] + bias[b][e], 0.0f);
+            *reinterpret_cast<bf16x4*>(nbuf + ((wr * RTW + r) * 16 + li) * AROW + col) = vo;
+          }
+        }
+      };
+      epilogue_hidden(B0, bufB);
+      __syncthreads();
+      // ---- hidden layers ---------------------------------------------------------------
+      bf16_t* cur = bufB;
+      bf16_t* nxt = bufA;
+#pragma unroll
+      for (int l = 0; l < NH; ++l) {
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+          for (int b = 0; b < TPW; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) {
+          bf16x8 af[RTW];
+#pragma unroll
+          for (int r = 0; r < RTW; ++r)
+            af[r] = *reinterpret_cast<const bf16x8*>(cur + ((wr * RTW + r) * 16 + li) * AROW +
+                                                     ks * 32 + 8 * lq);
+#pragma unroll
+          for (int b = 0; b < TPW; ++b)
+#pragma unroll
+            for (int r = 0; r < RTW; ++r)
+              acc[r][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WH[l][b][ks], af[r], acc[r][b],
+                                                                  0, 0, 0);
+        }
+        epilogue_hidden(BH[l], nxt);
+        __syncthreads();
+        bf16_t* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+      }
+      // ---- head: wave w takes row tile w ------------------------------------------------
+      if (wave < RT) {
+        f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + (wave * 16 + li) * AROW +
+                                                            ks * 32 + 8 * lq);
+          const bf16x8 wo = *reinterpret_cast<const bf16x8*>(wo_s + (ks * 64 + lane) * 8);
+          ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, a, ah, 0, 0, 0);
+        }
+        const int row = wave * 16 + li;
+        const int64_t gi = i0 + row;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (4 * lq + e < N_out) {
+            const float v = ah[e] + BO[e];
+            if (!SAMP && gi < N) c.out[(tN + gi) * N_out + 4 * lq + e] = v;
+            if (SAMP) ms_s[row * N_out + 4 * lq + e] = v;
+          }
+        }
+      }
+      if (SAMP) {
+        __syncthreads();  // the head's rows are in the stash
+        if (tid < ROWS && i0 + tid < N) {
+          // the step's own noise offset and [N]-row output blocks (sampling_layers.py:82-147:
+          // one `_next_offset()` per call of the stepwise rollout)
+          mippo_sampler::FwdParams p = c.samp;
+          const int A = p.A;
+          p.noise.offset_add += (uint64_t)t;
+          if (p.raw_out) p.raw_out += tN * A;
+          if (p.action) p.action += tN * A;
+          if (p.mu_out) p.mu_out += tN * A;
+          if (p.sigma_out) p.sigma_out += tN * A;
+          if (p.ll) p.ll += tN;
+          if (p.reg) p.reg += tN;
+          mippo_sampler::fwd_row(ms_s + tid * N_out, i0 + tid, p);
+        }
+      }
+      __syncthreads();  // bufA / bufB / bufX / the stash are free for the next step
+#pragma unroll
+      for (int u = 0; u < IN_PT; ++u) xin[u] = xnext[u];
+      // ---- after the last step: the carried state (reset select applied) ----------------
+      if (SAMP && t == T - 1) {
+#pragma unroll
+        for (int u = 0; u < IN_PT; ++u) {
+          const int e = tid + u * kWsThreads;
+          if (e < nel) {
+            const int row = (int)(((float)e + 0.5f) * rcpK0);
+            const int64_t gi = i0 + row;
+            if (gi < N) env.obs_out[gi * K0 + (e - row * K0)] = xin[u];
+          }
+        }
+        if (owner) {
+          const int64_t gi = i0 + owner_row;
+          env.key_out[gi] = nkey;
+          env.count_out[gi] = ncount;
+          env.counter_out[gi] = ncounter;
+          env.reward_out[gi] = m_row ? 0.0f : 1.0f;
+        }
+      }
+    }
+  }
+}
+
+template <int HV, int NHV, int HA, int NHA, int RT>
+__global__ void __launch_bounds__(kWsThreads, 2)
+rollout_ws_kernel(WsChain a, WsChain v, RolloutEnv env, int n_value) {
+  constexpr size_t nv = RolloutLds<HV, RT, false>::bytes, na = RolloutLds<HA, RT, true>::bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[nv > na ? nv : na];
+  if ((int)blockIdx.x < n_value)
+    ws_rollout_body<HV, NHV, RT, false>(v, env, (int)blockIdx.x, n_value, smem);
+  else
+    ws_rollout_body<HA, NHA, RT, true>(a, env, (int)blockIdx.x - n_value,
+                                       (int)gridDim.x - n_value, smem);
+}
+
+int fill_chain(WsChain& c, const char* who, int64_t N, int64_t L, const void* const* w,
+               const float* const* bias, const int64_t* dims, float* out) {
+  c = {};
+  c.M = N;
+  c.M_head = N;
+  c.K0 = (int)dims[0];
+  c.N_out = (int)dims[L];
+  c.out = out;
+  for (int64_t l = 0; l < L; ++l) {
+    MI_REQUIRE(w[l] && al16(w[l]), "%s: weight images must be 16-byte aligned", who);
+    c.layer[l].w = static_cast<const bf16_t*>(w[l]);
+    c.layer[l].bias = bias ? bias[l] : nullptr;
+    MI_REQUIRE(!c.layer[l].bias || (reinterpret_cast<uintptr_t>(c.layer[l].bias) & 15) == 0 ||
+                   l == L - 1,
+               "%s: hidden biases must be 16-byte aligned", who);
+  }
+  return 0;
+}
+
+}  // namespace
+
+// 1 if mi_rollout_mock_ws_bf16 takes these trunks: the pairs the one-launch policy step is
+// instantiated for (mi_policy_ws_dual_supported) with a sampler row that fits the stash.
+extern "C" int mi_rollout_mock_ws_supported(int64_t La, const int64_t* a_dims,
+                                            const int64_t* a_acts, int64_t Lc,
+                                            const int64_t* c_dims, const int64_t* c_acts) {
+  if (!a_dims || !a_acts || !c_dims || !c_acts || La < 2 || Lc < 2) return 0;
+  if (!mi_policy_ws_dual_supported(La, a_dims, a_acts, Lc, c_dims, c_acts)) return 0;
+  return 32 * a_dims[La] <= 4096 && a_dims[La] <= 16 && c_dims[Lc] <= 16;
+}
+
+extern "C" int mi_rollout_mock_ws_bf16(
+    const int64_t* env_key, const int64_t* env_step_count, const int64_t* wrap_step_counter,
+    const float* obs0, const int64_t* reset_key, int64_t max_steps, int64_t max_len, int64_t T,
+    int64_t N, const float* norm_mean, const float* norm_m2, const float* norm_count,
+    float norm_eps, int64_t La, const void* const* a_w, const float* const* a_bias,
+    const int64_t* a_dims, const int64_t* a_acts, int64_t Lc, const void* const* c_w,
+    const float* const* c_bias, const int64_t* c_dims, const int64_t* c_acts,
+    const uint64_t* rng_state, uint64_t offset_add, float min_std, float std_scale,
+    float entropy_weight, int deterministic, float* obs_seq, float* next_obs_seq,
+    float* reward_seq, uint8_t* done_seq, uint8_t* trunc_seq, float* raw_seq, float* action_seq,
+    float* loglik_seq, float* mu_seq, float* sigma_seq, float* value_seq, int64_t* env_key_out,
+    int64_t* env_step_count_out, int64_t* wrap_step_counter_out, float* obs_out,
+    float* reward_out, mi_stream_t stream) {
+  MI_REQUIRE(T >= 1 && T <= (1 << 20) && N >= 1, "mi_rollout_mock_ws_bf16: bad T / N");
+  MI_REQUIRE(env_key && env_step_count && wrap_step_counter && obs0 && reset_key && rng_state,
+             "mi_rollout_mock_ws_bf16: null state pointer");
+  MI_REQUIRE(obs_seq && next_obs_seq && reward_seq && done_seq && trunc_seq && raw_seq &&
+                 action_seq && loglik_seq && value_seq,
+             "mi_rollout_mock_ws_bf16: null Transition pointer");
+  MI_REQUIRE(env_key_out && env_step_count_out && wrap_step_counter_out && obs_out && reward_out,
+             "mi_rollout_mock_ws_bf16: null final-state pointer");
+  // a value-trunk workgroup may still be reading the step-0 state of a tile whose
+  // action-trunk workgroup has already finished: the final state needs its own buffers
+  MI_REQUIRE(env_key_out != env_key && env_step_count_out != env_step_count &&
+                 wrap_step_counter_out != wrap_step_counter && obs_out != obs0,
+             "mi_rollout_mock_ws_bf16: the final state must not alias the initial state");
+  MI_REQUIRE(mi_rollout_mock_ws_supported(La, a_dims, a_acts, Lc, c_dims, c_acts),
+             "mi_rollout_mock_ws_bf16: trunks outside the one-launch rollout's class "
+             "(mi_rollout_mock_ws_supported)");
+  MI_REQUIRE(!norm_mean || (norm_m2 && norm_count), "mi_rollout_mock_ws_bf16: incomplete normaliser");
+  MI_REQUIRE(max_steps >= 0 && max_len >= 0, "mi_rollout_mock_ws_bf16: bad episode lengths");
+  WsChain a, v;
+  int rc = fill_chain(a, "mi_rollout_mock_ws_bf16(action)", N, La, a_w, a_bias, a_dims, nullptr);
+  if (rc) return rc;
+  rc = fill_chain(v, "mi_rollout_mock_ws_bf16(value)", N, Lc, c_w, c_bias, c_dims, value_seq);
+  if (rc) return rc;
+  a.norm_mean = v.norm_mean = norm_mean;
+  a.norm_m2 = v.norm_m2 = norm_m2;
+  a.norm_count = v.norm_count = norm_count;
+  a.norm_eps = v.norm_eps = norm_eps;
+  const int64_t A2 = a_dims[La];
+  a.samp = {nullptr, {rng_state, offset_add, nullptr, nullptr}, raw_seq, action_seq, mu_seq,
+            sigma_seq, loglik_seq, nullptr, (int)(A2 / 2), min_std, std_scale, entropy_weight,
+            deterministic};
+  RolloutEnv env = {env_key, env_step_count, wrap_step_counter, obs0, reset_key, max_steps,
+                    max_len, (int)T, N, obs_seq, next_obs_seq, reward_seq, done_seq, trunc_seq,
+                    env_key_out, env_step_count_out, wrap_step_counter_out, obs_out, reward_out};
+  constexpr int RT = 2;  // 32-row tiles: 4096 envs = one tile per workgroup and trunk
+  const int64_t ntiles = mippo::ceil_div(N, 16 * RT);
+  const int64_t cus = ws_grid(1 << 30);
+  int64_t nv = ntiles, na = ntiles;
+  if (nv + na > cus) {
+    nv = cus / 2;
+    na = cus - nv;
+    if (nv > ntiles) nv = ntiles;
+    if (na > ntiles) na = ntiles;
+  }
+  const int64_t hv = c_dims[1], nhv = Lc - 2, ha = a_dims[1], nha = La - 2;
+  hipStream_t st = mippo::as_stream(stream);
+#define X(p, q, r, s_)                                                                    \
+  if (hv == p && nhv == q && ha == r && nha == s_) {                                      \
+    hipLaunchKernelGGL((rollout_ws_kernel<p, q, r, s_, RT>), dim3((unsigned)(nv + na)),   \
+                       dim3(kWsThreads), 0, st, a, v, env, (int)nv);                      \
+    return mippo::check_launch("mi_rollout_mock_ws_bf16");                                \
+  }
+  WS_DUAL_MENU(X)
+#undef X
+  MI_REQUIRE(false, "mi_rollout_mock_ws_bf16: no instantiation for these trunks");
+}

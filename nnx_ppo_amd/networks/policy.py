@@ -45,6 +45,9 @@ WS_POLICY_ROLLOUT = os.environ.get("MIPPO_WS_ROLLOUT", "1") != "0"
 WS_MIN_ROWS = 8192
 # MIPPO_WS_MASKS=0: the weights-stationary backward reads relu' from the bf16 images (A/B)
 USE_MASKS = os.environ.get("MIPPO_WS_MASKS", "1") != "0"
+# MIPPO_FUSED_ROLLOUT=0 keeps the rollout stepwise (two launches per step) where the one-launch
+# rollout (mi_rollout_mock_ws_bf16) would apply (A/B timing, bit-identity tests)
+FUSED_ROLLOUT = os.environ.get("MIPPO_FUSED_ROLLOUT", "1") != "0"
 # the GAE scan, the advantage statistics and the loss gradients inside the backward launch
 # (mi_policy_ws_bwd_gae_bf16) instead of a launch of their own between forward and backward
 GAE_IN_BWD = os.environ.get("MIPPO_GAE_IN_BWD", "1") != "0"
@@ -249,6 +252,105 @@ class MLPActorCritic(Sequential):
             regularization_loss=r["reg"],
             metrics=dict(enumerate([{}] * n_pre + [adapter_out["metrics"]])),
             rollout_extras=pre_extras + [adapter_out["rollout_extras"]])
+
+    # ---- the whole rollout in one launch (rollout.py:48-73) ---------------------------
+    def unroll_fused(self, env, env_state, network_state, unroll_length: int, reset_key):
+        """`unroll_env` for EpisodeWrapper(MockEnv) — the env with a device-side step — as ONE
+        launch (`mi_rollout_mock_ws_bf16`: a workgroup owns a tile of envs for all T steps).
+        Returns what `unroll_env` returns, every leaf bit-identical to the stepwise rollout,
+        or None when the fused form does not apply (any other env, PyTree observations,
+        trunks outside the class, injected noise): the caller then steps."""
+        if not (FUSED and FUSED_ROLLOUT) or config.compute_dtype() != "bf16":
+            return None
+        from .. import random as rnd
+        from ..algorithms.types import State, Transition
+        from ..envs.constants import constant
+        from ..envs.synthetic import MockEnv
+        from ..wrappers.episode_wrapper import EpisodeWrapper
+
+        if type(env) is not EpisodeWrapper or type(env.env) is not MockEnv \
+                or not isinstance(env.env.obs_size, int) or rnd._TORCH_ONLY[0]:
+            return None
+        if self._flattener is not None or not isinstance(env_state, State):
+            return None
+        obs = env_state.obs
+        if not (isinstance(obs, torch.Tensor) and obs.dim() == 2 and self._fusable(obs, obs.shape[0])):
+            return None
+        N, K0 = obs.shape
+        data, info = env_state.data, env_state.info
+        try:
+            key, count, counter = data["key"], data["step_count"], info["step_counter"]
+        except (KeyError, TypeError):
+            return None
+        if set(data) != {"key", "step_count"} or set(info) != {"step_counter", "truncated"} \
+                or env_state.metrics:
+            return None
+        for t in (key, count, counter):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64
+                    and t.shape == (N,)):
+                return None
+        if not (isinstance(reset_key, torch.Tensor) and reset_key.is_cuda
+                and reset_key.dtype == torch.int64 and reset_key.dim() == 0):
+            return None
+        a_layers, sampler, c_layers = self._parts()
+        if sampler.noise_override is not None or unroll_length < 1 or K0 != env.env.obs_size:
+            return None
+        chain = lambda ls: ([l._ff for l in ls], [dense_chain._bias(l) for l in ls],
+                            [ls[0].in_features] + [l.out_features for l in ls],
+                            [l.act_code for l in ls])
+        dense_chain.refresh(list(a_layers) + list(c_layers))
+        ca, cc = chain(a_layers), chain(c_layers)
+        cache = self.__dict__.setdefault("_rollout_fused_cache", {})
+        ck = (tuple(ca[2]), tuple(ca[3]), tuple(cc[2]), tuple(cc[3]))
+        if ck not in cache:
+            cache[ck] = ops.rollout_mock_ws_supported(ca[2], ca[3], cc[2], cc[3])
+        if not cache[ck]:
+            return None
+        norm = None
+        if self._norm is not None:
+            n = self._norm
+            norm = (n.mean.value, n.M2.value, n.counter.value, n.epsilon)
+        T = int(unroll_length)
+        off = sampler._pending          # step t takes offset off + t: T calls of _next_offset()
+        sampler._pending += T
+        c = lambda t: t if t.is_contiguous() else t.contiguous()
+        r = ops.rollout_mock_ws(
+            c(key), c(count), c(counter), c(obs), reset_key, env.env.max_steps, env.max_len, T,
+            norm, ca, cc, sampler._state(obs.device), off,
+            deterministic=sampler.deterministic, **sampler._kw())
+        value = r["value"]
+        if value.shape[-1] == 1:
+            value = value.squeeze(-1)
+        La, Lc = len(a_layers), len(c_layers)
+        a_metrics = {i: {} for i in range(La)}
+        a_metrics[La] = {"mu": r["mu"], "sigma": r["sigma"]}
+        n_pre = len(self.layers) - 1
+        net_metrics = dict(enumerate(
+            [{}] * n_pre + [{"action": a_metrics, "value": {i: {} for i in range(Lc)}}]))
+        extras = [r["obs"]] + [None] * (n_pre - 1) + [
+            {"action": [None] * La + [r["raw"]], "value": [None] * Lc}]
+        rollout = Transition(
+            obs=r["obs"],
+            network_output=PPONetworkOutput(actions=r["action"],
+                                            loglikelihoods=r["log_likelihood"],
+                                            value_estimates=value),
+            rewards=r["reward"], done=r["done"], truncated=r["truncated"],
+            next_obs=r["next_obs"], metrics={"env": {}, "net": net_metrics},
+            rollout_extras=extras)
+        dev = obs.device
+        final_env = State(
+            data={"key": r["key_out"], "step_count": r["count_out"]}, obs=r["obs_out"],
+            reward=r["reward_out"],
+            # after the reset select both flags are down: a finished episode was replaced by
+            # its reset state, an unfinished one has neither (rollout.py:41-44)
+            done=constant((N,), torch.float32, 0.0, dev), metrics={},
+            info={"step_counter": r["counter_out"],
+                  "truncated": constant((N,), torch.bool, 0, dev)})
+        # the carry: stateless layers only (the fusable pattern), passed through as the
+        # stepwise call passes it
+        final_net = [()] * n_pre + [{"action": list(network_state[-1]["action"]),
+                                    "value": list(network_state[-1]["value"])}]
+        return final_net, final_env, rollout
 
     # ---- loss replay (ppo.py:411-431) ------------------------------------------------
     def replay_with_bootstrap(self, state0, x_seq, done_seq, extras_seq, last_obs):
