@@ -30,25 +30,15 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "gemm_epi.h"
 
 namespace {
 
 using namespace mippo_bf16;
 
-enum { EPI_FWD = 0, EPI_DX = 1 };
-
-struct Epi {
-  const float* bias;   // FWD: [J] or null
-  int act;             // FWD
-  float* out_f32;      // [I][ld_f32] or null
-  int64_t ld_f32;
-  bf16_t* out_bf;      // [I][ld_bf] or null (padding columns are written as zero)
-  int64_t ld_bf;
-  bf16_t* aux_bf;      // FWD: pre-activation [I][ld_bf] or null
-  const bf16_t* prev;  // DX: previous layer's output (pre-activation for swish) or null
-  int64_t ld_prev;
-  int prev_act;        // DX
-};
+using mippo_gemm::Epi;
+using mippo_gemm::EPI_FWD;
+using mippo_gemm::EPI_DX;
 
 template <int WM, int WN, int TM, int TN, int EPI>
 __global__ void __launch_bounds__(kThreads)
@@ -639,6 +629,10 @@ weights_to_bf16_multi_kernel(WTable tab) {
 template <int EPI>
 int launch_nt(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int64_t I, int64_t J,
               int64_t R, const Epi& ep, hipStream_t st) {
+  // matrix-core-bound shapes: 256 x 256 tiles with direct-to-LDS loads (gemm256_bf16.hip);
+  // bit-identical to the kernels below
+  const int took = mippo_gemm::nt256_launch(EPI, A, lda, B, ldb, I, J, R, ep, st);
+  if (took) return took < 0 ? took : 0;
   if (J > 64) {
     dim3 grid((unsigned)mippo::ceil_div(I, 128), (unsigned)mippo::ceil_div(J, 128));
     hipLaunchKernelGGL((nt_gemm_kernel<2, 2, 4, 4, EPI>), grid, dim3(kThreads), 0, st, A, lda, B,

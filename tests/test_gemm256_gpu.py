@@ -1,0 +1,92 @@
+"""The 256 x 256-tile NT GEMM with direct-to-LDS loads (csrc/gemm256_bf16.hip) that
+`mi_dense_fwd_bf16` / `mi_dense_bwd_dx_bf16` dispatch to for matrix-core-bound layers
+(`feedforward.py:42-51` at BASELINE config 3's sizes): against an fp64 evaluation on the same
+bf16-rounded operands (1e-4 rel: fp32 accumulation order only), and BIT-IDENTICAL to the
+128-row kernel it replaces — reached here by evaluating the same rows in blocks of fewer than
+2048 rows, which the dispatch leaves on the old kernel."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = torch.float64
+BF = torch.bfloat16
+
+
+def _r(a):
+    return torch.as_tensor(a, dtype=torch.float32).to(BF).to(D)
+
+
+SHAPES = [(4096, 512, 512), (4100, 256, 256), (2304, 32, 512), (6000, 512, 256),
+          (2048, 64, 384), (3000, 256, 136)]
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+@pytest.mark.parametrize("act", ["relu", "none", "tanh"])
+def test_gemm256_forward_and_dx(dev, M, K, N, act):
+    from nnx_ppo_amd import _lib, ops
+
+    rng = np.random.default_rng(M + 3 * K + 5 * N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(K, N)) / math.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    code = ops.ACT_CODES[act]
+    g = lambda a: torch.as_tensor(a).to(dev)
+    x_bf = ops.cast_pad_bf16(g(x))
+    w_bf = torch.zeros(K, ops.pad8(N), dtype=BF, device=dev)
+    wt_bf = torch.zeros(N, ops.pad8(K), dtype=BF, device=dev)
+    ops.weights_to_bf16(g(w), w_bf, wt_bf)
+
+    _, y_bf, _ = ops.dense_fwd_bf16(x_bf, wt_bf, g(b), K, N, code, want_f32=False, want_bf=True)
+    z64 = _r(x) @ _r(w) + torch.as_tensor(b, dtype=D)
+    y64 = {"none": z64, "relu": torch.relu(z64), "tanh": torch.tanh(z64)}[act]
+    got = y_bf[:, :N].float().cpu().to(D)
+    # bf16 output: 2^-8 relative rounding on top of the accumulation-order bound
+    assert np.allclose(got.numpy(), y64.numpy(), rtol=2.0 ** -7, atol=2e-3), \
+        float((got - y64).abs().max())
+    # bit-identical to the 128-row kernel (blocks of < 2048 rows stay on it)
+    blk = 1000
+    old = torch.cat([ops.dense_fwd_bf16(x_bf[i:i + blk].contiguous(), wt_bf, g(b), K, N, code,
+                                        want_f32=False, want_bf=True)[1]
+                     for i in range(0, M, blk)])
+    assert torch.equal(y_bf, old)
+
+    # dX times relu'(prev) (the class the 256-row kernel takes) and without a previous layer
+    dz = rng.normal(size=(M, N)).astype(np.float32)
+    prev = rng.normal(size=(M, K)).astype(np.float32)
+    dz_bf, prev_bf = ops.cast_pad_bf16(g(dz)), ops.cast_pad_bf16(g(prev))
+    for p_act, p_bf in ((ops.ACT_RELU, prev_bf), (ops.ACT_NONE, None)):
+        _, gx_bf = ops.dense_bwd_dx_bf16(dz_bf, w_bf, p_bf, p_act, K, N, want_f32=False,
+                                         want_bf=True)
+        gx64 = _r(dz) @ _r(w).t()
+        if p_act == ops.ACT_RELU:
+            gx64 = gx64 * (_r(prev) > 0).to(D)
+        got = gx_bf[:, :K].float().cpu().to(D)
+        assert np.allclose(got.numpy(), gx64.numpy(), rtol=2.0 ** -7, atol=2e-3)
+        old = torch.cat([ops.dense_bwd_dx_bf16(
+            dz_bf[i:i + blk].contiguous(), w_bf,
+            None if p_bf is None else p_bf[i:i + blk].contiguous(), p_act, K, N,
+            want_f32=False, want_bf=True)[1] for i in range(0, M, blk)])
+        assert torch.equal(gx_bf, old)
+
+
+def test_gemm256_asymmetric_identity(dev):
+    """A = I against an asymmetric B pins the operand maps and the swizzle: the output must be
+    B's rows exactly, not a transpose or a permutation of them."""
+    from nnx_ppo_amd import ops
+
+    M, K, N = 2304, 256, 256
+    x = torch.zeros(M, K, device=dev)
+    x[:K] = torch.eye(K, device=dev)
+    x[K:2 * K] = 2 * torch.eye(K, device=dev)
+    w = ((torch.arange(K * N, device=dev, dtype=torch.float32).reshape(K, N) % 251) - 125) / 4
+    w_bf = torch.zeros(K, N, dtype=BF, device=dev)
+    wt_bf = torch.zeros(N, K, dtype=BF, device=dev)
+    ops.weights_to_bf16(w, w_bf, wt_bf)
+    _, y_bf, _ = ops.dense_fwd_bf16(ops.cast_pad_bf16(x), wt_bf, None, K, N, ops.ACT_NONE,
+                                    want_f32=False, want_bf=True)
+    assert torch.equal(y_bf[:K], w.to(BF))
+    assert torch.equal(y_bf[K:2 * K], (2 * w).to(BF))
+    assert float(y_bf[2 * K:].float().abs().sum()) == 0.0
