@@ -143,14 +143,25 @@ nt256_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict
 #pragma unroll
     for (int a = 0; a < TM; ++a)
       af[a] = *reinterpret_cast<const bf16x8*>(slot + fa + a * (16 * 64));
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b)
         // transposed tile: weights as the first operand -> lane holds 4 consecutive columns
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    // the emitted order: the 4 weight fragments and the first row fragment, then every group
+    // of 4 MFMAs (one row tile) with the NEXT row tile's fragment read beside it — the LDS
+    // reads hide behind the matrix pipe instead of in front of it (all 12 reads first, then
+    // `lgkmcnt(0)`, left the pipe idle for the whole read phase of both waves of a SIMD)
+    // (one row fragment AHEAD: the read of row tile a + 2 is issued before the MFMAs of row
+    // tile a, so it has two groups of MFMAs to land)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int a = 0; a < TM - 2; ++a) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     // slot t + 1 (issued two iterations ago) has landed once at most the 8 younger DMAs of
     // slots t + 2 and t + 3 are still in flight
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -219,6 +230,180 @@ nt256_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict
   }
 }
 
+// ---- dW on 256 x 256 tiles: gW[K,N] = X[M,K]^T . dZ[M,N], split over M into fp32 slabs ----
+// Both operands are REDUCE-major (the reduce index m is their row index): a slot is 32 rows of
+// 512 bytes of each, DMA'd as they lie in memory (one instruction = two rows); the MFMA
+// fragments are gathered by the transposing LDS read (ds_read_b64_tr_b16, as gemm_bf16.hip's
+// dW).  The bank swizzle is again on the source address: 16-byte chunk c of row r sits at
+// position c ^ 2 f(r), f(r) = (r & 3) | ((r >> 3 & 1) << 2) — the eight rows a 32-lane half
+// of a transposing read touches (4 rows of two 16-lane groups, 8 rows apart) then fall into
+// the eight different 32-byte slots of the 256-byte bank row.
+struct Dw256Problem {
+  const bf16_t* A;  // X  [M][lda]
+  const bf16_t* B;  // dZ [M][ldb]
+  float* slabs;     // [S][I * J + J]
+  int64_t lda, ldb, I, J;
+  int tile_begin;   // first tile index of this problem; tiles_j column tiles per row tile
+  int tiles_j;
+};
+constexpr int kMaxDw256 = 8;
+struct Dw256Table {
+  Dw256Problem p[kMaxDw256];
+  int n, tiles;     // problems, tiles of all problems
+  int64_t M, rows_per_split;
+};
+
+__device__ __forceinline__ int swz_tn(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
+
+__global__ void __launch_bounds__(kT, 2)
+tn256_kernel(Dw256Table tab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // split-major ids (the tiles of one row range are neighbours), then the XCD remap
+  const unsigned total = gridDim.x;
+  const unsigned hw = blockIdx.x;
+  const unsigned chunk = total / 8, rem = total % 8;
+  const unsigned xcd = hw % 8, idx = hw / 8;
+  const unsigned logical = xcd * chunk + (xcd < rem ? xcd : rem) + idx;
+  const int zsplit = (int)(logical / (unsigned)tab.tiles);
+  const int tile = (int)(logical % (unsigned)tab.tiles);
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxDw256; ++q)
+    if (q < tab.n && tile >= tab.p[q].tile_begin) pi = q;
+  const Dw256Problem pr = tab.p[pi];
+  const int lt = tile - pr.tile_begin;
+  const int64_t i0 = (int64_t)(lt / pr.tiles_j) * TB;
+  const int64_t j0 = (int64_t)(lt % pr.tiles_j) * TB;
+  const int64_t I = pr.I, J = pr.J;
+  const int64_t r_begin = (int64_t)zsplit * tab.rows_per_split;
+  int64_t r_end = r_begin + tab.rows_per_split;
+  r_end = r_end < tab.M ? r_end : tab.M;
+  const int nk = r_end > r_begin ? (int)((r_end - r_begin) / KB) : 0;  // whole slots (M % 32 == 0)
+
+  // ---- staging: instruction q of an operand = rows 2q, 2q + 1 of the slot (2 x 512 bytes);
+  // wave w issues q = 2w, 2w + 1 ------------------------------------------------------------
+  const char* ga[2];
+  const char* gb[2];
+  unsigned la[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (wave * 2 + q) * 2 + (lane >> 5);
+    const int src_chunk = (lane & 31) ^ swz_tn(row);
+    // column chunks beyond the operand's row stay inside it (their products land in output
+    // rows / columns that are never stored)
+    const int64_t ca = i0 + src_chunk * 8 < pr.lda ? i0 + src_chunk * 8 : 0;
+    const int64_t cb = j0 + src_chunk * 8 < pr.ldb ? j0 + src_chunk * 8 : 0;
+    ga[q] = reinterpret_cast<const char*>(pr.A + (r_begin + row) * pr.lda + ca);
+    gb[q] = reinterpret_cast<const char*>(pr.B + (r_begin + row) * pr.ldb + cb);
+    la[q] = (unsigned)((wave * 2 + q) * 1024);
+  }
+  const int64_t stride_a = (int64_t)KB * pr.lda * 2, stride_b = (int64_t)KB * pr.ldb * 2;
+  auto stage = [&](int t) {
+    const int tc = t < nk ? t : (nk > 0 ? nk - 1 : 0);
+    unsigned char* slot = lds + (t & (NSLOT - 1)) * kSlotBytes;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[q] + tc * stride_a),
+                                       (lds_ptr_t)(slot + la[q]), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[q] + tc * stride_b),
+                                       (lds_ptr_t)(slot + kOpBytes + la[q]), 16, 0, 0);
+  };
+
+  f32x4 acc[TM][TN], accb[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < TN; ++b) accb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = i0 == 0 && wm == 0;  // column sums of dZ: once per column tile
+  typedef __attribute__((ext_vector_type(8))) short ones_s16x8;
+  const bf16x8 ones = __builtin_bit_cast(
+      bf16x8, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
+  // transposing fragment gather (gemm_bf16.hip: frag): lane 4q + p of each 16-lane group g
+  // addresses row 8g + q (+ 4 for the second read), columns c0 + 4p .. 4p + 3
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int xo = swz_tn(8 * g + tq);  // the same for row + 4
+  unsigned oa[TM], ob[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+    oa[a] = (unsigned)((8 * g + tq) * 512 + (((wm * 16 + 2 * a + (tp >> 1)) ^ xo) * 16) +
+                       8 * (tp & 1));
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+    ob[b] = (unsigned)(kOpBytes + (8 * g + tq) * 512 +
+                       (((wn * 8 + 2 * b + (tp >> 1)) ^ xo) * 16) + 8 * (tp & 1));
+  using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+  auto frag = [&](const unsigned char* slot, unsigned off) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + off + 4 * 512));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int t = 0; t < nk; ++t) {
+    stage(t + 3);
+    const unsigned char* slot = lds + (t & (NSLOT - 1)) * kSlotBytes;
+    bf16x8 af[TM], bfr[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bfr[b] = frag(slot, ob[b]);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[a] = frag(slot, oa[a]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        // dZ fragment first: a lane ends with 4 CONSECUTIVE output columns of one row
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], ones, accb[b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* slab = pr.slabs + (int64_t)zsplit * (I * J + J);
+  const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int64_t i = i0 + wm * 128 + a * 16 + li;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int64_t j = j0 + wn * 64 + b * 16 + 4 * lq;
+      if (i < I && j < J) *reinterpret_cast<f32x4*>(slab + i * J + j) = acc[a][b];  // J % 8 == 0
+    }
+  }
+  if (do_bias && li == 0) {  // every row of the ones-tile holds the same sums
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int64_t j = j0 + wn * 64 + b * 16 + 4 * lq;
+      if (j < J) *reinterpret_cast<f32x4*>(slab + I * J + j) = accb[b];
+    }
+  }
+}
+
 }  // namespace
 
 namespace mippo_gemm {
@@ -265,6 +450,73 @@ int nt256_launch(int epi, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t
                        J, R, ep, (int)tiles_j);
   const int rc = mippo::check_launch("nt256_gemm_bf16");
   return rc ? rc : 1;
+}
+
+// The dW problems of a grouped launch that the 256 x 256 kernel takes: K and N multiples of 8
+// covering at least four tiles, M a multiple of 32 and >= 8192.  dw256_plan decides the split for
+// the taken problems together; dw256_launch runs them in ONE launch and reports slab
+// positions / counts like the 128-row path.
+bool dw256_takes(int64_t K, int64_t N, int64_t M) {
+  static const int enabled = [] {
+    const char* e = getenv("MIPPO_GEMM256");
+    return !(e && e[0] == '0');
+  }();
+  // at least four 256 x 256 tiles: with fewer, filling the chip takes so many M-splits that
+  // the fp32 slabs (S x K x N x 4 bytes, written and read again) outweigh the operands —
+  // measured at M = 61 440 (tools/microbench_dw256.py): 512 x 512 alone 72 -> 64 us, inside the
+  // 17-512-512-1 critic's group 137 -> 107 us; 256 x 256 alone 34 -> 42 us (the 128-row kernel
+  // keeps it)
+  return enabled && K % 8 == 0 && N % 8 == 0 && M >= 8192 && M % KB == 0 &&
+         mippo::ceil_div(K, TB) * mippo::ceil_div(N, TB) >= 4;
+}
+
+void dw256_plan(int64_t M, int64_t tiles, int64_t* rows, int64_t* S) {
+  static const int64_t target = [] {  // MIPPO_DW256_BLOCKS: workgroups aimed at (tuning aid)
+    const char* e = getenv("MIPPO_DW256_BLOCKS");
+    return e ? (int64_t)atoi(e) : (int64_t)mippo::kNumCU;
+  }();
+  int64_t s = target / (tiles < 1 ? 1 : tiles);
+  if (s < 1) s = 1;
+  const int64_t max_s = M / 256 < 1 ? 1 : M / 256;  // at least 8 slots per workgroup
+  if (s > max_s) s = max_s;
+  *rows = mippo::ceil_div(mippo::ceil_div(M, s), KB) * KB;
+  *S = mippo::ceil_div(M, *rows);
+}
+
+int64_t dw256_tiles(int64_t K, int64_t N) { return mippo::ceil_div(K, TB) * mippo::ceil_div(N, TB); }
+
+int dw256_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, const int64_t* K,
+                 const int64_t* N, int64_t M, float* const* slabs, int64_t rows, int64_t S,
+                 hipStream_t st) {
+  if (n < 1 || n > kMaxDw256) return -EINVAL;
+  Dw256Table tab = {};
+  tab.n = n;
+  tab.M = M;
+  tab.rows_per_split = rows;
+  int tiles = 0;
+  for (int l = 0; l < n; ++l) {
+    Dw256Problem& pr = tab.p[l];
+    pr.A = x_bf[l];
+    pr.B = dz_bf[l];
+    pr.slabs = slabs[l];
+    pr.lda = mippo::ceil_div(K[l], 8) * 8;
+    pr.ldb = mippo::ceil_div(N[l], 8) * 8;
+    pr.I = K[l];
+    pr.J = N[l];
+    pr.tile_begin = tiles;
+    pr.tiles_j = (int)mippo::ceil_div(N[l], TB);
+    tiles += (int)dw256_tiles(K[l], N[l]);
+  }
+  tab.tiles = tiles;
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      kLdsBytes);
+  if (attr != hipSuccess) {
+    mippo::set_error("dw256_launch: cannot raise the LDS limit");
+    return -EIO;
+  }
+  hipLaunchKernelGGL(tn256_kernel, dim3((unsigned)(tiles * S)), dim3(kT), kLdsBytes, st, tab);
+  return mippo::check_launch("tn256_gemm_dw_bf16");
 }
 
 }  // namespace mippo_gemm

@@ -788,6 +788,11 @@ extern "C" int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const
   for (int64_t l = 0; l < n; ++l) {
     int64_t rows, S;
     dw_split_plan(M, dw_tiles(K[l], N[l]), &rows, &S);
+    if (mippo_gemm::dw256_takes(K[l], N[l], M)) {  // (alone in its launch: the largest split)
+      int64_t r2, S2;
+      mippo_gemm::dw256_plan(M, mippo_gemm::dw256_tiles(K[l], N[l]), &r2, &S2);
+      if (S2 > S) S = S2;
+    }
     total += S * (K[l] * N[l] + N[l]);
   }
   return total * (int64_t)sizeof(float);
@@ -808,12 +813,47 @@ static int dw_grouped_launch(const char* who, int64_t n, const void* const* x_bf
                "%s: bad problem %lld", who, (long long)l);
     KNv[l] = K[l] * N[l];
   }
+  // matrix-core-bound problems (both dimensions >= 128 at training sizes) go out first, in
+  // one launch of the 256 x 256-tile kernel (gemm256_bf16.hip); the rest below
+  bool big[kMaxDwProblems];
+  int n_big = 0;
+  {
+    const bf16_t* xa[kMaxDwProblems];
+    const bf16_t* za[kMaxDwProblems];
+    float* sl[kMaxDwProblems];
+    int64_t Kb[kMaxDwProblems], Nb[kMaxDwProblems];
+    int64_t tiles_big = 0;
+    for (int64_t l = 0; l < n; ++l) {
+      big[l] = mippo_gemm::dw256_takes(K[l], N[l], M);
+      if (big[l]) tiles_big += mippo_gemm::dw256_tiles(K[l], N[l]);
+    }
+    if (tiles_big) {
+      int64_t rows_b, S_b;
+      mippo_gemm::dw256_plan(M, tiles_big, &rows_b, &S_b);
+      for (int64_t l = 0; l < n; ++l) {
+        if (!big[l]) continue;
+        xa[n_big] = static_cast<const bf16_t*>(x_bf[l]);
+        za[n_big] = static_cast<const bf16_t*>(dz_bf[l]);
+        Kb[n_big] = K[l];
+        Nb[n_big] = N[l];
+        sl[n_big] = ws;
+        slab_ptr[l] = ws;
+        Sv[l] = S_b;
+        ws += S_b * (KNv[l] + N[l]);
+        ++n_big;
+      }
+      const int rc = mippo_gemm::dw256_launch(n_big, xa, za, Kb, Nb, M, sl, rows_b, S_b, st);
+      if (rc) return rc;
+      if (n_big == n) return 0;
+    }
+  }
   // one workgroup range per tile class (by output width), problems of a class side by
   // side; all classes go out in ONE launch
   DwAll all = {};
   unsigned next = 0;
   int64_t tiles_all = 0;
-  for (int64_t l = 0; l < n; ++l) tiles_all += dw_tiles(K[l], N[l]);
+  for (int64_t l = 0; l < n; ++l)
+    if (!big[l]) tiles_all += dw_tiles(K[l], N[l]);
   int64_t rows, S;
   dw_split_plan(M, tiles_all, &rows, &S);
   size_t lds = 0;
@@ -823,7 +863,7 @@ static int dw_grouped_launch(const char* who, int64_t n, const void* const* x_bf
     int64_t gx = 0, gy = 0;
     for (int64_t l = 0; l < n; ++l) {
       const int c = N[l] > 64 ? 0 : (N[l] > 16 ? 1 : 2);
-      if (c != cls) continue;
+      if (c != cls || big[l]) continue;
       idx[tab.n++] = (int)l;
       const int64_t tx = mippo::ceil_div(K[l], 128), ty = mippo::ceil_div(N[l], dw_tile_n(N[l]));
       if (tx > gx) gx = tx;

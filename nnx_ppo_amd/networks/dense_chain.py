@@ -97,13 +97,32 @@ FUSED_MAX_LAYERS = 8
 FUSED_MAX_WIDTH = 512
 
 
-def _fusable(layers, M: int) -> bool:
-    """Whole-trunk kernels (csrc/mlp_bf16.hip) take up to 8 layers of width <= 512.
-    Measured inside a HIP graph (tools/microbench_trunk.py) they are at least as fast as
-    the per-layer GEMMs up to that width at every M (512-wide, M = 30 720: 73 us
-    forward / 67 us dX chain against 77 / 82 us)."""
+# MIPPO_GEMM256_CHAIN=1: trunks at least GEMM256_MIN_WIDTH wide run LAYER BY LAYER at training
+# sizes (M > WS_MIN_ROWS) unless the weights-stationary kernels take them.  The per-layer NT
+# GEMM on 256 x 256 tiles with direct-to-LDS loads (csrc/gemm256_bf16.hip) moves a
+# 61 440 x 512 x 512 layer at ~650 TF/s with its bias / relu / image epilogue (the 128-row
+# kernel: 385; hipBLASLt's plain product: 706) — but a trunk is not only its square layers:
+# layer by layer, the thin first and last layers (17 -> 512, 512 -> 1) each make a full pass
+# over a 63 MB image that the whole-trunk walk never writes twice, and BASELINE config 3 ran
+# 18.4 M env-steps/s this way against 21.8 M on the whole-trunk kernels (measured, round 3).
+# So the default stays the whole-trunk walk; trunks wider than FUSED_MAX_WIDTH, which always
+# ran per layer, get the new kernel through the same entry points.
+GEMM256_CHAIN = os.environ.get("MIPPO_GEMM256_CHAIN", "0") == "1"
+GEMM256_MIN_WIDTH = 256
+
+
+def _fusable(layers, M: int, need_input_grad: bool = False) -> bool:
+    """Whole-trunk kernels (csrc/mlp_bf16.hip) take up to 8 layers of width <= 512.  Up to
+    8192 rows (rollout / evaluation sizes) and for narrow trunks they beat the per-layer
+    GEMMs (a layer is one or two k-tiles of work: launch and round-trip latency, not MFMA
+    rate); wide trunks at training sizes go per layer (see GEMM256_CHAIN)."""
     width = max(max(l.in_features, l.out_features) for l in layers)
-    return len(layers) <= FUSED_MAX_LAYERS and width <= FUSED_MAX_WIDTH
+    if len(layers) > FUSED_MAX_LAYERS or width > FUSED_MAX_WIDTH:
+        return False
+    if (GEMM256_CHAIN and M > WS_MIN_ROWS and width >= GEMM256_MIN_WIDTH
+            and not _ws(layers, M, need_input_grad)):
+        return False
+    return True
 
 
 # Training-size chains in the shape class of the weights-stationary kernels (csrc/trunk_ws.hip:
@@ -153,7 +172,7 @@ def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
     """Returns (ctx, fp32 output [M, N_last]).  ctx keeps, per layer, the bf16 input
     (dW operand), the tensor its act' is evaluated on, and the bf16 W shadow."""
     M = x2.shape[0]
-    if _fusable(layers, M):
+    if _fusable(layers, M, need_input_grad):
         fwd = ops.mlp_ws_fwd_bf16 if _ws(layers, M, need_input_grad) else ops.mlp_fwd_bf16
         y, sv = fwd(x2, *_chain_args(layers), train=True)
         saved = [(xb, aux, _shadows(l)[0]) for (xb, aux), l in zip(sv, layers)]
@@ -193,7 +212,7 @@ def backward(layers, ctx, g_out2: torch.Tensor):
     L = len(layers)
     last = layers[-1]
     grads = [(l.kernel.grad, l.bias.grad if l.bias is not None else None) for l in layers]
-    if _fusable(layers, M) and (L > 1 or need_input_grad):
+    if _fusable(layers, M_fwd, need_input_grad) and (L > 1 or need_input_grad):
         dims = [layers[0].in_features] + [l.out_features for l in layers]
         refresh(layers)
         if _ws(layers, M_fwd, need_input_grad):

@@ -90,3 +90,55 @@ def test_gemm256_asymmetric_identity(dev):
     assert torch.equal(y_bf[:K], w.to(BF))
     assert torch.equal(y_bf[K:2 * K], (2 * w).to(BF))
     assert float(y_bf[2 * K:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 512, 512), (12288, 256, 256), (8192, 256, 512),
+                                   (9216, 384, 136), (8192, 128, 264)])
+def test_dw256_vs_fp64(dev, M, K, N):
+    """dW / db on 256 x 256 tiles (tn256_kernel): fp64 on the same bf16-rounded operands,
+    bitwise reproducible, and the grouped form with a thin problem beside it."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(M + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    dz = rng.normal(size=(M, N)).astype(np.float32)
+    g = lambda a: torch.as_tensor(a).to(dev)
+    x_bf, dz_bf = ops.cast_pad_bf16(g(x)), ops.cast_pad_bf16(g(dz))
+    gw = torch.zeros(K, N, device=dev)
+    gb = torch.zeros(N, device=dev)
+    ops.dense_bwd_dw_bf16(x_bf, dz_bf, gw, gb, accumulate=True)
+    gw64 = _r(x).t() @ _r(dz)
+    gb64 = _r(dz).sum(0)
+    s = math.sqrt(M)
+    assert np.allclose(gw.cpu().numpy(), gw64.numpy(), rtol=1e-4, atol=2e-5 * s), \
+        float((gw.cpu().to(D) - gw64).abs().max())
+    assert np.allclose(gb.cpu().numpy(), gb64.numpy(), rtol=1e-4, atol=2e-5 * s)
+    gw2 = torch.zeros(K, N, device=dev)
+    ops.dense_bwd_dw_bf16(x_bf, dz_bf, gw2, None, accumulate=False)
+    assert torch.equal(gw2, gw)
+    # grouped: this problem (256-tile kernel) beside a thin head (128-row kernel), one call
+    dz2 = rng.normal(size=(M, 3)).astype(np.float32)
+    dz2_bf = ops.cast_pad_bf16(g(dz2))
+    gw_a, gb_a = torch.zeros(K, N, device=dev), torch.zeros(N, device=dev)
+    gw_b, gb_b = torch.zeros(N, 3, device=dev), torch.zeros(3, device=dev)
+    ops.dense_bwd_dw_grouped_bf16([(x_bf, dz_bf, gw_a, gb_a), (dz_bf, dz2_bf, gw_b, gb_b)],
+                                  accumulate=True)
+    assert torch.equal(gw_a, gw) and torch.equal(gb_a, gb)
+    assert np.allclose(gw_b.cpu().numpy(), (_r(dz).t() @ _r(dz2)).numpy(), rtol=1e-4,
+                       atol=2e-5 * s)
+
+
+def test_dw256_asymmetric_identity(dev):
+    """x = I rows (twice, so the split-M slabs add up) against an asymmetric dz pins the
+    transposing gather and the swizzle of both operands."""
+    from nnx_ppo_amd import ops
+
+    M, K, N = 8192, 256, 512
+    x = torch.zeros(M, K, device=dev)
+    x[:K] = torch.eye(K, device=dev)
+    x[4096:4096 + K] = torch.eye(K, device=dev)
+    dz = ((torch.arange(M * N, device=dev, dtype=torch.float32).reshape(M, N) % 251) - 125) / 2
+    gw = torch.zeros(K, N, device=dev)
+    ops.dense_bwd_dw_bf16(ops.cast_pad_bf16(x), ops.cast_pad_bf16(dz), gw, None, accumulate=False)
+    want = dz[:K].to(BF).float() + dz[4096:4096 + K].to(BF).float()
+    assert torch.equal(gw, want)
