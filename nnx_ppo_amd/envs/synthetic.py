@@ -20,22 +20,38 @@ class MockEnv:
     Unlike the reference's mock (whose noise key depends on the step only) each
     env mixes its own key in, so envs are decorrelated."""
 
-    def __init__(self, obs_size, action_size: int, max_steps: int = 5):
+    def __init__(self, obs_size, action_size: int, max_steps: int = 5,
+                 obs_law: str = "uniform"):
+        """`obs_law`: "uniform" (default) — zero-mean unit-variance uniform noise, one IEEE
+        multiply on exact operands, so the kernels, the CPU statement and the oracle agree bit
+        for bit (what `bench.py` and every parity test use); "normal" — N(0, 1) by Box-Muller,
+        the law of the reference's mock (`mock_env.py:43,53`: `jax.random.normal`), evaluated
+        with torch ops (no fused env step, no one-launch rollout; CPU / GPU / oracle agree to
+        the last ulp of log / cos, not bit for bit).  The kernels' work does not depend on the
+        law."""
+        if obs_law not in ("uniform", "normal"):
+            raise ValueError(f"MockEnv: obs_law must be 'uniform' or 'normal', got {obs_law!r}")
         self.obs_size = obs_size
         self.action_size = action_size
         self.max_steps = max_steps
         self.observation_size = obs_size
+        self.obs_law = obs_law
+
+    def _draw(self, key, shape, step):
+        if self.obs_law == "normal":
+            return rnd.unit_normal(key, shape, fold=step)
+        return rnd.unit_uniform(key, shape, fold=step)
 
     def _obs(self, key: torch.Tensor, step: torch.Tensor) -> Any:
         if isinstance(self.obs_size, dict):
             names = sorted(self.obs_size)
-            flat = rnd.unit_uniform(key, (sum(self.obs_size[n] for n in names),), fold=step)
+            flat = self._draw(key, (sum(self.obs_size[n] for n in names),), step)
             out, o = {}, 0
             for name in names:
                 out[name] = flat[..., o:o + self.obs_size[name]].contiguous()
                 o += self.obs_size[name]
             return out
-        return rnd.unit_uniform(key, (self.obs_size,), fold=step)
+        return self._draw(key, (self.obs_size,), step)
 
     def reset(self, rng: torch.Tensor) -> State:
         n = rng.shape
@@ -50,7 +66,8 @@ class MockEnv:
     def step(self, state: State, action: torch.Tensor) -> State:
         key = state.data["key"]
         count = state.data["step_count"]
-        if count.is_cuda and count.dim() == 1 and not rnd._TORCH_ONLY[0]:
+        if (count.is_cuda and count.dim() == 1 and not rnd._TORCH_ONLY[0]
+                and self.obs_law == "uniform"):
             # the whole step — counter, done flag and the observation draw — in one launch
             # (csrc/keys.hip: mi_mock_env_step); the same integers and floats as below
             from .. import ops
@@ -84,7 +101,8 @@ class MockEnv:
         key = state.data["key"]
         count = state.data["step_count"]
         if not (count.is_cuda and count.dim() == 1 and not rnd._TORCH_ONLY[0]
-                and key.is_contiguous() and count.is_contiguous()):
+                and key.is_contiguous() and count.is_contiguous()
+                and self.obs_law == "uniform"):
             return self.step(state, action), None
         n, dev = count.shape[0], count.device
         step = torch.empty_like(count)

@@ -269,7 +269,8 @@ class MLPActorCritic(Sequential):
         from ..wrappers.episode_wrapper import EpisodeWrapper
 
         if type(env) is not EpisodeWrapper or type(env.env) is not MockEnv \
-                or not isinstance(env.env.obs_size, int) or rnd._TORCH_ONLY[0]:
+                or not isinstance(env.env.obs_size, int) or rnd._TORCH_ONLY[0] \
+                or env.env.obs_law != "uniform":
             return None
         if self._flattener is not None or not isinstance(env_state, State):
             return None

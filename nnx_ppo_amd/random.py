@@ -161,6 +161,21 @@ def unit_uniform(k: torch.Tensor, shape=(), dtype=torch.float32,
     return (u - 0.5) * 3.4641016151377544
 
 
+def unit_normal(k: torch.Tensor, shape=(), fold: torch.Tensor | None = None) -> torch.Tensor:
+    """N(0, 1) draws (`jax.random.normal`, the law of the reference's test envs,
+    `test_dummies/mock_env.py:43,53`) by Box-Muller from the two 24-bit halves of each 64-bit
+    hash: z = sqrt(-2 ln u1) cos(2 pi u2), u1 in (0, 1], u2 in [0, 1).  Plain torch ops on any
+    device (no kernel of its own: the synthetic env's default law is `unit_uniform`, which
+    the kernels evaluate bit for bit; this one agrees between CPU and GPU only to the
+    transcendental functions' last ulp)."""
+    if fold is not None:
+        k = fold_key(k, fold)
+    b = bits(k, shape)
+    u1 = (_lsr(b, 40) + 1).to(torch.float32) * (1.0 / (1 << 24))
+    u2 = (_lsr(b, 16) & 0xFFFFFF).to(torch.float32) * (1.0 / (1 << 24))
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
+
+
 def fold_key(k: torch.Tensor, data: torch.Tensor) -> torch.Tensor:
     """Per-element fold of an int64 tensor into keys of the same shape:
     mix(k ^ mix(data + GOLDEN))."""

@@ -41,20 +41,25 @@ class State:
 
 
 class MockEnv:
-    def __init__(self, obs_size, action_size: int, max_steps: int = 5):
+    def __init__(self, obs_size, action_size: int, max_steps: int = 5, obs_law: str = "uniform"):
         self.obs_size, self.action_size, self.max_steps = obs_size, action_size, max_steps
         self.observation_size = obs_size
+        self.obs_law = obs_law  # "normal": the reference's own law (mock_env.py:43,53)
+
+    def _draw(self, key, shape, step):
+        return (K.unit_normal if self.obs_law == "normal" else K.unit_uniform)(key, shape,
+                                                                               fold=step)
 
     def _obs(self, key: torch.Tensor, step: torch.Tensor):
         if isinstance(self.obs_size, dict):
             names = sorted(self.obs_size)
-            flat = K.unit_uniform(key, (sum(self.obs_size[n] for n in names),), fold=step)
+            flat = self._draw(key, (sum(self.obs_size[n] for n in names),), step)
             out, o = {}, 0
             for n in names:
                 out[n] = flat[..., o:o + self.obs_size[n]].contiguous()
                 o += self.obs_size[n]
             return out
-        return K.unit_uniform(key, (self.obs_size,), fold=step)
+        return self._draw(key, (self.obs_size,), step)
 
     def reset(self, rng: torch.Tensor) -> State:  # mock_env.py:40-50
         zero = torch.zeros(rng.shape, dtype=torch.int64)

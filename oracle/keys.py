@@ -135,6 +135,19 @@ def unit_uniform(k, shape=(), fold=None) -> torch.Tensor:
     return torch.from_numpy((u - np.float32(0.5)) * np.float32(3.4641016151377544))
 
 
+def unit_normal(k, shape=(), fold=None) -> torch.Tensor:
+    """N(0, 1) by Box-Muller from the two 24-bit halves of each hash (the optional law of the
+    synthetic env, `mock_env.py:43,53`'s `jax.random.normal`; numpy float32 arithmetic)."""
+    if fold is not None:
+        k = fold_key(k, fold)
+    b = _u(bits(k, shape))
+    u1 = ((b >> np.uint64(40)) + np.uint64(1)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    u2 = ((b >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(np.float32) \
+        * np.float32(1.0 / (1 << 24))
+    z = np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+    return torch.as_tensor(z.astype(np.float32))
+
+
 def permutation(k, n: int) -> torch.Tensor:
     """`jax.random.permutation(key, n)`: stable argsort of n 64-bit hashes, compared as
     SIGNED integers (the product sorts int64)."""

@@ -4,6 +4,7 @@ pinned by the published SplitMix64 outputs, and the product's CPU statement
 for bit.  (`tests/test_keys_gpu.py` checks the HIP kernels against the same restatement.)
 Structure pinned: `ppo.py:271,284-294,544-548`, `rollout.py:57-59` (split / fold_in /
 permutation call for call); the VALUES of jax.random's threefry streams are parity unpinned."""
+import numpy as np
 import pytest
 import torch
 
@@ -106,3 +107,39 @@ def test_product_envs_on_cpu_equal_the_oracle_envs(obs_size):
         ps = op.tree_where(done, pe.reset(reset_keys[t]), ps)
         qs = op.tree_where(done, qe.reset(reset_keys[t]), qs)
         same(ps, qs)
+
+
+def test_normal_observation_law_option():
+    """`MockEnv(obs_law="normal")`: the reference mock's own law (`mock_env.py:43,53`:
+    `jax.random.normal`) as an option of the synthetic env.  Box-Muller on the key scheme's
+    bits: the product's statement and the oracle's agree to the last ulp of log / cos (not
+    bit for bit: that is why "uniform" stays the default), the draws are N(0, 1), and the
+    event stream (flags, counters, keys) stays exact."""
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+    from oracle import envs as oe
+
+    kids = ok.split(ok.key(11), 4096)
+    steps = torch.arange(4096, dtype=torch.int64) % 7
+    a = rnd.unit_normal(kids, (5,), fold=steps)
+    b = ok.unit_normal(kids, (5,), fold=steps)
+    assert a.shape == b.shape == (4096, 5) and a.dtype == torch.float32
+    assert np.allclose(a.numpy(), b.numpy(), rtol=0, atol=2e-6)
+    z = a.numpy().astype(np.float64).ravel()
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1.0) < 0.03
+    assert abs((z ** 3).mean()) < 0.08 and abs((z ** 4).mean() - 3.0) < 0.25   # not uniform (1.8)
+    with pytest.raises(ValueError):
+        MockEnv(5, 1, obs_law="cauchy")
+
+    pe = EpisodeWrapper(MockEnv(5, 1, max_steps=4, obs_law="normal"), 9)
+    qe = oe.EpisodeWrapper(oe.MockEnv(5, 1, max_steps=4, obs_law="normal"), 9)
+    k0 = ok.split(ok.key(3), 64)
+    ps, qs = pe.reset(k0), qe.reset(k0)
+    for t in range(6):
+        act = torch.zeros(64, 1)
+        ps, qs = pe.step(ps, act), qe.step(qs, act)
+        assert np.allclose(ps.obs.numpy(), qs.obs.numpy(), rtol=0, atol=2e-6)
+        assert torch.equal(ps.done, qs.done)
+        assert torch.equal(ps.info["step_counter"], qs.info["step_counter"])
+        assert torch.equal(ps.info["truncated"], qs.info["truncated"])
+        assert torch.equal(ps.data["step_count"], qs.data["step_count"])

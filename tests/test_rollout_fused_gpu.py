@@ -160,3 +160,41 @@ def test_fused_rollout_event_stream_vs_oracle(dev):
             assert int(ro.done.sum()) > N and int(ro.truncated.sum()) > 0
             c = info["critic"].numpy().mean()
             assert np.allclose(m["losses/critic/mean"].item(), c, rtol=3e-3)
+
+
+def test_normal_observation_law_runs_stepwise_and_matches_the_oracle(dev):
+    """`MockEnv(obs_law="normal")` (the reference mock's law, `mock_env.py:43,53`) is evaluated
+    with torch ops: no fused env step, no one-launch rollout — and a whole `ppo_step` on it
+    still matches the oracle: events exact, observations to the last ulp of log / cos."""
+    from nnx_ppo_amd import _lib, config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+    from oracle import envs as oe
+    from oracle import keys as okeys
+    from oracle import networks as on
+    from oracle import ppo as op
+
+    N, T = 128, 8
+    with config.use_compute_dtype("bf16"):
+        env = EpisodeWrapper(MockEnv(5, 1, max_steps=5, obs_law="normal"), 20)
+        oenv = oe.EpisodeWrapper(oe.MockEnv(5, 1, max_steps=5, obs_law="normal"), 20)
+        net = factories.make_mlp_actor_critic(5, 1, [64] * 4, [256] * 2, Rngs(3))
+        ts = ppo.new_training_state(env, net, N, 3, 1e-3, device=dev)
+        onet = on.from_product(net)
+        ots = op.new_training_state(oenv, onet, N, 3, okeys, 1e-3)
+        with _lib.profiler as prof:
+            ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 1, 2)
+        used = {name for name, *_ in prof.records}
+        assert "mi_rollout_mock_ws_bf16" not in used and "mi_mock_env_step" not in used
+        ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 1, 2, okeys)
+        assert np.allclose(ts.env_states.obs.cpu().numpy(), ots.env_states.obs.numpy(),
+                           rtol=0, atol=4e-6)
+        assert torch.equal(ts.env_states.data["step_count"].cpu(),
+                           ots.env_states.data["step_count"])
+        assert torch.equal(ts.env_states.info["step_counter"].cpu(),
+                           ots.env_states.info["step_counter"])
+        c = info["critic"].numpy().mean()
+        assert np.allclose(m["losses/critic/mean"].item(), c, rtol=3e-3)
