@@ -767,6 +767,28 @@ int mi_rollout_mock_ws_bf16(
     int64_t* env_step_count_out, int64_t* wrap_step_counter_out, float* obs_out,
     float* reward_out, mi_stream_t stream);
 
+/* The same rollout under make_gru_actor_critic's network (`recurrent.py:89-161` contract;
+ * the recurrent actor of mi_gru_policy_step_bf16 in the action-trunk workgroups): the carry
+ * h [N][H] stays in registers / LDS for the T steps and is reset to zeros where a step ends an
+ * episode (`rollout.py:41-44`, GRU.reset_state).  Network arguments as
+ * mi_gru_policy_step_bf16 (class: mi_gru_policy_step_supported), the rest as
+ * mi_rollout_mock_ws_bf16; h_out (the carry after the last reset select) must not alias h_in.
+ * Bit-identical to the stepwise launches. */
+int mi_rollout_mock_gru_ws_bf16(
+    const int64_t* env_key, const int64_t* env_step_count, const int64_t* wrap_step_counter,
+    const float* obs0, const int64_t* reset_key, int64_t max_steps, int64_t max_len, int64_t T,
+    int64_t N, int64_t K0, int64_t H, int64_t A2, const float* norm_mean, const float* norm_m2,
+    const float* norm_count, float norm_eps, const void* w_in, const float* b_in,
+    const void* w_proj, const float* b_proj, const float* w_h, const float* b_hn,
+    const void* w_out, const float* b_out, const float* h_in, float* h_out, int64_t Lc,
+    const void* const* c_w, const float* const* c_bias, const int64_t* c_dims,
+    const int64_t* c_acts, const uint64_t* rng_state, uint64_t offset_add, float min_std,
+    float std_scale, float entropy_weight, int deterministic, float* obs_seq,
+    float* next_obs_seq, float* reward_seq, uint8_t* done_seq, uint8_t* trunc_seq,
+    float* raw_seq, float* action_seq, float* loglik_seq, float* mu_seq, float* sigma_seq,
+    float* value_seq, int64_t* env_key_out, int64_t* env_step_count_out,
+    int64_t* wrap_step_counter_out, float* obs_out, float* reward_out, mi_stream_t stream);
+
 /* ---- e: one-shot peer exchange (new; the reference is single-device) -------- */
 
 /* Env-sharded data parallelism (BASELINE.json north_star): one process per

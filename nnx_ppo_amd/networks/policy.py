@@ -625,3 +625,92 @@ class GRUActorCritic(Sequential):
                                 "value": {i: {} for i in range(len(c_layers))}}},
             rollout_extras=[obs, {"action": [None, None, None, r["raw"]],
                                   "value": [None] * len(c_layers)}])
+
+    # ---- the whole rollout in one launch (rollout.py:48-73) ---------------------------
+    def unroll_fused(self, env, env_state, network_state, unroll_length: int, reset_key):
+        """`MLPActorCritic.unroll_fused` for the recurrent actor-critic
+        (`mi_rollout_mock_gru_ws_bf16`): the GRU carry stays on chip for the T steps and is
+        reset (zeros) where a step ends an episode.  Every leaf bit-identical to the stepwise
+        rollout; None when the fused form does not apply."""
+        if not (FUSED and FUSED_ROLLOUT):
+            return None
+        from .. import random as rnd
+        from ..algorithms.types import State, Transition
+        from ..envs.constants import constant
+        from ..envs.synthetic import MockEnv
+        from ..wrappers.episode_wrapper import EpisodeWrapper
+
+        if type(env) is not EpisodeWrapper or type(env.env) is not MockEnv \
+                or not isinstance(env.env.obs_size, int) or rnd._TORCH_ONLY[0] \
+                or env.env.obs_law != "uniform" or not isinstance(env_state, State):
+            return None
+        obs = env_state.obs
+        if not self._fusable(obs) or unroll_length < 1 or obs.shape[1] != env.env.obs_size:
+            return None
+        N, K0 = obs.shape
+        data, info = env_state.data, env_state.info
+        if not (isinstance(data, dict) and isinstance(info, dict)
+                and set(data) == {"key", "step_count"}
+                and set(info) == {"step_counter", "truncated"}) or env_state.metrics:
+            return None
+        key, count, counter = data["key"], data["step_count"], info["step_counter"]
+        for t in (key, count, counter):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64
+                    and t.shape == (N,)):
+                return None
+        if not (isinstance(reset_key, torch.Tensor) and reset_key.is_cuda
+                and reset_key.dtype == torch.int64 and reset_key.dim() == 0):
+            return None
+        d_in, gru, d_out, sampler, c_layers = self._parts()
+        if sampler.noise_override is not None or getattr(gru, "trainable_initial_state", False):
+            return None
+        a_state = network_state[-1]["action"]
+        v_state = network_state[-1]["value"]
+        h = a_state[1]
+        if not (isinstance(h, torch.Tensor) and h.is_cuda and h.dtype == torch.float32
+                and h.shape == (N, gru.hidden_features)):
+            return None
+        proj = gru._proj()
+        dense_chain.refresh([d_in, proj, d_out, *c_layers])
+        n = self._norm
+        T = int(unroll_length)
+        off = sampler._pending
+        sampler._pending += T
+        c = lambda t: t if t.is_contiguous() else t.contiguous()
+        r = ops.rollout_mock_gru_ws(
+            c(key), c(count), c(counter), c(obs), reset_key, env.env.max_steps, env.max_len, T,
+            (n.mean.value, n.M2.value, n.counter.value, n.epsilon),
+            (d_in._ff, d_in.bias.data),
+            (proj._ff, proj.bias.data if proj.bias is not None else None),
+            gru.w_h.data, gru.b_hn.data, (d_out._ff, d_out.bias.data), c(h),
+            ([l._ff for l in c_layers], [dense_chain._bias(l) for l in c_layers],
+             [c_layers[0].in_features] + [l.out_features for l in c_layers],
+             [l.act_code for l in c_layers]),
+            sampler._state(obs.device), off, deterministic=sampler.deterministic,
+            **sampler._kw())
+        value = r["value"]
+        if value.shape[-1] == 1:
+            value = value.squeeze(-1)
+        a_metrics = {0: {}, 1: {}, 2: {}, 3: {"mu": r["mu"], "sigma": r["sigma"]}}
+        rollout = Transition(
+            obs=r["obs"],
+            network_output=PPONetworkOutput(actions=r["action"],
+                                            loglikelihoods=r["log_likelihood"],
+                                            value_estimates=value),
+            rewards=r["reward"], done=r["done"], truncated=r["truncated"],
+            next_obs=r["next_obs"],
+            metrics={"env": {}, "net": {0: {}, 1: {"action": a_metrics,
+                                                   "value": {i: {} for i in
+                                                             range(len(c_layers))}}}},
+            rollout_extras=[r["obs"], {"action": [None, None, None, r["raw"]],
+                                       "value": [None] * len(c_layers)}])
+        dev = obs.device
+        final_env = State(
+            data={"key": r["key_out"], "step_count": r["count_out"]}, obs=r["obs_out"],
+            reward=r["reward_out"], done=constant((N,), torch.float32, 0.0, dev), metrics={},
+            info={"step_counter": r["counter_out"],
+                  "truncated": constant((N,), torch.bool, 0, dev)})
+        next_action = list(a_state)
+        next_action[1] = r["h_out"]
+        final_net = [(), {"action": next_action, "value": list(v_state)}]
+        return final_net, final_env, rollout

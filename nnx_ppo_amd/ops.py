@@ -1493,6 +1493,61 @@ def rollout_mock_ws(env_key, env_step_count, wrap_step_counter, obs0, reset_key,
     return out
 
 
+def rollout_mock_gru_ws(env_key, env_step_count, wrap_step_counter, obs0, reset_key,
+                        max_steps: int, max_len: int, T: int, norm, dense_in, proj, w_h, b_hn,
+                        dense_out, h_in, critic, rng_state, offset_add: int, *, min_std: float,
+                        std_scale: float, entropy_weight: float, deterministic: bool) -> dict:
+    """`rollout_mock_ws` for the recurrent actor-critic of `gru_policy_step`
+    (`mi_rollout_mock_gru_ws_bf16`): the carry rides in the launch; `h_out` is the carry after
+    the last reset select."""
+    N, K0 = obs0.shape
+    H = h_in.shape[1]
+    dev = obs0.device
+    c_w, c_b, c_dims, c_acts = critic
+    Lc = len(c_w)
+    A2 = dense_out[1].shape[0]
+    A = A2 // 2
+    for t in (env_key, env_step_count, wrap_step_counter):
+        _need(t.dtype == i64 and t.shape == (N,) and t.is_contiguous(),
+              "rollout_mock_gru_ws: env state leaves must be contiguous int64 [N]")
+    _need(reset_key.dtype == i64 and reset_key.numel() == 1, "rollout_mock_gru_ws: one int64 key")
+    _need(h_in.shape == (N, H) and h_in.is_contiguous() and w_h.shape == (H, 3 * H)
+          and obs0.is_contiguous(), "rollout_mock_gru_ws: carry [N, H], kernel [H, 3H]")
+    mk = lambda *sh: torch.empty(*sh, dtype=f32, device=dev)
+    out = dict(
+        obs=mk(T, N, K0), next_obs=mk(T, N, K0), reward=mk(T, N),
+        done=torch.empty(T, N, dtype=torch.bool, device=dev),
+        truncated=torch.empty(T, N, dtype=torch.bool, device=dev),
+        raw=mk(T, N, A), action=mk(T, N, A), log_likelihood=mk(T, N), mu=mk(T, N, A),
+        sigma=mk(T, N, A), value=mk(T, N, c_dims[-1]), h_out=mk(N, H),
+        key_out=torch.empty_like(env_key), count_out=torch.empty_like(env_step_count),
+        counter_out=torch.empty_like(wrap_step_counter), obs_out=mk(N, K0), reward_out=mk(N))
+    P = ctypes.c_void_p * Lc
+    i64s = lambda v: (ctypes.c_int64 * len(v))(*[int(q) for q in v])
+    n_mean, n_m2, n_cnt, n_eps = norm if norm is not None else (None, None, None, 0.0)
+    if profiler.active:
+        flop = K0 * H + 6 * H * H + H * A2 + sum(c_dims[l] * c_dims[l + 1] for l in range(Lc))
+        profiler.next_flops = 2.0 * T * N * flop
+        profiler.next_bytes = 4.0 * T * N * (2 * K0 + 4 * A + 2 + c_dims[-1]) + 2.0 * T * N
+    check(lib().mi_rollout_mock_gru_ws_bf16(
+        ptr(env_key, i64), ptr(env_step_count, i64), ptr(wrap_step_counter, i64), ptr(obs0, f32),
+        ptr(reset_key.reshape(1), i64), int(max_steps), int(max_len), int(T), N, K0, H, A2,
+        ptr(n_mean, f32), ptr(n_m2, f32), ptr(n_cnt, f32), float(n_eps),
+        ptr(dense_in[0], bf16), ptr(dense_in[1], f32), ptr(proj[0], bf16), ptr(proj[1], f32),
+        ptr(w_h, f32), ptr(b_hn, f32), ptr(dense_out[0], bf16), ptr(dense_out[1], f32),
+        ptr(h_in, f32), ptr(out["h_out"], f32),
+        Lc, P(*[ptr(t) for t in c_w]), P(*[ptr(t) for t in c_b]), i64s(c_dims), i64s(c_acts),
+        ptr(rng_state), int(offset_add), float(min_std), float(std_scale), float(entropy_weight),
+        int(bool(deterministic)), ptr(out["obs"], f32), ptr(out["next_obs"], f32),
+        ptr(out["reward"], f32), ptr(out["done"].view(u8)), ptr(out["truncated"].view(u8)),
+        ptr(out["raw"], f32), ptr(out["action"], f32), ptr(out["log_likelihood"], f32),
+        ptr(out["mu"], f32), ptr(out["sigma"], f32), ptr(out["value"], f32),
+        ptr(out["key_out"], i64), ptr(out["count_out"], i64), ptr(out["counter_out"], i64),
+        ptr(out["obs_out"], f32), ptr(out["reward_out"], f32), stream()),
+        "mi_rollout_mock_gru_ws_bf16")
+    return out
+
+
 def key_permutations(key: torch.Tensor, n_perm: int, n: int) -> torch.Tensor:
     """int64 [n_perm, n]: row e = random.permutation(random.fold_in(key, e), n)."""
     _need(key.dtype == i64 and key.numel() == 1, "key_permutations: one int64 key")

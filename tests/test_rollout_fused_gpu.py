@@ -198,3 +198,80 @@ def test_normal_observation_law_runs_stepwise_and_matches_the_oracle(dev):
                            ots.env_states.info["step_counter"])
         c = info["critic"].numpy().mean()
         assert np.allclose(m["losses/critic/mean"].item(), c, rtol=3e-3)
+
+
+@pytest.mark.parametrize("H,critic_h,N,T,max_steps,max_len",
+                         [(64, [256, 256], 64, 10, 3, 50), (64, [256, 256], 100, 7, 6, 4),
+                          (64, [256, 256], 4096, 30, 5, 1000), (128, [128, 128], 96, 6, 2, 9),
+                          (64, [64, 64], 9000, 3, 2, 7)])
+def test_fused_gru_rollout_equals_stepwise(dev, monkeypatch, H, critic_h, N, T, max_steps,
+                                           max_len):
+    """`mi_rollout_mock_gru_ws_bf16` (the recurrent actor of make_gru_actor_critic with its
+    carry on chip for the T steps, reset to zeros on done) against the stepwise rollout
+    (mi_gru_policy_step_bf16 + mi_mock_episode_step_select + the carry's reset select):
+    Transition, env state AND the carry bit-identical, two rollouts in a row."""
+    from nnx_ppo_amd import _lib, config
+    from nnx_ppo_amd import random as rnd
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.algorithms.rollout import unroll_env
+    from nnx_ppo_amd.envs import MockEnv
+    from nnx_ppo_amd.networks import factories, policy
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    out = []
+    with config.use_compute_dtype("bf16"):
+        for fused in (True, False):
+            monkeypatch.setattr(policy, "FUSED_ROLLOUT", fused)
+            env = EpisodeWrapper(MockEnv(5, 1, max_steps=max_steps), max_len)
+            net = factories.make_gru_actor_critic(5, 1, H, critic_h, Rngs(13))
+            ts = ppo.new_training_state(env, net, N, 13, 1e-3, device=dev)
+            key = rnd.key(77, device=dev)
+            res = []
+            net_state, env_state = ts.network_states, ts.env_states
+            for it in range(2):
+                with _lib.profiler as prof:
+                    net_state, env_state, tr = unroll_env(env, env_state, net, net_state, T,
+                                                          rnd.fold_in(key, it))
+                used = {name for name, *_ in prof.records}
+                assert ("mi_rollout_mock_gru_ws_bf16" in used) == fused, used
+                if fused and it == 1:
+                    assert used == {"mi_rollout_mock_gru_ws_bf16"}, used
+                res.append((net_state, env_state, tr))
+            out.append(res)
+    ra, rb = out
+    assert _same_tree(ra, rb) >= 2 * 19     # + the carry
+    h = ra[1][0][-1]["action"][1]
+    assert h.shape == (N, H)
+    done_last = ra[1][2].done[-1]
+    assert float(h[done_last].abs().sum()) == 0.0   # reset rows carry zeros
+    if bool((~done_last).any()):
+        assert float(h[~done_last].abs().sum()) > 0  # the others carry their state
+    assert int(ra[0][2].done.sum()) > 0
+
+
+def test_fused_gru_rollout_ppo_step_equals_stepwise(dev, monkeypatch):
+    from nnx_ppo_amd import config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.networks import factories, policy
+    from nnx_ppo_amd.networks.types import Rngs
+
+    out = []
+    with config.use_compute_dtype("bf16"):
+        for fused in (True, False):
+            monkeypatch.setattr(policy, "FUSED_ROLLOUT", fused)
+            env = cartpole_shaped(max_steps=5)
+            from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+            env = EpisodeWrapper(env, 1000)
+            net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(42))
+            ts = ppo.new_training_state(env, net, 512, 42, 3e-4, device=dev)
+            ms = []
+            for _ in range(2):
+                ts, m = ppo.ppo_step(env, ts, 512, 30, 0.95, 0.99, 0.2, True, False, 2, 2)
+                ms.append({k: float(v) for k, v in m.items()})
+            out.append((ts.optimizer.params.clone(), ms, ts.network_states, ts.env_states))
+    (pa, la, na, ea), (pb, lb, nb, eb) = out
+    assert torch.equal(pa, pb) and la == lb
+    _same_tree(na, nb)
+    _same_tree(ea, eb)
