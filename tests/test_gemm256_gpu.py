@@ -92,8 +92,8 @@ def test_gemm256_asymmetric_identity(dev):
     assert float(y_bf[2 * K:].float().abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("M,K,N", [(8192, 512, 512), (12288, 256, 256), (8192, 256, 512),
-                                   (9216, 384, 136), (8192, 128, 264)])
+@pytest.mark.parametrize("M,K,N", [(8192, 512, 512), (12288, 256, 256), (8192, 256, 1024),
+                                   (9216, 768, 264), (8192, 520, 512)])
 def test_dw256_vs_fp64(dev, M, K, N):
     """dW / db on 256 x 256 tiles (tn256_kernel): fp64 on the same bf16-rounded operands,
     bitwise reproducible, and the grouped form with a thin problem beside it."""
@@ -123,7 +123,11 @@ def test_dw256_vs_fp64(dev, M, K, N):
     gw_b, gb_b = torch.zeros(N, 3, device=dev), torch.zeros(3, device=dev)
     ops.dense_bwd_dw_grouped_bf16([(x_bf, dz_bf, gw_a, gb_a), (dz_bf, dz2_bf, gw_b, gb_b)],
                                   accumulate=True)
-    assert torch.equal(gw_a, gw) and torch.equal(gb_a, gb)
+    if -(-K // 256) * -(-N // 256) >= 4:   # on the 256-tile kernel: the same split either way
+        assert torch.equal(gw_a, gw) and torch.equal(gb_a, gb)
+    else:                                   # 128-row kernel: the split follows the group's tiles
+        assert np.allclose(gw_a.cpu().numpy(), gw64.numpy(), rtol=1e-4, atol=2e-5 * s)
+        assert np.allclose(gb_a.cpu().numpy(), gb64.numpy(), rtol=1e-4, atol=2e-5 * s)
     assert np.allclose(gw_b.cpu().numpy(), (_r(dz).t() @ _r(dz2)).numpy(), rtol=1e-4,
                        atol=2e-5 * s)
 
