@@ -161,7 +161,11 @@ __device__ __forceinline__ void ws_rollout_body(const WsChain& c, const RolloutE
   for (int row = tid >> 5; row < ROWS; row += kWsThreads >> 5)
     for (int k = K0 + (tid & 31); k < 32; k += 32) bufX[row * XROW + k] = (bf16_t)0.0f;
 
-  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);  // [ROWS][N_out]
+  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);  // [SB][ROWS][N_out]
+  // steps whose head rows share one sampler pass: one row per thread, 4096 stash floats
+  int SB = kWsThreads / ROWS;
+  if (SAMP && SB * ROWS * N_out > 4096) SB = 4096 / (ROWS * N_out);
+  if (SB < 1) SB = 1;
 
   for (int64_t tile = bid; tile < ntiles; tile += nblk) {
     const int64_t i0 = tile * ROWS;
@@ -331,28 +335,35 @@ __device__ __forceinline__ void ws_rollout_body(const WsChain& c, const RolloutE
           if (4 * lq + e < N_out) {
             const float v = ah[e] + BO[e];
             if (!SAMP && gi < N) c.out[(tN + gi) * N_out + 4 * lq + e] = v;
-            if (SAMP) ms_s[row * N_out + 4 * lq + e] = v;
+            if (SAMP) ms_s[((t % SB) * ROWS + row) * N_out + 4 * lq + e] = v;
           }
         }
       }
-      if (SAMP) {
-        __syncthreads();  // the head's rows are in the stash
-        if (tid < ROWS && i0 + tid < N) {
+      if (SAMP && ((t + 1) % SB == 0 || t == T - 1)) {
+        // The sampler row function is a ~2 500-cycle chain of transcendentals for ONE thread
+        // per row: run once per step it kept 32 of the 512 threads busy for a third of the
+        // step.  Nothing downstream waits for an action (the env of this launch does not read
+        // it), so the head's rows of SB steps wait in the stash and are sampled together.
+        __syncthreads();  // the head's rows of this step are in the stash
+        const int slot = tid / ROWS, row = tid % ROWS;
+        const int ts = t - (t % SB) + slot;  // the step whose rows sit in `slot`
+        if (slot < SB && ts <= t && i0 + row < N) {
           // the step's own noise offset and [N]-row output blocks (sampling_layers.py:82-147:
           // one `_next_offset()` per call of the stepwise rollout)
+          const int64_t sN = (int64_t)ts * N;
           mippo_sampler::FwdParams p = c.samp;
           const int A = p.A;
-          p.noise.offset_add += (uint64_t)t;
-          if (p.raw_out) p.raw_out += tN * A;
-          if (p.action) p.action += tN * A;
-          if (p.mu_out) p.mu_out += tN * A;
-          if (p.sigma_out) p.sigma_out += tN * A;
-          if (p.ll) p.ll += tN;
-          if (p.reg) p.reg += tN;
-          mippo_sampler::fwd_row(ms_s + tid * N_out, i0 + tid, p);
+          p.noise.offset_add += (uint64_t)ts;
+          if (p.raw_out) p.raw_out += sN * A;
+          if (p.action) p.action += sN * A;
+          if (p.mu_out) p.mu_out += sN * A;
+          if (p.sigma_out) p.sigma_out += sN * A;
+          if (p.ll) p.ll += sN;
+          if (p.reg) p.reg += sN;
+          mippo_sampler::fwd_row(ms_s + (slot * ROWS + row) * N_out, i0 + row, p);
         }
       }
-      __syncthreads();  // bufA / bufB / bufX / the stash are free for the next step
+      __syncthreads();  // bufA / bufB / bufX (and a sampled stash) are free for the next step
 #pragma unroll
       for (int u = 0; u < IN_PT; ++u) xin[u] = xnext[u];
       // ---- after the last step: the carried state (reset select applied) ----------------
@@ -498,7 +509,10 @@ __device__ __forceinline__ void ws_gru_rollout_body(const WsChain& c, const GruR
   }
   for (int row = tid >> 5; row < ROWS; row += kWsThreads >> 5)
     for (int k = K0 + (tid & 31); k < 32; k += 32) bufX[row * XROW + k] = (bf16_t)0.0f;
-  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);
+  float* const ms_s = reinterpret_cast<float*>(smem + Lds::stash);  // [SB][ROWS][N_out]
+  int SB = kWsThreads / ROWS;
+  if (SB * ROWS * N_out > 4096) SB = 4096 / (ROWS * N_out);
+  if (SB < 1) SB = 1;
 
   for (int64_t tile = bid; tile < ntiles; tile += nblk) {
     const int64_t i0 = tile * ROWS;
@@ -668,20 +682,26 @@ __device__ __forceinline__ void ws_gru_rollout_body(const WsChain& c, const GruR
         const int row = wave * 16 + li;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (4 * lq + e < N_out) ms_s[row * N_out + 4 * lq + e] = ao[e] + BO[e];
+          if (4 * lq + e < N_out)
+            ms_s[((t % SB) * ROWS + row) * N_out + 4 * lq + e] = ao[e] + BO[e];
       }
       __syncthreads();  // the head's rows are in the stash; every wave has read h'
-      if (tid < ROWS && i0 + tid < N) {
-        mippo_sampler::FwdParams p = c.samp;
-        const int A = p.A;
-        p.noise.offset_add += (uint64_t)t;
-        if (p.raw_out) p.raw_out += tN * A;
-        if (p.action) p.action += tN * A;
-        if (p.mu_out) p.mu_out += tN * A;
-        if (p.sigma_out) p.sigma_out += tN * A;
-        if (p.ll) p.ll += tN;
-        if (p.reg) p.reg += tN;
-        mippo_sampler::fwd_row(ms_s + tid * N_out, i0 + tid, p);
+      if ((t + 1) % SB == 0 || t == T - 1) {  // SB steps' rows sampled together (see above)
+        const int slot = tid / ROWS, row = tid % ROWS;
+        const int ts = t - (t % SB) + slot;
+        if (slot < SB && ts <= t && i0 + row < N) {
+          const int64_t sN = (int64_t)ts * N;
+          mippo_sampler::FwdParams p = c.samp;
+          const int A = p.A;
+          p.noise.offset_add += (uint64_t)ts;
+          if (p.raw_out) p.raw_out += sN * A;
+          if (p.action) p.action += sN * A;
+          if (p.mu_out) p.mu_out += sN * A;
+          if (p.sigma_out) p.sigma_out += sN * A;
+          if (p.ll) p.ll += sN;
+          if (p.reg) p.reg += sN;
+          mippo_sampler::fwd_row(ms_s + (slot * ROWS + row) * N_out, i0 + row, p);
+        }
       }
       // the carry of the next step: reset-on-done (rollout.py:41-44; GRU.reset_state = zeros)
 #pragma unroll
