@@ -665,7 +665,13 @@ int mi_policy_ws_bwd_bf16(
  * path; the four scalars differ from it in fp64 summation order only.
  * Supported: T <= 32, B % 64 == 0, B <= 2048, scalar value head, the one-launch trunk menu at
  * 64-row tiles, masks given.  workspace: mi_policy_ws_bwd_gae_workspace_bytes(T * B) bytes,
- * zeroed once (the launch re-arms it). */
+ * zeroed once (the launch re-arms it).
+ * `comm` (nullable; section e): an env-sharded run's one-shot communicator.  The advantage
+ * statistics are then those of the GLOBAL minibatch (`ppo.py:477-480` over world x B envs;
+ * SURVEY 8e (2)): a publishing workgroup hands its group's partial to every rank's region,
+ * the consumers sum world x B/64 partials in (rank, group) order — the same bits on every
+ * rank — and the launch counts as one collective of the communicator.  A sharded rank then
+ * launches what a single GPU launches (no GAE / exchange / loss launches of their own). */
 int64_t mi_policy_ws_bwd_gae_workspace_bytes(int64_t M);
 int mi_policy_ws_bwd_gae_supported(int64_t T, int64_t B, int64_t La, const int64_t* a_dims,
                                    const int64_t* a_acts, int64_t Lc, const int64_t* c_dims,
@@ -682,7 +688,7 @@ int mi_policy_ws_bwd_gae_bf16(
     const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
     const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
     const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
-    const void* const* a_mask, const void* const* c_mask, mi_stream_t stream);
+    const void* const* a_mask, const void* const* c_mask, void* comm, mi_stream_t stream);
 /* Exactly one of loss_out / partials_out above is given.  With partials_out (double
  * [T * B / 64][4], caller-owned) the launch leaves its per-tile fp64 partials there and does
  * not sum them — the sum at the tail of the launch is 2.5-3 us on its critical path for four
@@ -852,7 +858,14 @@ int mi_adam_step_allreduce_f32(void* comm, float* params, float* grads, float* m
                                int64_t n_shadows, const int64_t* shadow_begin,
                                const int64_t* shadow_K, const int64_t* shadow_N,
                                void* const* w_bf, void* const* wt_bf, void* const* frag_fwd,
-                               void* const* frag_bwd, mi_stream_t stream);
+                               void* const* frag_bwd, int64_t n_slab_leaves,
+                               const void* const* slab_ptr, const int64_t* n_slabs,
+                               const int64_t* slab_K, const int64_t* slab_N,
+                               const int64_t* gw_offset, const int64_t* gb_offset,
+                               const int64_t* gb_first, mi_stream_t stream);
+/* (n_slab_leaves > 0: the pending split-M slabs of mi_dense_bwd_dw_grouped_slabs_bf16 are
+ * summed into this rank's gradient chunk before it is pushed — mi_adam_step_slabs_f32's sums
+ * in the same order — so a sharded gradient step is forward, backward, dW and this launch.) */
 
 #ifdef __cplusplus
 }

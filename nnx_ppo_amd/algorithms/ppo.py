@@ -43,6 +43,9 @@ from .types import LoggingLevel, TrainingState, Transition
 # at [30, 1024], tools/microbench_gae_loss.py).  MIPPO_FUSED_GAE_LOSS=0: two launches (A/B
 # timing; also what a sharded run uses — the advantage statistics are exchanged in between).
 FUSED_GAE_LOSS = os.environ.get("MIPPO_FUSED_GAE_LOSS", "1") != "0"
+# MIPPO_SHARDED_GAE_IN_BWD=0: a sharded run keeps GAE / statistics exchange / loss as launches
+# of their own in front of the backward (A/B, and the reference form of the equivalence tests)
+SHARDED_GAE_IN_BWD = os.environ.get("MIPPO_SHARDED_GAE_IN_BWD", "1") != "0"
 
 
 def default_config() -> TrainConfig:
@@ -464,7 +467,13 @@ def ppo_loss(
         reg_flat = None if reg_seq is None else reg_seq.reshape(-1)
         fused_loss = (FUSED_GAE_LOSS and not parallel.is_distributed()
                       and ops.gae_ppo_loss_supported(T, B))
-        gae_bwd = (fused_loss and backward and LoggingLevel.CRITIC_EXTRA not in logging_level
+        # sharded over the one-shot transport the statistics cross the ranks INSIDE the
+        # backward launch (mi_policy_ws_bwd_gae_bf16 with the communicator): a sharded rank
+        # launches what a single GPU launches.  Over RCCL (host collectives) the three
+        # launches with the all-reduce between them remain.
+        in_bwd_ok = fused_loss or (FUSED_GAE_LOSS and parallel.peer_comm() is not None
+                                   and SHARDED_GAE_IN_BWD)
+        gae_bwd = (in_bwd_ok and backward and LoggingLevel.CRITIC_EXTRA not in logging_level
                    and fused is not None and hasattr(networks, "replay_backward_gae")
                    and networks.gae_backward_supported(ctx, T, B))
         if gae_bwd:

@@ -82,9 +82,11 @@ class PeerComm:
         return out
 
     def adam_step_allreduce(self, params, grads, m, v, step, *, lr, b1, b2, eps, weight_decay,
-                            shadows) -> bool:
+                            shadows, slabs=None) -> bool:
         """`ops.adam_step(..., begin_next=True)` with the gradient all-reduce-mean inside
-        the launch.  False (nothing launched) if the arena does not fit one slot."""
+        the launch.  `slabs`: pending dW slabs in `ops.adam_step`'s form — summed into this
+        rank's gradient before it is pushed (no reduction launch in front of the exchange).
+        False (nothing launched) if the arena does not fit one slot."""
         n = params.numel()
         if n * 4 > self.slot_bytes:
             return False
@@ -103,9 +105,21 @@ class PeerComm:
             P(*[ptr(t, bf) for t in col(3)]) if ns else None,
             P(*[ptr(t, bf) for t in col(4)]) if ns else None,
             P(*[ptr(t, bf) for t in col(5)]) if ns else None,
-            P(*[ptr(t, bf) for t in col(6)]) if ns else None, stream()),
+            P(*[ptr(t, bf) for t in col(6)]) if ns else None, *self._slab_args(slabs), stream()),
             "mi_adam_step_allreduce_f32")
         return True
+
+    @staticmethod
+    def _slab_args(slabs):
+        if slabs is None:
+            return (0, None, None, None, None, None, None, None)
+        sp, S, Ks, Ns, gw_off, gb_off = slabs[:6]
+        b_lo = slabs[6] if len(slabs) > 6 else None
+        nl = len(Ks)
+        Pl = ctypes.c_void_p * nl
+        Il = ctypes.c_int64 * nl
+        return (nl, Pl(*sp), Il(*S), Il(*Ks), Il(*Ns), Il(*gw_off), Il(*gb_off),
+                Il(*b_lo) if b_lo is not None and any(b_lo) else None)
 
     # ---- host-side checks (synchronise) --------------------------------------------------
     def status(self) -> tuple[int, int]:

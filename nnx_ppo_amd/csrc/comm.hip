@@ -25,22 +25,13 @@
 // error and finish with garbage instead of hanging the GPU; the host reads the count
 // (mi_comm_status) and raises.
 #include "bf16_common.h"
+#include "comm_common.h"
 #include "optim_common.h"
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kMaxWorld = 16;
-constexpr int64_t kChunkBytes = 4096;     // one block-pass: 256 threads x 16 B
-constexpr int64_t kHeaderBytes = 4096;
-constexpr int kMaxBlocks = 256;
-
-struct CommHeader {
-  unsigned long long seq;      // collectives completed on this rank
-  unsigned int ticket;         // blocks finished in the running collective
-  unsigned int errors;         // spins that timed out (sticky)
-  unsigned long long timeout;  // wall-clock ticks (100 MHz) a spin may last
-};
+using namespace mippo_comm;
+constexpr int kThreads = kCommThreads;
 
 struct Comm {                  // host object behind the opaque handle
   int rank, world;
@@ -50,25 +41,6 @@ struct Comm {                  // host object behind the opaque handle
   bool opened[kMaxWorld];
   unsigned int* error_word;    // caller-owned device word that mirrors hdr->errors (nullable)
 };
-
-struct CommDev {               // by value in the kernel arguments
-  int rank, world;
-  int64_t slot_bytes, chunks;
-  unsigned int* error_word;    // nullable: bumped with hdr->errors (mi_comm_set_error_word)
-  char* peer[kMaxWorld];
-};
-
-__host__ __device__ inline int64_t flags_off(const int64_t chunks, int world, int parity, int r) {
-  return kHeaderBytes + ((int64_t)(parity * world + r) * chunks) * 4;
-}
-__host__ __device__ inline int64_t slots_base(const int64_t chunks, int world) {
-  const int64_t f = kHeaderBytes + (int64_t)2 * world * chunks * 4;
-  return (f + 4095) / 4096 * 4096;
-}
-__host__ __device__ inline int64_t slot_off(const int64_t chunks, int world, int64_t slot_bytes,
-                                            int parity, int r) {
-  return slots_base(chunks, world) + (int64_t)(parity * world + r) * slot_bytes;
-}
 
 CommDev dev_view(const Comm* c) {
   CommDev d;
@@ -103,6 +75,28 @@ __device__ inline void push_chunk(const CommDev& c, int parity, unsigned int seq
   }
   // system-scope release by every storing thread (the stores of one wave to a peer are
   // not ordered with another wave's), then one lane raises the flags
+  __threadfence_system();
+  __syncthreads();
+  if (tid < c.world && tid != c.rank) {
+    unsigned int* flag = reinterpret_cast<unsigned int*>(
+        c.peer[tid] + flags_off(c.chunks, c.world, parity, c.rank)) + chunk;
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// push_chunk with the payload in LDS (a chunk = kChunkBytes / 16 = 256 16-byte pieces, one
+// per thread; the tail of a short chunk is zero-filled by the caller)
+__device__ inline void push_chunk_lds(const CommDev& c, int parity, unsigned int seq,
+                                      int64_t chunk, const float* __restrict__ src_lds,
+                                      int64_t nbytes) {
+  const int64_t off = slot_off(c.chunks, c.world, c.slot_bytes, parity, c.rank) +
+                      chunk * kChunkBytes;
+  const int tid = threadIdx.x;
+  const uint4 mine = reinterpret_cast<const uint4*>(src_lds)[tid];
+  for (int r = 0; r < c.world; ++r) {
+    if (r == c.rank) continue;
+    if ((int64_t)tid * 16 < nbytes) reinterpret_cast<uint4*>(c.peer[r] + off)[tid] = mine;
+  }
   __threadfence_system();
   __syncthreads();
   if (tid < c.world && tid != c.rank) {
@@ -151,20 +145,6 @@ __device__ inline float poison<float>() { return __builtin_nanf(""); }
 template <>
 __device__ inline double poison<double>() { return __builtin_nan(""); }
 
-// The collective counts itself once every block has finished (so a block that starts late
-// still reads the old `seq`).
-__device__ inline void finish(CommHeader* hdr, unsigned long long seq_new) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int blocks = gridDim.x;
-    if (__hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-        blocks - 1) {
-      hdr->seq = seq_new;
-      __hip_atomic_store(&hdr->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 allreduce_kernel(CommDev c, T* __restrict__ buf, int64_t n, T scale) {
@@ -199,7 +179,7 @@ allreduce_kernel(CommDev c, T* __restrict__ buf, int64_t n, T scale) {
     }
     __syncthreads();  // the flags of the next chunk are raised by other lanes
   }
-  finish(hdr, seq64);
+  comm_finish(hdr, seq64);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -226,7 +206,7 @@ allgather_kernel(CommDev c, const char* __restrict__ src, int64_t nbytes, char* 
     }
     __syncthreads();
   }
-  finish(hdr, seq64);
+  comm_finish(hdr, seq64);
 }
 
 // The optimiser step with the gradient exchange inside it: chunk by chunk, push this
@@ -242,6 +222,10 @@ adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
   constexpr int kPer = (int)(kChunkBytes / sizeof(float));  // 1024 elements = 4 passes of 256
   const int64_t nchunks = mippo::ceil_div(a.n, (int64_t)kPer);
   const float inv_world = 1.0f / (float)c.world;
+  // this rank's gradient chunk WITH the pending dW slabs summed in (mi_adam_step_slabs_f32's
+  // sums, the order of reduce_slabs_grouped_kernel): staged in LDS, pushed from there — the
+  // slab reduction needs no launch of its own in front of the exchange
+  __shared__ __attribute__((aligned(16))) float s_g[kChunkBytes / sizeof(float)];
   // Sticky: once a peer has failed to arrive (this launch or an earlier one) no update is
   // applied any more — parameters, moments and bf16 images keep their last good values and
   // the error word stops the run at this iteration's host sync (loop.IterationRunner.collect)
@@ -249,7 +233,18 @@ adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t e0 = ch * kPer;
     const int64_t cnt = a.n - e0 < kPer ? a.n - e0 : kPer;
-    if (!failed) push_chunk(c, parity, seq, ch, reinterpret_cast<const char*>(a.g + e0), cnt * 4);
+#pragma unroll
+    for (int pass = 0; pass < kPer; pass += kThreads) {
+      const int64_t i = e0 + pass + threadIdx.x;
+      float gv = 0.0f;
+      if (pass + threadIdx.x < cnt) {
+        gv = a.g[i];
+        if (a.slabs.n) gv = gv + mippo_optim::slab_sum(a, i, e0 + pass);
+      }
+      s_g[pass + threadIdx.x] = gv;
+    }
+    __syncthreads();
+    if (!failed) push_chunk_lds(c, parity, seq, ch, s_g, cnt * 4);
     const bool ok = !failed && wait_chunk(c, hdr, parity, seq, ch);  // lost peer: no more waits
     for (int64_t pass = 0; pass < cnt && ok; pass += kThreads) {
       const int64_t i = e0 + pass + threadIdx.x;
@@ -257,7 +252,7 @@ adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
         float s = 0.0f;
         for (int r = 0; r < c.world; ++r) {
           const float v = r == c.rank
-                              ? a.g[i]
+                              ? s_g[pass + threadIdx.x]
                               : reinterpret_cast<const float*>(
                                     c.peer[c.rank] +
                                     slot_off(c.chunks, c.world, c.slot_bytes, parity, r) +
@@ -270,7 +265,7 @@ adam_allreduce_kernel(CommDev c, mippo_optim::AdamArgs a) {
     __syncthreads();
   }
   mippo_optim::adam_end(a, st);
-  finish(hdr, seq64);
+  comm_finish(hdr, seq64);
 }
 
 int grid_for(int64_t nchunks) {
@@ -280,6 +275,17 @@ int grid_for(int64_t nchunks) {
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------
+
+namespace mippo_comm {
+bool dev_view_of(const void* comm, CommDev* out) {
+  if (!comm || !out) return false;
+  const Comm* c = static_cast<const Comm*>(comm);
+  for (int r = 0; r < c->world; ++r)
+    if (!c->peer[r]) return false;
+  *out = dev_view(c);
+  return true;
+}
+}  // namespace mippo_comm
 
 extern "C" int64_t mi_comm_handle_bytes(void) { return (int64_t)sizeof(hipIpcMemHandle_t); }
 
@@ -448,7 +454,10 @@ extern "C" int mi_adam_step_allreduce_f32(
     float b2, float eps, float weight_decay, int64_t* step, void* begin_next_ticket,
     int64_t n_shadows, const int64_t* shadow_begin, const int64_t* shadow_K,
     const int64_t* shadow_N, void* const* w_bf, void* const* wt_bf, void* const* frag_fwd,
-    void* const* frag_bwd, mi_stream_t stream) {
+    void* const* frag_bwd, int64_t n_slab_leaves, const void* const* slab_ptr,
+    const int64_t* n_slabs, const int64_t* slab_K, const int64_t* slab_N,
+    const int64_t* gw_offset, const int64_t* gb_offset, const int64_t* gb_first,
+    mi_stream_t stream) {
   MI_REQUIRE(comm, "mi_adam_step_allreduce_f32: null comm");
   Comm* c = static_cast<Comm*>(comm);
   COMM_READY(c, "mi_adam_step_allreduce_f32");
@@ -461,6 +470,26 @@ extern "C" int mi_adam_step_allreduce_f32(
                                        begin_next_ticket, n_shadows, shadow_begin, shadow_K,
                                        shadow_N, w_bf, wt_bf, frag_fwd, frag_bwd);
   if (rc) return rc;
+  MI_REQUIRE(n_slab_leaves >= 0 && n_slab_leaves <= mippo_optim::kMaxSlabLeaves,
+             "mi_adam_step_allreduce_f32: 0 <= n_slab_leaves <= %d", mippo_optim::kMaxSlabLeaves);
+  a.slabs.n = (int)n_slab_leaves;
+  for (int64_t l = 0; l < n_slab_leaves; ++l) {
+    MI_REQUIRE(slab_ptr && n_slabs && slab_K && slab_N && gw_offset && gb_offset && slab_ptr[l] &&
+                   n_slabs[l] >= 1 && slab_K[l] >= 1 && slab_N[l] >= 1 && gw_offset[l] >= 0 &&
+                   gw_offset[l] + slab_K[l] * slab_N[l] <= n &&
+                   (!gb_first || (gb_first[l] >= 0 && gb_first[l] < slab_N[l])) &&
+                   (gb_offset[l] < 0 ||
+                    gb_offset[l] + slab_N[l] - (gb_first ? gb_first[l] : 0) <= n),
+               "mi_adam_step_allreduce_f32: bad slab leaf %lld", (long long)l);
+    mippo_optim::SlabLeaf& lf = a.slabs.leaf[l];
+    lf.slabs = static_cast<const float*>(slab_ptr[l]);
+    lf.S = (int)n_slabs[l];
+    lf.KN = (int)(slab_K[l] * slab_N[l]);
+    lf.N = (int)slab_N[l];
+    lf.gw_off = gw_offset[l];
+    lf.gb_off = gb_offset[l];
+    lf.b_lo = gb_first ? (int)gb_first[l] : 0;
+  }
   hipLaunchKernelGGL(adam_allreduce_kernel, dim3(grid_for(mippo::ceil_div(n * 4, kChunkBytes))),
                      dim3(kThreads), 0, mippo::as_stream(stream), dev_view(c), a);
   return mippo::check_launch("mi_adam_step_allreduce_f32");

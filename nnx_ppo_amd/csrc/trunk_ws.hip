@@ -32,6 +32,7 @@
 #include "bf16_common.h"
 #include "sampler_math.h"
 
+#include "comm_common.h"
 #include "trunk_ws_fwd.h"
 
 namespace {
@@ -408,6 +409,15 @@ struct WsGae {
   int T, B;
   float gamma, lambda, clip, critic_weight;
   int normalize;
+  // Env-sharded run (world > 1; SURVEY 8e (2): the normalisation of `ppo.py:477-480` is over
+  // the GLOBAL minibatch): a publishing workgroup writes its group's partial into slot
+  // (parity, rank) of EVERY rank's one-shot region (comm.hip) and raises that group's flag
+  // there; the consumers wait for world x B/64 flags of their own region and sum the partials
+  // in (rank, group) order — every rank the same bits.  The launch counts as one collective
+  // of the communicator (comm_finish), so the two slot parities alternate with the other
+  // exchanges of the gradient step.
+  mippo_comm::CommDev cd;
+  int world;
 };
 // -DGAE_W_FIRST=1: every trunk's stationary fragments requested before the scan (measured:
 // the 256-wide value trunk then spills 29 registers to scratch, 66.4 -> 64.5 M env-steps/s)
@@ -610,6 +620,16 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
   if constexpr (GAE) {
     const WsGae& g = *gp;
     const int GB = g.B >> 6;  // env groups = row tiles per step
+    // sharded: this launch is collective number seq + 1 of the communicator (every workgroup
+    // reads the old count: it moves only once all of them have finished, comm_finish)
+    unsigned int x_seq = 0;
+    int x_parity = 0;
+    if (g.world > 1) {
+      const unsigned long long s64 =
+          reinterpret_cast<const mippo_comm::CommHeader*>(g.cd.peer[g.cd.rank])->seq + 1;
+      x_seq = (unsigned int)s64;
+      x_parity = (int)(s64 & 1);
+    }
     float* const sf = reinterpret_cast<float*>(smem + (size_t)wave * kGaeStageBytes);
     unsigned char* const sb = smem + (size_t)wave * kGaeStageBytes + kGaeMaxT * 64 * 4;
     if constexpr (SAMP) {
@@ -630,7 +650,24 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           s1 += __shfl_down(s1, off, 64);
           s2 += __shfl_down(s2, off, 64);
         }
-        if (lane == 0) {
+        if (g.world > 1) {
+          // lane q hands the partial to rank q (its own region included): payload, system
+          // release, then the group's flag (comm.hip: push_chunk)
+          const double b1 = __shfl(s1, 0, 64), b2 = __shfl(s2, 0, 64);
+          if (lane < g.world) {
+            using namespace mippo_comm;
+            char* region = g.cd.peer[lane];
+            double* dst = reinterpret_cast<double*>(
+                region + slot_off(g.cd.chunks, g.cd.world, g.cd.slot_bytes, x_parity, g.cd.rank) +
+                (int64_t)bid * 16);
+            __hip_atomic_store(dst, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 1, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            unsigned int* flag = reinterpret_cast<unsigned int*>(
+                region + flags_off(g.cd.chunks, g.cd.world, x_parity, g.cd.rank)) + bid;
+            __hip_atomic_store(flag, x_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        } else if (lane == 0) {
           // write-through (sc1) stores, drained, then the arrival (gae_loss.hip's hand-over)
           __hip_atomic_store(&g.sp[2 * bid], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&g.sp[2 * bid + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -662,6 +699,47 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
       float* const s_norm = reinterpret_cast<float*>(gsm + WsGaeLds::norm);
       if (wave == 0) {
         bool timed_out = false;
+        double t1 = 0.0, t2 = 0.0;
+        int n_ranks = 1;
+        if (g.world > 1) {
+          using namespace mippo_comm;
+          n_ranks = g.world;
+          char* own = g.cd.peer[g.cd.rank];
+          CommHeader* hdr = reinterpret_cast<CommHeader*>(own);
+          const unsigned long long limit = hdr->timeout;
+          const int total = g.world * GB;
+          bool late = hdr->errors != 0;  // a lost peer earlier: nothing is trusted any more
+          for (int idx = lane; idx < total && !late; idx += 64) {
+            const int q = idx / GB, gg = idx - q * GB;
+            const unsigned int* flag = reinterpret_cast<const unsigned int*>(
+                own + flags_off(g.cd.chunks, g.cd.world, x_parity, q)) + gg;
+            const unsigned long long t0 = wall_clock64();
+            while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
+                         x_seq) < 0) {
+              __builtin_amdgcn_s_sleep(2);
+              if (wall_clock64() - t0 > limit) {
+                atomicAdd(&hdr->errors, 1u);
+                if (g.cd.error_word) atomicAdd(g.cd.error_word, 1u);
+                __hip_atomic_fetch_add(g.arrive + 1, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                late = true;
+                break;
+              }
+            }
+          }
+          timed_out = __ballot(late) != 0ull;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: written by other devices
+          // the same tree over world x GB partials, (rank, group) order: lane-strided, then
+          // lane order — identical on every rank
+          for (int idx = lane; idx < total; idx += 64) {
+            const int q = idx / GB, gg = idx - q * GB;
+            const double* sp = reinterpret_cast<const double*>(
+                own + slot_off(g.cd.chunks, g.cd.world, g.cd.slot_bytes, x_parity, q) +
+                (int64_t)gg * 16);
+            t1 += __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            t2 += __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        } else {
         if (lane == 0) {
           // header words 3, 4 (zero in production): a spin limit in microseconds and a number
           // of arrivals to wait for beyond the real ones — the test hook that forces the
@@ -688,10 +766,10 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
         // acquire only: the partials may sit stale in this XCD's L2 from the previous launch
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // gae_loss_kernel's tree over the group partials: lane-strided, then lane order
-        double t1 = 0.0, t2 = 0.0;
         for (int gg = lane; gg < GB; gg += 64) {
           t1 += __hip_atomic_load(&g.sp[2 * gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           t2 += __hip_atomic_load(&g.sp[2 * gg + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -699,7 +777,7 @@ __device__ __forceinline__ void ws_bwd_body(const WsBwdChain& c, const int bid, 
           t2 += __shfl_down(t2, off, 64);
         }
         if (lane == 0) {
-          const double cnt = (double)g.T * (double)g.B;
+          const double cnt = (double)g.T * (double)g.B * (double)n_ranks;
           const double m = t1 / cnt;
           double var = t2 / cnt - m * m;
           if (var < 0.0) var = 0.0;
@@ -995,6 +1073,11 @@ policy_ws_bwd_gae_kernel(WsBwdChain a, WsBwdChain v, WsGae g, int n_value) {
   else
     ws_bwd_body<HA, NHA, 4, true, true, true>(a, (int)blockIdx.x - n_value,
                                               (int)gridDim.x - n_value, smem, &g, gsm);
+  // sharded: the launch counts as one collective once every workgroup has finished
+  if (g.world > 1)
+    mippo_comm::comm_finish(reinterpret_cast<mippo_comm::CommHeader*>(g.cd.peer[g.cd.rank]),
+                            reinterpret_cast<const mippo_comm::CommHeader*>(
+                                g.cd.peer[g.cd.rank])->seq + 1);
   // this workgroup's partials are out (write-through stores, drained) before it takes a ticket
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1409,10 +1492,21 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
     const void* const* a_aux, void* a_dz_last, void* const* a_dz_bf, int64_t Lc,
     const void* const* c_w, const int64_t* c_dims, const int64_t* c_acts,
     const void* const* c_aux, void* c_dz_last, void* const* c_dz_bf,
-    const void* const* a_mask, const void* const* c_mask, mi_stream_t stream) {
+    const void* const* a_mask, const void* const* c_mask, void* comm, mi_stream_t stream) {
   MI_REQUIRE(mean_and_std && extras && rewards && values && last_value && done && truncated &&
                  ll_new && ll_old && workspace && a_mask && c_mask,
              "mi_policy_ws_bwd_gae_bf16: null pointer");
+  mippo_comm::CommDev cd = {};
+  int world = 1;
+  if (comm) {  // env-sharded: the advantage statistics cross the ranks inside the launch
+    MI_REQUIRE(mippo_comm::dev_view_of(comm, &cd),
+               "mi_policy_ws_bwd_gae_bf16: communicator not connected (mi_comm_connect)");
+    world = cd.world;
+    MI_REQUIRE(world >= 1 && world <= mippo_comm::kMaxWorld && B / 64 <= cd.chunks &&
+                   (B / 64) * 16 <= cd.slot_bytes,
+               "mi_policy_ws_bwd_gae_bf16: %lld env groups do not fit the communicator's slots",
+               (long long)(B / 64));
+  }
   MI_REQUIRE((loss_out != nullptr) != (partials_out != nullptr),
              "mi_policy_ws_bwd_gae_bf16: exactly one of loss_out (summed in the launch) and "
              "partials_out (deferred: mi_policy_loss_finalize_f32)");
@@ -1442,7 +1536,7 @@ extern "C" int mi_policy_ws_bwd_gae_bf16(
                                                       kGaeHeaderBytes),
              reinterpret_cast<double*>(static_cast<char*>(workspace) + 64),
              static_cast<unsigned int*>(workspace), static_cast<unsigned int*>(workspace) + 1,
-             (int)T, (int)B, gamma, lambda, clip_range, critic_weight, normalize};
+             (int)T, (int)B, gamma, lambda, clip_range, critic_weight, normalize, cd, world};
   int64_t nv, na;
   ws_dual_split(M / 64, M / 64, &nv, &na, ws_gae_split_pct());
   const int64_t hv = c_dims[1], nhv = Lc - 2, ha = a_dims[1], nha = La - 2;

@@ -21,7 +21,7 @@ from typing import Any
 
 import torch
 
-from .. import config, ops
+from .. import config, ops, parallel
 from . import dense_chain
 from .adapter import PPOAdapter, _Fork, _can_fork
 from .containers import Sequential
@@ -498,7 +498,7 @@ class MLPActorCritic(Sequential):
             ms2, ex2, sampler._state(ms2.device), off, g_reg, da, dc, masks, rewards, values,
             last_values, done, truncated, ll_new, ll_old, reg, gamma, lambda_, normalize,
             clip_range, critic_weight, eps2=eps2, loss_out=loss_out, defer=defer,
-            **sampler._kw())
+            comm=parallel.peer_comm(), **sampler._kw())
         problems = []
         for ls, c, dz in ((c_layers, v_ctx, c_dz), (a_layers, a_ctx, a_dz)):
             for i in range(len(ls) - 1, -1, -1):

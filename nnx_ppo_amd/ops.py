@@ -886,8 +886,12 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
                         ll_old, reg, gamma: float, lambda_: float, normalize: bool,
                         clip_range: float, critic_weight: float, *, min_std: float,
                         std_scale: float, entropy_weight: float, eps2=None,
-                        loss_out: torch.Tensor | None = None, defer: list | None = None):
-    """`gae_ppo_loss` + `policy_bwd_bf16(ws=True, masks=...)` in ONE launch
+                        loss_out: torch.Tensor | None = None, defer: list | None = None,
+                        comm=None):
+    """`comm` (a `comm.PeerComm`): env-sharded run — the advantage statistics are exchanged
+    between the ranks INSIDE the launch (global-minibatch normalisation, `ppo.py:477-480`).
+
+    `gae_ppo_loss` + `policy_bwd_bf16(ws=True, masks=...)` in ONE launch
     (`mi_policy_ws_bwd_gae_bf16`): the GAE scan, the advantage statistics and the loss
     gradients are evaluated inside the backward's workgroups.  `[T, B]` operands as in
     `gae_ppo_loss`.  Returns (actor dz list, critic dz list, loss_out[4]); the dz images are
@@ -949,7 +953,8 @@ def policy_bwd_gae_bf16(mean_and_std, extras, rng_state, offset_add: int, g_reg:
         ptr(a_dz[La - 1], bf16), arr(a_dz[:La - 1], La - 1),
         Lc, arr(c_w, Lc), i64s(c_dims), i64s(c_acts), arr(c_aux[:Lc - 1], Lc - 1),
         ptr(c_dz[Lc - 1], bf16), arr(c_dz[:Lc - 1], Lc - 1),
-        arr(am[:La - 1], La - 1), arr(cm[:Lc - 1], Lc - 1), stream()),
+        arr(am[:La - 1], La - 1), arr(cm[:Lc - 1], Lc - 1),
+        None if comm is None else comm._h, stream()),
         "mi_policy_ws_bwd_gae_bf16")
     return a_dz, c_dz, loss_out
 

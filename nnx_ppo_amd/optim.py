@@ -108,21 +108,27 @@ class Optimizer:
         table = [(off, l.kernel.shape[0], l.kernel.shape[1], l._w_bf, l._wt_bf, l._ff, l._fb)
                  for l, off in shadowed]
         ops.slab_defer.arena = None
-        if parallel.is_distributed() or norm_out is not None or \
+        comm = parallel.peer_comm() if parallel.is_distributed() else None
+        # the one-shot exchange fused into Adam sums the pending slabs itself (per chunk, before
+        # the push); every other reader of the whole gradient needs them reduced first
+        fused_exchange = (comm is not None and norm_out is None
+                          and self.gradient_clipping is None
+                          and self.n * 4 <= comm.slot_bytes)
+        if (parallel.is_distributed() and not fused_exchange) or norm_out is not None or \
                 (self.gradient_clipping is not None and not have_norm):
             ops.flush_pending_slabs()  # somebody reads the whole gradient before Adam
         if parallel.is_distributed():
-            comm = parallel.peer_comm()
-            if comm is not None and norm_out is None and self.gradient_clipping is None and \
-                    comm.adam_step_allreduce(
-                        self.params, self.grads, self.m, self.v, self.step,
-                        lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
-                        weight_decay=self.weight_decay, shadows=table):
-                # exchange + mean + Adam + bf16 images + gradient zeroing: one launch
+            if fused_exchange and comm.adam_step_allreduce(
+                    self.params, self.grads, self.m, self.v, self.step,
+                    lr=self.learning_rate, b1=self.b1, b2=self.b2, eps=self.eps,
+                    weight_decay=self.weight_decay, shadows=table,
+                    slabs=self._pending_slabs()):
+                # slab sums + exchange + mean + Adam + bf16 images + gradient zeroing: one launch
                 self._clean = True
                 bump_param_epoch()
                 dense_chain.mark_fresh([l for l, _ in shadowed])
                 return
+            ops.flush_pending_slabs()
             parallel.allreduce_mean_(self.grads)
             have_norm = False
         gn = None

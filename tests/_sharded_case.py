@@ -11,9 +11,16 @@ What makes the two runs comparable value for value:
     process uses the union of the shards' slices, shard by shard (a global
     minibatch is the union of the local ones).
 What differs is floating-point summation order only."""
+import os
+
 import torch
 
-N, T, E, MB = 128, 8, 2, 2
+# MIPPO_SHARDED_CASE=big: BASELINE configs[1]'s network in bf16 at a size where a sharded rank's
+# gradient step is the FOUR launches of a single GPU (N / world = 1024 envs, B = 512 per rank:
+# mi_policy_ws_fwd_bf16, mi_policy_ws_bwd_gae_bf16 with the statistics exchanged inside it,
+# mi_dense_bwd_dw_grouped_slabs_bf16, mi_adam_step_allreduce_f32 summing the slabs)
+BIG = os.environ.get("MIPPO_SHARDED_CASE") == "big"
+N, T, E, MB = (2048, 30, 1, 2) if BIG else (128, 8, 2, 2)
 ARGS = (0.95, 0.99, 0.2, True, False, E, MB)
 
 
@@ -41,7 +48,8 @@ def build_state(dev, rank, world):
     from nnx_ppo_amd.tree import tree_map
 
     env = _env()
-    net = factories.make_mlp_actor_critic(5, 1, [32, 32], [64, 64], Rngs(21), entropy_weight=0.0)
+    hidden = ([64] * 4, [256] * 2) if BIG else ([32, 32], [64, 64])
+    net = factories.make_mlp_actor_critic(5, 1, *hidden, Rngs(21), entropy_weight=0.0)
     net.eval()  # deterministic policy: no noise stream
     n_local = N // world
     all_keys = rnd.split(rnd.key(77, dev), N)
@@ -77,15 +85,26 @@ def run_iterations(env, ts, inds, iters=2):
     from nnx_ppo_amd.algorithms import ppo
     from nnx_ppo_amd.algorithms.types import LoggingLevel
 
+    from nnx_ppo_amd import _lib, config
+
     n_local = ts.env_states.done.shape[0]
     level = LoggingLevel.LOSSES | LoggingLevel.ACTOR_EXTRA
     ms = []
-    for _ in range(iters):
-        ts, m = ppo.ppo_step(env, ts, n_local, T, *ARGS, 1.0, level, minibatch_inds=inds)
-        ms.append({k: float(v) for k, v in m.items()})
+    used = set()
+    with config.use_compute_dtype("bf16" if BIG else "f32"):
+        for it in range(iters):
+            if it == iters - 1:
+                with _lib.profiler as prof:
+                    ts, m = ppo.ppo_step(env, ts, n_local, T, *ARGS, 1.0, level,
+                                         minibatch_inds=inds)
+                used = sorted({name for name, *_ in prof.records})
+            else:
+                ts, m = ppo.ppo_step(env, ts, n_local, T, *ARGS, 1.0, level,
+                                     minibatch_inds=inds)
+            ms.append({k: float(v) for k, v in m.items()})
     norm = ts.networks.layers[0]
     return {"params": ts.optimizer.params.clone(), "adam_m": ts.optimizer.m.clone(),
             "step": int(ts.optimizer.step), "norm_mean": norm.mean.value.clone(),
             "norm_m2": norm.M2.value.clone(), "norm_count": float(norm.counter.value),
             "steps_taken": int(ts.steps_taken), "metrics": ms,
-            "obs": ts.env_states.obs.clone()}
+            "obs": ts.env_states.obs.clone(), "used": list(used)}

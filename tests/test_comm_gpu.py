@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 HERE = Path(__file__).resolve().parent
 
 
-def _run_pair(tmp_path, scenario, timeout=240):
+def _run_pair(tmp_path, scenario, timeout=240, env=None):
     store = tmp_path / f"store_{scenario}"
     procs = [subprocess.Popen([sys.executable, str(HERE / "_comm_worker.py"), str(r), "2",
-                               str(store), scenario, str(tmp_path)],
+                               str(store), scenario, str(tmp_path)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = []
@@ -78,3 +78,61 @@ def test_sharded_ppo_step_equals_single_process(dev, tmp_path):
             assert np.isclose(got0, want, rtol=2e-4, atol=2e-6), (it, k, got0, want)
     # and it was not a trivial run
     assert not torch.equal(ref["params"].cpu(), build_state(dev, 0, 1)[1].optimizer.params.cpu())
+
+
+def test_sharded_gradient_step_is_the_four_launches_of_a_single_gpu(dev, tmp_path):
+    """on the one-shot transport a sharded rank's gradient step is forward,
+    backward WITH the GAE scan / global advantage statistics / loss inside
+    (`mi_policy_ws_bwd_gae_bf16` exchanging the statistics partials through the peers' regions),
+    dW, and `mi_adam_step_allreduce_f32` summing the dW slabs — no GAE / statistics-exchange /
+    loss / slab-reduction launches of their own.  2 ranks x 1024 envs (C2's network, bf16)
+    against 1 process x 2048 envs with the union minibatches: parameters within the bf16
+    path's order bound, the ranks bit-identical.  (Two ranks share the one GPU of the box: the
+    kernels and the protocol are a node's; xGMI itself is not covered.)"""
+    import os
+
+    sys.path.insert(0, str(HERE))
+    env_vars = dict(os.environ, MIPPO_SHARDED_CASE="big")
+    _run_pair(tmp_path, "sharded_ppo", timeout=400, env=env_vars)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    # the single-process reference in a child too (the case module reads its size at import)
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from _sharded_case import build_state, run_iterations;"
+            "dev = torch.device('cuda', 0); env, ts, inds = build_state(dev, 0, 1);"
+            "r = run_iterations(env, ts, inds); torch.cuda.synchronize();"
+            "torch.save({k: (v.cpu() if isinstance(v, torch.Tensor) else v) "
+            "for k, v in r.items()}, %r)"
+            % (str(HERE.parent), str(HERE), str(tmp_path / "ref.pt")))
+    p = subprocess.run([sys.executable, "-c", code], env=env_vars, capture_output=True,
+                       text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    ref = torch.load(tmp_path / "ref.pt", weights_only=True)
+    per_step = {"mi_policy_ws_fwd_bf16", "mi_policy_ws_bwd_gae_bf16",
+                "mi_dense_bwd_dw_grouped_slabs_bf16"}
+    for r in (r0, r1):
+        used = set(r["used"])
+        assert per_step | {"mi_adam_step_allreduce_f32"} <= used, sorted(used)
+        # none of the launches the sharded step used to need
+        assert not used & {"mi_gae_stats_f32", "mi_gae_f32", "mi_ppo_loss_f32",
+                           "mi_allreduce_oneshot_f64", "mi_reduce_slabs_grouped_f32",
+                           "mi_policy_ws_bwd_bf16", "mi_adam_step_f32",
+                           "mi_adam_step_slabs_f32"}, sorted(used)
+    assert per_step | {"mi_adam_step_slabs_f32"} <= set(ref["used"])
+    for k in ("params", "adam_m", "norm_mean", "norm_m2"):
+        assert torch.equal(r0[k], r1[k]), k              # replicas bit-identical
+    assert r0["step"] == r1["step"] == ref["step"]
+    assert torch.equal(torch.cat([r0["obs"], r1["obs"]]), ref["obs"])
+    cpu = lambda t: t.double().numpy()
+    # bf16 images of gradients that differ in fp64 summation order of the statistics: a few
+    # roundings flip; Adam moves a parameter by <= lr = 1e-3 per step whatever the gradient
+    worst = float(np.abs(cpu(r0["params"]) - cpu(ref["params"])).max())
+    assert worst < 5e-4, worst
+    assert np.allclose(cpu(r0["norm_mean"]), cpu(ref["norm_mean"]), rtol=1e-5, atol=1e-6)
+    for it in range(2):
+        for k, want in ref["metrics"][it].items():
+            if not k.startswith("losses/"):
+                continue
+            got0, got1 = r0["metrics"][it][k], r1["metrics"][it][k]
+            assert got0 == got1, k
+            assert np.isclose(got0, want, rtol=5e-3, atol=2e-5), (it, k, got0, want)
