@@ -331,6 +331,22 @@ int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const float* b_hn, co
                         const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out,
                         float* h_final, void* h_prev_bf, int64_t T, int64_t B, int64_t H,
                         mi_stream_t stream);
+/* mi_gru_seq_fwd_bf16 (training form) with the layers BEHIND the recurrence of
+ * make_gru_actor_critic's actor in the same launch: Dense(H -> N_out = 2A) (`feedforward.py:42-51`;
+ * w_out = its forward fragment-major image) and NormalTanhSampler in replay mode
+ * (`sampling_layers.py:82-147`: the stored raw actions `extras` [T*B, A] scored -> loglik, reg
+ * [T*B]).  ms_out [T*B, N_out]: the head's fp32 rows (the sampler backward's input);
+ * h_bf_out [T*B, H]: bf16 image of h_out (the head's dW operand).  Bit-identical to
+ * mi_gru_seq_fwd_bf16 + mi_mlp_fwd_bf16 + mi_tanh_gauss_fwd_f32.  Class:
+ * mi_gru_seq_fwd_tail_supported (the T x 16-row history must fit 96 KB of LDS). */
+int mi_gru_seq_fwd_tail_supported(int64_t T, int64_t H, int64_t N_out);
+int mi_gru_seq_fwd_tail_bf16(
+    const float* gi, const float* w_h, const float* b_hn, const float* h0, const uint8_t* done,
+    float* h_out, float* h_prev_out, float* gates_out, float* h_final, void* h_prev_bf,
+    const void* w_out, const float* b_out, int64_t N_out, float* ms_out, void* h_bf_out,
+    const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
+    float min_std, float std_scale, float entropy_weight, float* loglik, float* reg, int64_t T,
+    int64_t B, int64_t H, mi_stream_t stream);
 int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_prev,
                         const float* w_h, const uint8_t* done, float* dgi, float* dgh, float* dh0,
                         void* dgh_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream);

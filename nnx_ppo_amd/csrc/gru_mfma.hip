@@ -18,6 +18,7 @@
 // the A operand of dh = dgh . W_h^T.
 // Cell arithmetic and the reset-on-done rule as in gru.hip (flax GRUCell: PARITY UNPINNED).
 #include "bf16_common.h"
+#include "sampler_math.h"
 
 namespace {
 
@@ -42,14 +43,32 @@ constexpr int GROWS = 16;
 // around a memory instruction makes the compiler's wait counting take the path with the
 // FEWEST younger instructions, i.e. wait for almost everything — the steady state below
 // must be straight-line code.
-template <bool TRAIN, int H, bool GUARD, bool BF>
+// TAIL (loss replay of make_gru_actor_critic's actor): the layers BEHIND the recurrence —
+// Dense(H -> 2A) and the tanh-Gaussian sampler scoring the stored actions
+// (`feedforward.py:42-51`, `sampling_layers.py:82-147`) — ride in this launch.  They do not
+// depend on the recurrence beyond h_t, and one thread per row of a transcendental chain has
+// no place inside the time loop: the bf16 image of every h_t stays in LDS (T x 16 rows), and
+// after the loop the workgroup multiplies its T row tiles by the head's weights and samples
+// its T x 16 rows in parallel.  Two launches (a 1024-row-tile chain walk and the sampler)
+// leave the critical path of every gradient step; same MFMA tiles, same k order, same row
+// function: bit-identical to them.
+struct GruTail {
+  const bf16_t* wo;   // forward fragment-major image of the head's kernel [H -> N_out <= 16]
+  const float* bo;    // [N_out] or null
+  float* ms_out;      // [T * B][N_out] fp32: the head's rows (the sampler backward's input)
+  bf16_t* h_bf;       // [T * B][H]: bf16 image of h_out — the x operand of the head's dW
+  mippo_sampler::FwdParams samp;  // rows are t * B + env
+  int N_out;
+};
+
+template <bool TRAIN, int H, bool GUARD, bool BF, bool TAIL = false>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
                     const uint8_t* __restrict__ done, float* __restrict__ h_out,
                     float* __restrict__ h_prev_out, float* __restrict__ gates_out,
                     float* __restrict__ h_final, bf16_t* __restrict__ h_prev_bf, int64_t T,
-                    int64_t B) {
+                    int64_t B, GruTail tail) {
   // (the gate expressions are evaluated as written — no fma contraction — in every
   // instantiation and in the one-launch rollout step of trunk_ws.hip: bit-identical carries)
 #pragma clang fp contract(off)
@@ -69,6 +88,7 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   constexpr int HROW = H + 8;
   bf16_t* hb0 = reinterpret_cast<bf16_t*>(lds_raw);  // [2][16][H + 8]
   bf16_t* hb1 = hb0 + GROWS * HROW;
+  bf16_t* const hist = hb1 + GROWS * HROW;            // TAIL: [T][16][H + 8], bf16(h_t)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,6 +221,14 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
           *reinterpret_cast<f32x4*>(gto + og + (unsigned)(3 * H)) = qn;
         }
       }
+      if constexpr (TAIL) {  // the head's operand: h_t before the reset select
+        bf16x4 hr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hr[e] = (bf16_t)hnew[e];
+        *reinterpret_cast<bf16x4*>(hist + ((int)t * GROWS + li) * HROW + ucol[ui]) = hr;
+        if (valid)
+          *reinterpret_cast<bf16x4*>(tail.h_bf + ((int64_t)t * B + rowc) * H + ucol[ui]) = hr;
+      }
       bf16x4 hb4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -229,6 +257,46 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   for (int ui = 0; ui < UTW; ++ui) {
     if (wave + 4 * ui >= UT) continue;
     if (valid) *reinterpret_cast<f32x4*>(h_final + rowc * (unsigned)H + ucol[ui]) = h[ui];
+  }
+  if constexpr (TAIL) {
+    // ---- the head on the workgroup's T row tiles, then the sampler on its T x 16 rows ------
+    float* const ms_s = reinterpret_cast<float*>(hist + (size_t)T * GROWS * HROW);  // [T*16][N_out]
+    const int N_out = tail.N_out;
+    bf16x8 wo[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wo[ks] = *reinterpret_cast<const bf16x8*>(tail.wo + ((size_t)ks << 9) + lane * 8);
+    f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tail.bo) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * lq + e < N_out) bo[e] = tail.bo[4 * lq + e];
+    }
+    __syncthreads();  // every h_t image is in `hist` (the last step's barrier covers the rest)
+    for (int t = wave; t < (int)T; t += kThreads / 64) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(hist + (t * GROWS + li) * HROW +
+                                                          ks * 32 + 8 * lq);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[ks], a, acc, 0, 0, 0);  // D[n][row]
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 4 * lq + e;
+        if (n < N_out) {
+          const float v = acc[e] + bo[e];
+          ms_s[(t * GROWS + li) * N_out + n] = v;
+          if (valid) tail.ms_out[((int64_t)t * B + rowc) * N_out + n] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < (int)T * GROWS; idx += kThreads) {
+      const int t = idx / GROWS, r = idx % GROWS;
+      if (row0 + r < B)
+        mippo_sampler::fwd_row(ms_s + idx * N_out, (int64_t)t * B + row0 + r, tail.samp);
+    }
   }
 }
 
@@ -448,7 +516,8 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
   bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
 #define MI_GRU_FWD(TRAIN, HH, GUARD, BF)                                                       \
   hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, HH, GUARD, BF>), grid, dim3(kThreads), lds, st, \
-                     gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, hpb, T, B)
+                     gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, hpb, T, B,  \
+                     GruTail{})
 #define MI_GRU_FWD_H(HH)                                                       \
   if (H == HH) {                                                               \
     if (!h_prev_out) {                                                         \
@@ -469,6 +538,71 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
 #undef MI_GRU_FWD_H
 #undef MI_GRU_FWD
   return mippo::check_launch("mi_gru_seq_fwd_bf16");
+}
+
+// LDS of the TAIL form: the two carry tiles + the T x 16-row history + the head's rows
+static size_t gru_tail_lds(int64_t T, int64_t H, int64_t N_out) {
+  return (size_t)(2 + T) * GROWS * (H + 8) * sizeof(bf16_t) + (size_t)T * GROWS * N_out * 4;
+}
+
+extern "C" int mi_gru_seq_fwd_tail_supported(int64_t T, int64_t H, int64_t N_out) {
+  return T >= 1 && mfma_shape_ok(H) && N_out >= 2 && N_out <= 16 && N_out % 2 == 0 &&
+         gru_tail_lds(T, H, N_out) <= 96 * 1024;
+}
+
+// mi_gru_seq_fwd_bf16 (training form, bf16 image of h_prev) with the head Dense(H -> N_out)
+// and the tanh-Gaussian sampler in replay mode (stored raw actions `extras` scored: log-
+// likelihood and entropy regulariser out) inside the launch — see GruTail.  w_out: forward
+// fragment-major image of the head's kernel; ms_out [T*B, N_out] the head's fp32 rows;
+// h_bf_out [T*B, H] the bf16 image of h_out (the head's dW operand).
+extern "C" int mi_gru_seq_fwd_tail_bf16(
+    const float* gi, const float* w_h, const float* b_hn, const float* h0, const uint8_t* done,
+    float* h_out, float* h_prev_out, float* gates_out, float* h_final, void* h_prev_bf,
+    const void* w_out, const float* b_out, int64_t N_out, float* ms_out, void* h_bf_out,
+    const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
+    float min_std, float std_scale, float entropy_weight, float* loglik, float* reg, int64_t T,
+    int64_t B, int64_t H, mi_stream_t stream) {
+  const char* who = "mi_gru_seq_fwd_tail_bf16";
+  MI_REQUIRE(B >= 1 && B * 4 * H < (1LL << 31) && mi_gru_seq_fwd_tail_supported(T, H, N_out),
+             "%s: T=%lld H=%lld N_out=%lld outside the supported class", who, (long long)T,
+             (long long)H, (long long)N_out);
+  MI_REQUIRE(gi && w_h && b_hn && h0 && h_out && h_prev_out && gates_out && h_final &&
+                 h_prev_bf && w_out && ms_out && h_bf_out && extras && loglik && reg,
+             "%s: null pointer", who);
+  MI_REQUIRE(rng_state || eps2, "%s: need rng_state or injected entropy noise", who);
+  MI_REQUIRE(al16(w_out) && al16(h_bf_out), "%s: buffers must be 16-byte aligned", who);
+  GruTail tail = {static_cast<const bf16_t*>(w_out), b_out, ms_out,
+                  static_cast<bf16_t*>(h_bf_out),
+                  {extras, {rng_state, offset_add, eps2, eps2}, nullptr, nullptr, nullptr, nullptr,
+                   loglik, reg, (int)(N_out / 2), min_std, std_scale, entropy_weight, 0},
+                  (int)N_out};
+  const size_t lds = gru_tail_lds(T, H, N_out);
+  const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
+  hipStream_t st = mippo::as_stream(stream);
+  const bool guard = B % GROWS != 0;
+  bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
+#define MI_GRU_TAIL(HH, GUARD)                                                                   \
+  {                                                                                              \
+    static const hipError_t attr = hipFuncSetAttribute(                                          \
+        reinterpret_cast<const void*>(&gru_fwd_mfma_kernel<true, HH, GUARD, true, true>),        \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
+    MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
+    hipLaunchKernelGGL((gru_fwd_mfma_kernel<true, HH, GUARD, true, true>), grid, dim3(kThreads), \
+                       lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final,  \
+                       hpb, T, B, tail);                                                         \
+  }
+#define MI_GRU_TAIL_H(HH)            \
+  if (H == HH) {                     \
+    if (guard) MI_GRU_TAIL(HH, true) \
+    else MI_GRU_TAIL(HH, false)      \
+  }
+  MI_GRU_TAIL_H(32)
+  MI_GRU_TAIL_H(64)
+  MI_GRU_TAIL_H(96)
+  MI_GRU_TAIL_H(128)
+#undef MI_GRU_TAIL_H
+#undef MI_GRU_TAIL
+  return mippo::check_launch(who);
 }
 
 extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_prev,

@@ -6,6 +6,8 @@ import os
 from collections.abc import Sequence
 from typing import Any
 
+import torch
+
 from .. import config
 from .types import ModuleState, StatefulModule, StatefulModuleOutput, add_reg, zero_scalar
 
@@ -20,6 +22,9 @@ def _device_of(x):
 # the bootstrap observation as step T of a stateless value chain's replay
 # (Sequential.replay_with_bootstrap); MIPPO_BOOTSTRAP_IN_CHAIN=0: a forward_value launch
 BOOTSTRAP_IN_CHAIN = os.environ.get("MIPPO_BOOTSTRAP_IN_CHAIN", "1") != "0"
+# a linear head + sampler behind a recurrent layer inside its sequence launch
+# (recurrent.GRU.replay(tail=...)); MIPPO_REC_TAIL=0: their own launches (A/B, bit-identity tests)
+REC_TAIL = os.environ.get("MIPPO_REC_TAIL", "1") != "0"
 
 
 class Sequential(StatefulModule):
@@ -131,15 +136,35 @@ class Sequential(StatefulModule):
                     cctx, gi2 = dense_chain.forward_train(
                         chain, x2 if x2.is_contiguous() else x2.contiguous(), upstream_needs)
                     layer_extras = None if extras_seq is None else extras_seq[j]
-                    rctx, x, r, fs = rec.replay(state0[j], None, done_seq, layer_extras,
-                                                need_input_grad=True,
-                                                gi_seq=gi2.view(*lead, gi2.shape[-1]))
+                    # ... and a linear head + tanh-Gaussian sampler right behind the recurrent
+                    # layer (make_gru_actor_critic's actor) ride in ITS launch: two launches
+                    # leave the critical path of the gradient step (csrc/gru_mfma.hip: GruTail)
+                    tail = None
+                    if (REC_TAIL and j + 3 == n and extras_seq is not None
+                            and isinstance(extras_seq[j + 2], torch.Tensor)
+                            and hasattr(rec, "replay_tail_supported")
+                            and rec.replay_tail_supported(lead[0], self.layers[j + 1],
+                                                          self.layers[j + 2])):
+                        tail = (self.layers[j + 1], self.layers[j + 2], extras_seq[j + 2])
+                    res = rec.replay(state0[j], None, done_seq, layer_extras,
+                                     need_input_grad=True,
+                                     gi_seq=gi2.view(*lead, gi2.shape[-1]),
+                                     **({"tail": tail} if tail is not None else {}))
+                    rctx, x, r, fs = res[:4]
                     ctxs.append(("chain+rec", i, j, cctx, lead, rctx))
                     final_state.extend(state0[i:j])
                     final_state.append(fs)
                     reg = add_reg(reg, r)
                     upstream_needs = True
                     i = j + 1
+                    if tail is not None:
+                        head_ctx, samp_ctx, out_d, reg_s = res[4]
+                        ctxs.append(("chain", j + 1, j + 2, head_ctx, lead))
+                        ctxs.append(("layer", j + 2, samp_ctx))
+                        final_state.extend([state0[j + 1], ()])
+                        reg = add_reg(reg, reg_s)
+                        x = out_d
+                        i = n
                     continue
                 lead = x.shape[:-1]
                 x2 = x.reshape(-1, x.shape[-1])

@@ -103,10 +103,28 @@ class GRU(StatefulModule):
         projection does not run on the bf16 trunk kernels."""
         return self._proj() if self._mfma() else None
 
-    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None):
+    def replay_tail_supported(self, T: int, head, sampler) -> bool:
+        """True when `replay(..., tail=(head, sampler, raw_seq))` can run the linear `head`
+        Dense and the tanh-Gaussian `sampler` behind this layer inside the sequence launch
+        (`mi_gru_seq_fwd_tail_bf16`)."""
+        from .feedforward import Dense
+        from .sampling_layers import NormalTanhSampler
+
+        return (self._mfma() and type(head) is Dense and type(sampler) is NormalTanhSampler
+                and head.act_code == ops.ACT_NONE and head.in_features == self.hidden_features
+                and head.bias is not None and sampler.noise_override is None
+                and not sampler.deterministic
+                and ops.gru_seq_fwd_tail_supported(T, self.hidden_features, head.out_features))
+
+    def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None,
+               tail=None):
         """`gi_seq` [T, B, 3H]: the input projection, already evaluated by the caller as the
         last layer of the preceding Dense chain (`x_seq` is then unused and
-        `replay_backward` returns the gradient w.r.t. `gi_seq`)."""
+        `replay_backward` returns the gradient w.r.t. `gi_seq`).
+        `tail` = (head Dense, sampler, raw actions [T, B, A]) with `gi_seq`
+        (`replay_tail_supported`): head and sampler replay ride in the sequence launch; the
+        return value gains a fifth element (head ctx as `dense_chain.forward_train` builds it,
+        sampler ctx as `NormalTanhSampler.replay` builds it, sampler output dict, reg [T, B])."""
         H = self.hidden_features
         mfma = self._mfma()
         pctx = None
@@ -126,6 +144,25 @@ class GRU(StatefulModule):
                 gi = gi2.view(T, B, 3 * H)
             else:
                 gi = self._gi(x2).view(T, B, 3 * H)
+        if tail is not None:
+            from . import dense_chain
+
+            head, sampler, raw_seq = tail
+            dense_chain.refresh([head])
+            A2 = head.out_features
+            ex2 = raw_seq.reshape(T * B, A2 // 2)
+            if not ex2.is_contiguous():
+                ex2 = ex2.contiguous()
+            off = sampler._next_offset()
+            h_out, h_prev, gates, h_final, ms2, h_bf, ll, reg = ops.gru_seq_fwd_tail(
+                gi, self.w_h.data, self.b_hn.data, state0.contiguous(), done_seq.contiguous(),
+                head._ff, head.bias.data, A2, ex2, sampler._state(gi.device), off,
+                **sampler._kw())
+            ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx)
+            head_ctx = ([(h_bf, None, dense_chain._shadows(head)[0])], T * B, True)
+            samp_ctx = (ms2, ex2, off, None, (T, B, A2))
+            out = {"action": None, "log_likelihood": ll.view(T, B)}
+            return ctx, h_out, None, h_final, (head_ctx, samp_ctx, out, reg.view(T, B))
         h_out, h_prev, gates, h_final = ops.gru_seq_fwd(
             gi, self.w_h.data, self.b_hn.data, state0.contiguous(), done_seq.contiguous(),
             train=True, mfma=mfma)

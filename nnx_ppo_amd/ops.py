@@ -1701,6 +1701,46 @@ def gru_seq_fwd(gi, w_h, b_hn, h0, done, train: bool, mfma: bool = False):
     return h_out, h_prev, gates, h_final
 
 
+def gru_seq_fwd_tail_supported(T: int, H: int, N_out: int) -> bool:
+    return bool(lib().mi_gru_seq_fwd_tail_supported(int(T), int(H), int(N_out)))
+
+
+def gru_seq_fwd_tail(gi, w_h, b_hn, h0, done, w_out_ff, b_out, N_out: int, extras, rng_state,
+                     offset_add: int, *, min_std: float, std_scale: float,
+                     entropy_weight: float, eps2=None):
+    """`gru_seq_fwd(train=True, mfma=True)` with the head Dense(H -> N_out) and the sampler's
+    replay (stored raw actions `extras` [T*B, A] scored) inside the launch
+    (`mi_gru_seq_fwd_tail_bf16`).  Returns (h_out, h_prev (with `.bf16_image`), gates, h_final,
+    ms [T*B, N_out], h_bf [T*B, H], log_likelihood [T*B], reg [T*B])."""
+    T, B, H3 = gi.shape
+    H = H3 // 3
+    _need(w_h.shape == (H, H3) and b_hn.shape == (H,) and h0.shape == (B, H),
+          "gru_seq_fwd_tail: shapes")
+    dev = gi.device
+    M = T * B
+    h_out = torch.empty(T, B, H, dtype=f32, device=dev)
+    h_prev = torch.empty(T, B, H, dtype=f32, device=dev)
+    gates = torch.empty(T, B, 4 * H, dtype=f32, device=dev)
+    h_final = torch.empty(B, H, dtype=f32, device=dev)
+    hp_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    h_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    ms = torch.empty(M, N_out, dtype=f32, device=dev)
+    ll = torch.empty(M, dtype=f32, device=dev)
+    reg = torch.empty(M, dtype=f32, device=dev)
+    d = None if done is None else _as_u8(done)
+    _need(extras.shape == (M, N_out // 2) and extras.is_contiguous(),
+          "gru_seq_fwd_tail: extras must be a contiguous [T*B, A]")
+    check(lib().mi_gru_seq_fwd_tail_bf16(
+        ptr(gi, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32), ptr(d), ptr(h_out, f32),
+        ptr(h_prev, f32), ptr(gates, f32), ptr(h_final, f32), ptr(hp_bf), ptr(w_out_ff, bf16),
+        ptr(b_out, f32), int(N_out), ptr(ms, f32), ptr(h_bf), ptr(extras, f32), ptr(rng_state),
+        int(offset_add), ptr(eps2, f32), float(min_std), float(std_scale),
+        float(entropy_weight), ptr(ll, f32), ptr(reg, f32), T, B, H, stream()),
+        "mi_gru_seq_fwd_tail_bf16")
+    h_prev.bf16_image = hp_bf
+    return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg
+
+
 def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False, dgh_as_bf16: bool = False):
     """Returns (dgi [T,B,3H], dgh [T,B,3H]).  `dgh_as_bf16` (matrix-core path): dgh comes
     back as its bf16 image [T*B, 3H] — the dz operand of the recurrent kernel's dW launch —

@@ -129,7 +129,9 @@ def test_c4_gru_bf16_mfma_ppo_step_vs_oracle(dev):
                 ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 2, 2)
             ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 2, okeys)
             used = _called(prof)
-            assert {"mi_gru_seq_fwd_bf16", "mi_gru_seq_bwd_bf16"} <= used, used
+            # the matrix-core recurrence — since round 3 with the head Dense and the sampler's
+            # replay riding in the forward sequence launch
+            assert {"mi_gru_seq_fwd_tail_bf16", "mi_gru_seq_bwd_bf16"} <= used, used
             assert "mi_gru_seq_fwd_f32" not in used   # the matrix-core recurrence, not VALU
             done = info["rollout"].done
             assert int(done.sum()) >= int(0.15 * N * T)  # reset-heavy: ~20 % of the steps

@@ -174,3 +174,38 @@ def test_gru_bias_tail_gradient_folded_equals_reduced(dev, bf16):
         outs.append(ts.optimizer.params.clone())
         assert all(torch.isfinite(torch.as_tensor(v)).all() for v in m.values())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatch):
+    """`mi_gru_seq_fwd_tail_bf16`: the linear head and the sampler's replay behind the GRU ride
+    in the sequence launch (containers.Sequential.replay, REC_TAIL).  Against the launches they
+    replace — same network, same rollout, same minibatch: every loss scalar and every parameter
+    gradient bit for bit (the head's MFMA tiles, k order and the sampler's row function are the
+    same), and the launch list."""
+    from nnx_ppo_amd import _lib, config
+    from nnx_ppo_amd.algorithms import ppo
+    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.networks import containers, factories
+    from nnx_ppo_amd.networks.types import Rngs
+    from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
+
+    out = []
+    with config.use_compute_dtype("bf16"):
+        for tail in (True, False):
+            monkeypatch.setattr(containers, "REC_TAIL", tail)
+            env = EpisodeWrapper(cartpole_shaped(max_steps=5), 1000)
+            net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(9))
+            ts = ppo.new_training_state(env, net, 512, 9, 3e-4, device=dev)
+            ms = []
+            for it in range(2):
+                with _lib.profiler as prof:
+                    ts, m = ppo.ppo_step(env, ts, 512, 30, 0.95, 0.99, 0.2, True, False, 2, 2)
+                ms.append({k: float(v) for k, v in m.items()})
+                used = {name for name, *_ in prof.records}
+                assert ("mi_gru_seq_fwd_tail_bf16" in used) == tail, used
+                if tail:
+                    assert "mi_tanh_gauss_fwd_f32" not in used and "mi_gru_seq_fwd_bf16" not in used
+            out.append((ts.optimizer.params.clone(), ts.optimizer.m.clone(), ms))
+    (pa, ma, la), (pb, mb, lb) = out
+    assert la == lb
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
