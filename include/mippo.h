@@ -331,6 +331,20 @@ int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const float* b_hn, co
                         const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out,
                         float* h_final, void* h_prev_bf, int64_t T, int64_t B, int64_t H,
                         mi_stream_t stream);
+/* mi_gru_seq_bwd_bf16 with the backward of those two layers IN FRONT of the BPTT inside the
+ * launch: the sampler's backward (`mi_tanh_gauss_bwd_f32`'s operands, rows t*B + env) and the
+ * head's dX (w_out_bwd = its backward fragment-major image); dz_out_bf [T*B, pad8(N_out)]
+ * receives the head's output-gradient image (its dW operand).  dgi and the bf16 image of dgh
+ * out as mi_gru_seq_bwd_bf16.  Bit-identical to mi_tanh_gauss_bwd_f32 + mi_mlp_bwd_dx_bf16 +
+ * mi_gru_seq_bwd_bf16. */
+int mi_gru_seq_bwd_tail_supported(int64_t T, int64_t H, int64_t N_out);
+int mi_gru_seq_bwd_tail_bf16(
+    const float* gates, const float* h_prev, const float* w_h, const uint8_t* done, float* dgi,
+    float* dh0, void* dgh_bf, const void* w_out_bwd, int64_t N_out, const float* mean_and_std,
+    const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
+    const float* g_loglik, float g_reg, float min_std, float std_scale, float entropy_weight,
+    void* dz_out_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
 /* mi_gru_seq_fwd_bf16 (training form) with the layers BEHIND the recurrence of
  * make_gru_actor_critic's actor in the same launch: Dense(H -> N_out = 2A) (`feedforward.py:42-51`;
  * w_out = its forward fragment-major image) and NormalTanhSampler in replay mode

@@ -32,6 +32,156 @@ constexpr int GROWS = 16;
 // leave in flight).
 
 
+// Stores of the transposed tile.  A lane (li, lq) of the MFMA result holds 16 bytes of ROW li:
+// lanes 0..15 are 16 different rows, so a store straight from that arrangement reaches memory
+// as 64 separate 16-byte requests — 7 such stores per step were 22 of the training forward's
+// 39 us at T = 30, B = 1024, H = 64 (17.5 us with the stores compiled out).  One ds_bpermute
+// per dword moves the data to the arrangement lane' = 4 * row + chunk: 4 consecutive lanes then
+// hold the 64 contiguous bytes a wave owns of a row, 16 requests per store.
+// A lane whose row is not there (past B, or past the rows the workgroup fills) repeats the
+// store of the tile's row 0 — same address, same data, same instruction — instead of being
+// switched off: a predicated store is a branch around it, and with a path that skips the stores
+// the compiler's s_waitcnt vmcnt(N) for the ring of per-step operands may only count the LOADS
+// issued since (N ~ 12: every step waited for the previous step's stores to land).
+struct RowLanes {
+  int src4;        // 4 * (the lane whose data this lane stores)
+  unsigned rowc;   // the row this lane stores, its 16-byte chunk
+  unsigned chunk;
+  __device__ inline RowLanes(int lane, int64_t row0, int64_t B, int rpw, bool guard) {
+    int r = lane >> 2;
+    chunk = (unsigned)(lane & 3);
+    if (guard && !(r < rpw && row0 + r < B)) r = 0;  // row0 itself always exists
+    src4 = 4 * (r + 16 * (int)chunk);
+    rowc = (unsigned)(row0 + r);
+  }
+  __device__ inline f32x4 operator()(const f32x4 v) const {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = v[e];  // (a bit_cast of the element expression itself reads element 0)
+      o[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(f)));
+    }
+    return o;
+  }
+};
+__device__ inline bf16x4 to_bf16x4(const f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+  return o;
+}
+
+// The 4 elements a lane (li < 4) of the transposed tile holds, one each to lanes li, li + 4,
+// li + 8, li + 12 of its row of 16 (three DPP row shifts): see the PACK form of the kernels.
+__device__ inline float spread4(const f32x4 a) {
+  const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+  int v = __float_as_int(a0);
+  v = __builtin_amdgcn_update_dpp(v, __float_as_int(a1), 0x114, 0xF, 0x2, false);  // row_shr:4
+  v = __builtin_amdgcn_update_dpp(v, __float_as_int(a2), 0x118, 0xF, 0x4, false);  // row_shr:8
+  v = __builtin_amdgcn_update_dpp(v, __float_as_int(a3), 0x11C, 0xF, 0x8, false);  // row_shr:12
+  return __int_as_float(v);
+}
+
+// The done flags of the workgroup's rows, a window of DONE_WIN steps at a time in LDS.  They used
+// to ride in the register ring with the other per-step operands; the compiler widens a loaded
+// byte (v_and 0xff) at the END of each unrolled group of PFW steps, and that touch waits for
+// loads issued a few instructions earlier — one memory round trip per group, a third of the
+// kernels' time.  From LDS the flag is a ds_read_u8 where it is used.
+constexpr int DONE_WIN = 240;  // steps; a multiple of every PFW, so a group never straddles
+struct DoneWindow {
+  uint8_t* s;  // [DONE_WIN][GROWS]
+  int64_t lo;  // first step held
+  // all threads of the workgroup (barriers inside): hold steps lo_ .. lo_ + DONE_WIN - 1
+  __device__ inline void stage(const uint8_t* done, int64_t lo_, int64_t T, int64_t B,
+                               int64_t row0, int rpw, int tid) {
+    lo = lo_;
+    __syncthreads();  // nobody still reads the previous window
+    const int64_t first = lo_ > 0 ? lo_ : 0;
+    const int64_t end = lo_ + DONE_WIN < T ? lo_ + DONE_WIN : T;
+    for (int i = (int)(first - lo_) * GROWS + tid; i < (int)(end - lo_) * GROWS; i += kThreads) {
+      const int r = i % GROWS;
+      s[i] = (r < rpw && row0 + r < B) ? done[(lo_ + i / GROWS) * B + row0 + r] : 0;
+    }
+    __syncthreads();
+  }
+  __device__ inline bool holds(int64_t t_lo, int64_t t_hi) const {
+    return t_lo >= lo && t_hi < lo + DONE_WIN;
+  }
+  __device__ inline bool at(int64_t t, int row) const { return s[(int)(t - lo) * GROWS + row] != 0; }
+};
+
+// PACK rows per workgroup (a small batch spread over the chip, `rows_per_group`): the step's
+// outputs leave through LDS.  What a store costs here is the INSTRUCTION, not its bytes — at
+// T = 30, B = 1024, H = 64 every one of the training forward's 7 stores per wave and step added
+// 2.0-2.6 us to the launch whether it carried 16 rows or 4 — and a tile with 4 live rows fills a
+// quarter of each.  So every wave drops its pieces into a per-row record in LDS (all output
+// arrays of the row back to back), and after the step's barrier the workgroup sweeps the PACK
+// records with whole 64-lane, 16-bytes-per-lane stores: 8 store instructions per workgroup and
+// step instead of 28-32 (forward), 5 instead of 24 (BPTT).  Two record buffers alternate, so the
+// sweep of step t runs beside the arithmetic of step t + 1.
+struct OutArray {
+  void* base;     // [T][B][row_bytes]
+  int rec_off;    // where the row's bytes sit in the record
+  int row_bytes;
+};
+template <int NA, int RECB, int PACK>
+struct PackedStores {
+  static constexpr int REC = RECB + 16;  // + 16: rows land in different LDS banks
+  static constexpr int CPR = RECB / 16;  // 16-byte chunks per row
+  static constexpr int NCH = PACK * CPR;
+  static constexpr int J = (NCH + kThreads - 1) / kThreads;
+  static constexpr int LDS_BYTES = 2 * PACK * REC;
+  unsigned char* buf;  // [2][PACK][REC]
+  char* fp[J];         // this thread's chunk of sweep j: where it goes at the current step ...
+  int64_t fs[J];       // ... and how far that moves per step
+  unsigned fl[J];      // its place in a record buffer
+  // `t_first`: the first step swept; `dir` = +1 / -1: the order of the steps
+  __device__ inline void init(unsigned char* lds, const OutArray (&arr)[NA], int tid, int64_t row0,
+                              int64_t B, int64_t t_first, int dir) {
+    buf = lds;
+    const int rows_here = (int)(B - row0 < PACK ? B - row0 : PACK);
+    const int n_valid = rows_here * CPR;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      // past the live chunks: repeat an earlier one (same bytes to the same place) — no predicate
+      const int c = (tid + j * kThreads) % n_valid;
+      const int row = c / CPR, w = (c % CPR) * 16;
+      fl[j] = (unsigned)(row * REC + w);
+      fp[j] = nullptr;
+      fs[j] = 0;
+#pragma unroll
+      for (int k = 0; k < NA; ++k)
+        if (w >= arr[k].rec_off && w < arr[k].rec_off + arr[k].row_bytes) {
+          fs[j] = (int64_t)dir * B * arr[k].row_bytes;
+          fp[j] = static_cast<char*>(arr[k].base) +
+                  (t_first * B + row0 + row) * arr[k].row_bytes + (w - arr[k].rec_off);
+        }
+    }
+  }
+  // the record of tile row `li` (< PACK) for the step of parity `par`
+  __device__ inline unsigned char* rec(int par, int li) const {
+    return buf + (par * PACK + li) * REC;
+  }
+  // after the barrier behind the step's record writes: out, and on to the next step
+  __device__ inline void sweep(int par, int tid) {
+    const unsigned char* b = buf + par * PACK * REC;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (j * kThreads + (tid & ~63) < NCH)  // wave-uniform: a sweep's last waves may be empty
+        *reinterpret_cast<u32x4*>(fp[j]) = *reinterpret_cast<const u32x4*>(b + fl[j]);
+      fp[j] += fs[j];
+    }
+  }
+};
+constexpr int fwd_rec_bytes(int H, bool TRAIN, bool BF, bool TAIL) {
+  return 4 * H + (TRAIN ? 20 * H : 0) + (TRAIN && BF ? 2 * H : 0) + (TAIL ? 2 * H : 0);
+}
+constexpr int bwd_rec_bytes(int H, bool F32, bool BF) {
+  return 12 * H + (F32 ? 12 * H : 0) + (BF ? 6 * H : 0);
+}
+constexpr int packed_lds(int rec_bytes, int pack) { return 2 * pack * (rec_bytes + 16); }
+
+
 // Addressing: a lane's element offsets (row * stride + unit) are fixed for the whole
 // sequence and fit 32 bits; per step only a wave-uniform base pointer moves.  Rows past
 // B (last workgroup) are clamped for loads and masked for stores, so the step body has
@@ -61,14 +211,14 @@ struct GruTail {
   int N_out;
 };
 
-template <bool TRAIN, int H, bool GUARD, bool BF, bool TAIL = false>
+template <bool TRAIN, int H, bool GUARD, bool BF, bool TAIL = false, int PACK = 0>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
                     const uint8_t* __restrict__ done, float* __restrict__ h_out,
                     float* __restrict__ h_prev_out, float* __restrict__ gates_out,
                     float* __restrict__ h_final, bf16_t* __restrict__ h_prev_bf, int64_t T,
-                    int64_t B, GruTail tail) {
+                    int64_t B, int rpw, GruTail tail) {
   // (the gate expressions are evaluated as written — no fma contraction — in every
   // instantiation and in the one-launch rollout step of trunk_ws.hip: bit-identical carries)
 #pragma clang fp contract(off)
@@ -88,12 +238,20 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   constexpr int HROW = H + 8;
   bf16_t* hb0 = reinterpret_cast<bf16_t*>(lds_raw);  // [2][16][H + 8]
   bf16_t* hb1 = hb0 + GROWS * HROW;
-  bf16_t* const hist = hb1 + GROWS * HROW;            // TAIL: [T][16][H + 8], bf16(h_t)
+  DoneWindow dwin = {reinterpret_cast<uint8_t*>(hb1 + GROWS * HROW), 0};
+  // PACK: the output records (PackedStores); rpw == PACK
+  constexpr int OFF_HP = 4 * H, OFF_G = TRAIN ? 8 * H : 4 * H, OFF_HPB = OFF_G + (TRAIN ? 16 * H : 0);
+  constexpr int OFF_HB = OFF_HPB + (TRAIN && BF ? 2 * H : 0);
+  constexpr int N_OUT_ARR = 1 + (TRAIN ? 2 : 0) + (TRAIN && BF ? 1 : 0) + (TAIL ? 1 : 0);
+  using Packed = PackedStores<N_OUT_ARR, fwd_rec_bytes(H, TRAIN, BF, TAIL), PACK ? PACK : 1>;
+  unsigned char* const stg = reinterpret_cast<unsigned char*>(hb1 + GROWS * HROW) + DONE_WIN * GROWS;
+  // TAIL: [T][16][H + 8], bf16(h_t)
+  bf16_t* const hist = reinterpret_cast<bf16_t*>(stg + (PACK ? Packed::LDS_BYTES : 0));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * GROWS;
+  const int64_t row0 = (int64_t)blockIdx.x * rpw;  // rows rpw .. 15 of the tile stay empty
   constexpr int H3 = 3 * H;
 
   // W_h fragments of this wave's units: W_h[k][gate*H + unit], lane (li, lq) the column
@@ -125,138 +283,281 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   }
   // this lane: row `row0 + li`, units (wave + 4 ui) * 16 + 4 lq + e  (e = 0..3)
   const int64_t row = row0 + li;
-  const bool valid = !GUARD || row < B;
+  const bool valid = !GUARD || (li < rpw && row < B);
   const unsigned rowc = (unsigned)(valid ? row : B - 1);  // clamped: loads stay inside
-  f32x4 h[UTW], bn[UTW];
-  unsigned ucol[UTW];
+  if constexpr (PACK > 0) {
+    // ---- a small batch spread thin: rpw == PACK == 4 rows per workgroup ---------------------
+    // Of the MFMA result's 16 row slots 4 are live.  With a lane = 4 elements of one row the gate
+    // math (~25 VALU instructions and 6 transcendentals per element) ran on 16 lanes and was
+    // ~1,200 of a step's ~2,700 cycles, the longest link of its chain.  So the 4 elements of a
+    // live lane go out to the dead ones (spread4): lane (li, lq) owns ONE element for the whole
+    // sequence — row li & 3, unit 16 ut + 4 lq + (li >> 2) — carry, bias, per-step operands (one
+    // dword each) and results alike.  The results leave through per-row records in LDS
+    // (PackedStores).  Same expressions per element: the same bits as the other form.
+    static_assert(PACK == 4, "the spread form is written for 4 rows per workgroup");
+    const int rr = li & 3;
+    const int64_t srow = row0 + rr;
+    const bool svalid = srow < B;
+    const unsigned srowc = (unsigned)(svalid ? srow : B - 1);
+    for (int i = tid; i < 2 * GROWS * HROW; i += kThreads) hb0[i] = (bf16_t)0.0f;  // dead rows
+    __syncthreads();
+    float hc[UTW], bnv[UTW];
+    unsigned ucol[UTW];
 #pragma unroll
-  for (int ui = 0; ui < UTW; ++ui) {
-    const int ut = wave + 4 * ui;
-    const bool on = ut < UT;
-    ucol[ui] = (unsigned)((on ? ut : 0) * 16 + 4 * lq);
-    bn[ui] = on ? *reinterpret_cast<const f32x4*>(b_hn + ucol[ui]) : f32x4{0.f, 0.f, 0.f, 0.f};
-    h[ui] = (on && valid) ? *reinterpret_cast<const f32x4*>(h0 + rowc * (unsigned)H + ucol[ui])
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (on) {
-      bf16x4 hb4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) hb4[e] = (bf16_t)h[ui][e];
-      *reinterpret_cast<bf16x4*>(hb0 + li * HROW + ucol[ui]) = hb4;
+    for (int ui = 0; ui < UTW; ++ui) {
+      const int ut = wave + 4 * ui;
+      const bool on = ut < UT;
+      ucol[ui] = (unsigned)((on ? ut : 0) * 16 + 4 * lq + (li >> 2));
+      bnv[ui] = on ? b_hn[ucol[ui]] : 0.0f;
+      hc[ui] = (on && svalid) ? h0[srowc * (unsigned)H + ucol[ui]] : 0.0f;
+      if (on) hb0[rr * HROW + ucol[ui]] = (bf16_t)hc[ui];
     }
-  }
-  const int64_t last_t = T - 1;
-  // gi / done of steps t .. t+PFW-1 for the owned elements (ring of PFW register slots)
-  f32x4 gq[PFW][UTW][3];
-  // (the done byte stays RAW in its slot: testing it here would make every load_step wait
-  // for its own load — and, vmcnt being in order, for every store before it: one full
-  // memory round trip per time step, which is what this kernel used to cost)
-  unsigned dq[PFW];
-  const uint8_t* const done_c = done ? done : reinterpret_cast<const uint8_t*>(w_h);
-  auto load_step = [&](int64_t t, f32x4 (&dst)[UTW][3], unsigned& dn) {
-    const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
-    const float* gt = gi + tc * B * H3;
-    dn = done_c[done ? tc * B + rowc : 0];
-#pragma unroll
-    for (int ui = 0; ui < UTW; ++ui)
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-        dst[ui][g] = *reinterpret_cast<const f32x4*>(gt + rowc * (unsigned)H3 +
-                                                     (unsigned)(g * H) + ucol[ui]);
-  };
-#pragma unroll
-  for (int d = 0; d < PFW; ++d) load_step(d, gq[d], dq[d]);
-  __syncthreads();
-  bf16_t* hb = hb0;
-  bf16_t* hbn = hb1;
-  auto step = [&](int64_t t, f32x4 (&gcur)[UTW][3], unsigned& dcur) {
-    const bool reset = done != nullptr && dcur != 0;
-    f32x4 acc[UTW][3];
-#pragma unroll
-    for (int ui = 0; ui < UTW; ++ui)
-#pragma unroll
-      for (int g = 0; g < 3; ++g) acc[ui][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
+    Packed pk;
+    {
+      OutArray arr[N_OUT_ARR];
+      int k = 0;
+      arr[k++] = {h_out, 0, 4 * H};
+      if constexpr (TRAIN) {
+        arr[k++] = {h_prev_out, OFF_HP, 4 * H};
+        arr[k++] = {gates_out, OFF_G, 16 * H};
+        if constexpr (BF) arr[k++] = {h_prev_bf, OFF_HPB, 2 * H};
+      }
+      if constexpr (TAIL) arr[k++] = {tail.h_bf, OFF_HB, 2 * H};
+      pk.init(stg, arr, tid, row0, B, 0, +1);
+    }
+    const int64_t last_t = T - 1;
+    float gq[PFW][UTW][3];  // gi of steps t .. t+PFW-1 for the owned elements
+    auto load_step = [&](int64_t t, float (&dst)[UTW][3]) {
+      const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
+      const float* gt = gi + tc * B * H3;
 #pragma unroll
       for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
-        for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
-          acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
-                                                              0, 0, 0);
+        for (int g = 0; g < 3; ++g) dst[ui][g] = gt[srowc * (unsigned)H3 + (unsigned)(g * H) + ucol[ui]];
+    };
+#pragma unroll
+    for (int d = 0; d < PFW; ++d) load_step(d, gq[d]);
+    if (done) dwin.stage(done, 0, T, B, row0, rpw, tid);
+    __syncthreads();
+    bf16_t* hb = hb0;
+    bf16_t* hbn = hb1;
+    auto step = [&](int64_t t, float (&gcur)[UTW][3]) {
+      const bool reset = done != nullptr && dwin.at(t, rr);
+      f32x4 acc[UTW][3];
+#pragma unroll
+      for (int ui = 0; ui < UTW; ++ui)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[ui][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui)
+#pragma unroll
+          for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
+            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
+                                                                0, 0, 0);
+      }
+      unsigned char* const rc0 = pk.rec((int)(t & 1), rr);
+#pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        if constexpr (UT % 4 != 0)
+          if (wave + 4 * ui >= UT) continue;  // wave-uniform
+        const float hp = hc[ui];
+        const float r = fast_sigmoid(gcur[ui][0] + spread4(acc[ui][0]));
+        const float z = fast_sigmoid(gcur[ui][1] + spread4(acc[ui][1]));
+        const float qn = spread4(acc[ui][2]) + bnv[ui];
+        const float n = fast_tanh(gcur[ui][2] + r * qn);
+        const float hnew = (1.0f - z) * n + z * hp;
+        unsigned char* const rc = rc0 + 4 * ucol[ui];
+        *reinterpret_cast<float*>(rc) = hnew;
+        if constexpr (TRAIN) {
+          *reinterpret_cast<float*>(rc + OFF_HP) = hp;
+          *reinterpret_cast<float*>(rc + OFF_G) = r;
+          *reinterpret_cast<float*>(rc + OFF_G + 4 * H) = z;
+          *reinterpret_cast<float*>(rc + OFF_G + 8 * H) = n;
+          *reinterpret_cast<float*>(rc + OFF_G + 12 * H) = qn;
+          if constexpr (BF) *reinterpret_cast<bf16_t*>(rc + OFF_HPB - 2 * ucol[ui]) = (bf16_t)hp;
+        }
+        if constexpr (TAIL) {  // bf16(h_t): the head's operand (before the reset) and its dW's x
+          *reinterpret_cast<bf16_t*>(rc + OFF_HB - 2 * ucol[ui]) = (bf16_t)hnew;
+          hist[((int)t * GROWS + rr) * HROW + ucol[ui]] = (bf16_t)hnew;
+        }
+        const float hcn = reset ? 0.0f : hnew;
+        hc[ui] = hcn;
+        hbn[rr * HROW + ucol[ui]] = (bf16_t)hcn;
+      }
+      __syncthreads();
+      pk.sweep((int)(t & 1), tid);
+      bf16_t* tmp = hb;
+      hb = hbn;
+      hbn = tmp;
+      __builtin_amdgcn_sched_barrier(0);  // (the refill behind its slot's use: see the other form)
+      load_step(t + PFW, gcur);
+    };
+    int64_t t0 = 0;
+    if (T >= PFW) {  // first group peeled, the loop inside its branch (see the other form)
+#pragma unroll
+      for (int d = 0; d < PFW; ++d) step(d, gq[d]);
+      for (t0 = PFW; t0 + PFW <= T; t0 += PFW) {
+        if (done && !dwin.holds(t0, t0 + PFW - 1)) dwin.stage(done, t0, T, B, row0, rpw, tid);
+#pragma unroll
+        for (int d = 0; d < PFW; ++d) step(t0 + d, gq[d]);
+      }
     }
-    float* ho = h_out + t * B * H;
-    float* hpo = TRAIN ? h_prev_out + t * B * H : nullptr;
-    float* gto = TRAIN ? gates_out + t * B * 4 * H : nullptr;
-    // bf16 image of h_prev [T*B][H]: the x operand of the recurrent kernel's dW launch
-    bf16_t* hpb = (TRAIN && BF) ? h_prev_bf + t * B * H : nullptr;
+    if (done && t0 < T && !dwin.holds(t0, T - 1)) dwin.stage(done, t0, T, B, row0, rpw, tid);
+#pragma unroll
+    for (int d = 0; d < PFW; ++d)
+      if (t0 + d < T) step(t0 + d, gq[d]);
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
-      if (wave + 4 * ui >= UT) continue;  // wave-uniform
-      const f32x4 hp = h[ui];
-      f32x4 r, z, n, qn, hnew;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        r[e] = fast_sigmoid(gcur[ui][0][e] + acc[ui][0][e]);
-        z[e] = fast_sigmoid(gcur[ui][1][e] + acc[ui][1][e]);
-        qn[e] = acc[ui][2][e] + bn[ui][e];
-        n[e] = fast_tanh(gcur[ui][2][e] + r[e] * qn[e]);
-        hnew[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
-      }
-      if (valid) {
-        const unsigned o = rowc * (unsigned)H + ucol[ui];
-        *reinterpret_cast<f32x4*>(ho + o) = hnew;
-        if constexpr (TRAIN) {
-          *reinterpret_cast<f32x4*>(hpo + o) = hp;
-          if constexpr (BF) {
-            bf16x4 pb;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pb[e] = (bf16_t)hp[e];
-            *reinterpret_cast<bf16x4*>(hpb + o) = pb;
-          }
-          const unsigned og = rowc * (unsigned)(4 * H) + ucol[ui];
-          *reinterpret_cast<f32x4*>(gto + og) = r;
-          *reinterpret_cast<f32x4*>(gto + og + (unsigned)H) = z;
-          *reinterpret_cast<f32x4*>(gto + og + (unsigned)(2 * H)) = n;
-          *reinterpret_cast<f32x4*>(gto + og + (unsigned)(3 * H)) = qn;
-        }
-      }
-      if constexpr (TAIL) {  // the head's operand: h_t before the reset select
-        bf16x4 hr;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hr[e] = (bf16_t)hnew[e];
-        *reinterpret_cast<bf16x4*>(hist + ((int)t * GROWS + li) * HROW + ucol[ui]) = hr;
-        if (valid)
-          *reinterpret_cast<bf16x4*>(tail.h_bf + ((int64_t)t * B + rowc) * H + ucol[ui]) = hr;
-      }
-      bf16x4 hb4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float hc = reset ? 0.0f : hnew[e];
-        h[ui][e] = hc;
-        hb4[e] = (bf16_t)hc;
-      }
-      *reinterpret_cast<bf16x4*>(hbn + li * HROW + ucol[ui]) = hb4;
+      if (wave + 4 * ui >= UT) continue;
+      if (svalid) h_final[srowc * (unsigned)H + ucol[ui]] = hc[ui];
     }
+  } else {
+    f32x4 h[UTW], bn[UTW];
+    unsigned ucol[UTW];
+    const RowLanes sl(lane, row0, B, rpw, GUARD);  // the arrangement the global stores go out in
+    unsigned scol[UTW];
+  #pragma unroll
+    for (int ui = 0; ui < UTW; ++ui) {
+      const int ut = wave + 4 * ui;
+      const bool on = ut < UT;
+      ucol[ui] = (unsigned)((on ? ut : 0) * 16 + 4 * lq);
+      scol[ui] = (unsigned)((on ? ut : 0) * 16) + 4 * sl.chunk;
+      bn[ui] = on ? *reinterpret_cast<const f32x4*>(b_hn + ucol[ui]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      h[ui] = (on && valid) ? *reinterpret_cast<const f32x4*>(h0 + rowc * (unsigned)H + ucol[ui])
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (on) {
+        bf16x4 hb4;
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) hb4[e] = (bf16_t)h[ui][e];
+        *reinterpret_cast<bf16x4*>(hb0 + li * HROW + ucol[ui]) = hb4;
+      }
+    }
+    const int64_t last_t = T - 1;
+    // gi of steps t .. t+PFW-1 for the owned elements (ring of PFW register slots; the done
+    // flags: DoneWindow)
+    f32x4 gq[PFW][UTW][3];
+    auto load_step = [&](int64_t t, f32x4 (&dst)[UTW][3]) {
+      const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
+      const float* gt = gi + tc * B * H3;
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui)
+  #pragma unroll
+        for (int g = 0; g < 3; ++g)
+          dst[ui][g] = *reinterpret_cast<const f32x4*>(gt + rowc * (unsigned)H3 +
+                                                       (unsigned)(g * H) + ucol[ui]);
+    };
+  #pragma unroll
+    for (int d = 0; d < PFW; ++d) load_step(d, gq[d]);
+    if (done) dwin.stage(done, 0, T, B, row0, rpw, tid);
     __syncthreads();
-    bf16_t* tmp = hb;
-    hb = hbn;
-    hbn = tmp;
-    load_step(t + PFW, gcur, dcur);  // refill this slot: consumed PFW steps from now
-  };
-  // whole groups of PFW steps: straight-line; then the remainder
-  int64_t t0 = 0;
-  for (; t0 + PFW <= T; t0 += PFW) {
-#pragma unroll
-    for (int d = 0; d < PFW; ++d) step(t0 + d, gq[d], dq[d]);
-  }
-#pragma unroll
-  for (int d = 0; d < PFW; ++d)
-    if (t0 + d < T) step(t0 + d, gq[d], dq[d]);
-#pragma unroll
-  for (int ui = 0; ui < UTW; ++ui) {
-    if (wave + 4 * ui >= UT) continue;
-    if (valid) *reinterpret_cast<f32x4*>(h_final + rowc * (unsigned)H + ucol[ui]) = h[ui];
+    bf16_t* hb = hb0;
+    bf16_t* hbn = hb1;
+    auto step = [&](int64_t t, f32x4 (&gcur)[UTW][3]) {
+      const bool reset = done != nullptr && dwin.at(t, li);
+      f32x4 acc[UTW][3];
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui)
+  #pragma unroll
+        for (int g = 0; g < 3; ++g) acc[ui][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
+  #pragma unroll
+        for (int ui = 0; ui < UTW; ++ui)
+  #pragma unroll
+          for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
+            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
+                                                                0, 0, 0);
+      }
+      float* ho = h_out + t * B * H;
+      float* hpo = TRAIN ? h_prev_out + t * B * H : nullptr;
+      float* gto = TRAIN ? gates_out + t * B * 4 * H : nullptr;
+      // bf16 image of h_prev [T*B][H]: the x operand of the recurrent kernel's dW launch
+      bf16_t* hpb = (TRAIN && BF) ? h_prev_bf + t * B * H : nullptr;
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        if constexpr (UT % 4 != 0)
+          if (wave + 4 * ui >= UT) continue;  // wave-uniform (a branch: see RowLanes)
+        const f32x4 hp = h[ui];
+        f32x4 r, z, n, qn, hnew;
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          r[e] = fast_sigmoid(gcur[ui][0][e] + acc[ui][0][e]);
+          z[e] = fast_sigmoid(gcur[ui][1][e] + acc[ui][1][e]);
+          qn[e] = acc[ui][2][e] + bn[ui][e];
+          n[e] = fast_tanh(gcur[ui][2][e] + r[e] * qn[e]);
+          hnew[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
+        }
+        {  // out through the row-major lane arrangement (RowLanes)
+          const f32x4 s_hnew = sl(hnew);
+          const unsigned o = sl.rowc * (unsigned)H + scol[ui];
+          *reinterpret_cast<f32x4*>(ho + o) = s_hnew;
+          if constexpr (TRAIN) {
+            const f32x4 s_hp = sl(hp), s_r = sl(r), s_z = sl(z), s_n = sl(n), s_qn = sl(qn);
+            *reinterpret_cast<f32x4*>(hpo + o) = s_hp;
+            if constexpr (BF) *reinterpret_cast<bf16x4*>(hpb + o) = to_bf16x4(s_hp);
+            const unsigned og = sl.rowc * (unsigned)(4 * H) + scol[ui];
+            *reinterpret_cast<f32x4*>(gto + og) = s_r;
+            *reinterpret_cast<f32x4*>(gto + og + (unsigned)H) = s_z;
+            *reinterpret_cast<f32x4*>(gto + og + (unsigned)(2 * H)) = s_n;
+            *reinterpret_cast<f32x4*>(gto + og + (unsigned)(3 * H)) = s_qn;
+          }
+          if constexpr (TAIL)  // bf16 image of h_t: the x operand of the head's dW
+            *reinterpret_cast<bf16x4*>(tail.h_bf + ((int64_t)t * B + sl.rowc) * H + scol[ui]) =
+                to_bf16x4(s_hnew);
+        }
+        if constexpr (TAIL)  // the head's operand: h_t before the reset select
+          *reinterpret_cast<bf16x4*>(hist + ((int)t * GROWS + li) * HROW + ucol[ui]) =
+              to_bf16x4(hnew);
+        bf16x4 hb4;
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float hc = reset ? 0.0f : hnew[e];
+          h[ui][e] = hc;
+          hb4[e] = (bf16_t)hc;
+        }
+        *reinterpret_cast<bf16x4*>(hbn + li * HROW + ucol[ui]) = hb4;
+      }
+      __syncthreads();
+      bf16_t* tmp = hb;
+      hb = hbn;
+      hbn = tmp;
+      // refill this slot (consumed PFW steps from now).  Behind a scheduling barrier: hoisted above
+      // the gate math the loads would need registers of their own while the old slot is still
+      // live, and the copies back into the slot at the end of a PFW group wait for loads issued
+      // moments before (the look-ahead collapses to one round trip per group)
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(t + PFW, gcur);
+    };
+    // whole groups of PFW steps: straight-line; then the remainder.  The first group is peeled:
+    // the compiler places ONE set of s_waitcnt vmcnt(N) in the loop body, valid for every way
+    // into it — entered straight from the prologue (the ring filled back to back, a slot's load
+    // only a few memory instructions old when it is consumed) N would be ~12 for every iteration,
+    // i.e. each step waiting for the previous step's stores; entered from a group, the loop's
+    // counts are the steady state's (a slot's load ~PFW steps of instructions old).
+    // (the loop INSIDE the branch of the peeled group: no way into it but through a group)
+    int64_t t0 = 0;
+    if (T >= PFW) {
+  #pragma unroll
+      for (int d = 0; d < PFW; ++d) step(d, gq[d]);
+      for (t0 = PFW; t0 + PFW <= T; t0 += PFW) {
+        if (done && !dwin.holds(t0, t0 + PFW - 1)) dwin.stage(done, t0, T, B, row0, rpw, tid);
+  #pragma unroll
+        for (int d = 0; d < PFW; ++d) step(t0 + d, gq[d]);
+      }
+    }
+    if (done && t0 < T && !dwin.holds(t0, T - 1)) dwin.stage(done, t0, T, B, row0, rpw, tid);
+  #pragma unroll
+    for (int d = 0; d < PFW; ++d)
+      if (t0 + d < T) step(t0 + d, gq[d]);
+  #pragma unroll
+    for (int ui = 0; ui < UTW; ++ui) {
+      if (wave + 4 * ui >= UT) continue;
+      if (valid) *reinterpret_cast<f32x4*>(h_final + rowc * (unsigned)H + ucol[ui]) = h[ui];
+    }
   }
   if constexpr (TAIL) {
     // ---- the head on the workgroup's T row tiles, then the sampler on its T x 16 rows ------
@@ -294,7 +595,7 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     __syncthreads();
     for (int idx = tid; idx < (int)T * GROWS; idx += kThreads) {
       const int t = idx / GROWS, r = idx % GROWS;
-      if (row0 + r < B)
+      if (r < rpw && row0 + r < B)
         mippo_sampler::fwd_row(ms_s + idx * N_out, (int64_t)t * B + row0 + r, tail.samp);
     }
   }
@@ -306,13 +607,30 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 // dh carry in registers; the dgh tile (bf16) in LDS is the B operand of
 // dh_prev^T += W_h . dgh^T; A operand = W_h[unit][j] rows (contiguous in j).
 // F32: write dgh as fp32; BF: write its bf16 image (the dW operand).
-template <int H, bool GUARD, bool F32, bool BF>
+// TAIL (mirror of the forward's GruTail): the sampler's backward and the head's dX are evaluated
+// HERE instead of by two launches in front of this one.  Prologue: the workgroup's T x 16 rows
+// run the sampler backward row function (d loss / d (mean | pre-softplus std) from
+// d loss / d log-likelihood and the regulariser's weight), the rows — rounded to bf16, the head's
+// dz image, which is also written out for its dW — wait in LDS; per step the gradient w.r.t. h_t
+// is one MFMA k-step of that tile against the head's backward fragments (g_h = dz . W_out^T,
+// the product mi_mlp_bwd_dx_bf16 makes), in the lane that consumes it.  Bit-identical to the
+// three launches.
+struct GruBwdTail {
+  const bf16_t* wo_b;  // backward fragment-major image of the head's kernel (columns = H inputs)
+  bf16_t* dz_out;      // [T * B][ld_dz] bf16 image of the head's output gradient (its dW operand)
+  int64_t ld_dz;       // pad8(N_out)
+  mippo_sampler::BwdParams sb;  // rows are t * B + env
+  int N_out;
+};
+
+template <int H, bool GUARD, bool F32, bool BF, bool TAIL = false, int PACK = 0>
 __global__ void __launch_bounds__(kThreads)
 gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
                     const float* __restrict__ h_prev, const float* __restrict__ w_h,
                     const uint8_t* __restrict__ done, float* __restrict__ dgi,
                     float* __restrict__ dgh, float* __restrict__ dh0,
-                    bf16_t* __restrict__ dgh_bf, int64_t T, int64_t B) {
+                    bf16_t* __restrict__ dgh_bf, int64_t T, int64_t B, int rpw,
+                    GruBwdTail tail) {
 #pragma clang fp contract(off)
   constexpr int UT = H / 16;
   constexpr int UTW = (UT + 3) / 4;
@@ -323,11 +641,42 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   bf16_t* dg0 = reinterpret_cast<bf16_t*>(lds_raw);  // [2][16][3H + 8]
   bf16_t* dg1 = dg0 + GROWS * GROW;
+  constexpr int DZROW = 32 + 8;                       // TAIL: one k-step of head columns + pad
+  DoneWindow dwin = {reinterpret_cast<uint8_t*>(dg1 + GROWS * GROW), 0};
+  // PACK: the output records (PackedStores); rpw == PACK
+  constexpr int OFF_GH = 12 * H, OFF_GB = OFF_GH + (F32 ? 12 * H : 0);
+  constexpr int N_OUT_ARR = 1 + (F32 ? 1 : 0) + (BF ? 1 : 0);
+  using Packed = PackedStores<N_OUT_ARR, bwd_rec_bytes(H, F32, BF), PACK ? PACK : 1>;
+  unsigned char* const stg = reinterpret_cast<unsigned char*>(dg1 + GROWS * GROW) + DONE_WIN * GROWS;
+  // TAIL: [T][16][DZROW]
+  bf16_t* const dzs = reinterpret_cast<bf16_t*>(stg + (PACK ? Packed::LDS_BYTES : 0));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * GROWS;
+  const int64_t row0 = (int64_t)blockIdx.x * rpw;  // rows rpw .. 15 of the tile stay empty
+
+  if constexpr (TAIL) {
+    // the sampler backward on the workgroup's T x 16 rows (sampler.hip's row function), the
+    // rows rounded to bf16 as the head's dz image: into LDS (k-padded with zeros) and out
+    for (int i = tid; i < (int)T * GROWS * DZROW; i += kThreads) dzs[i] = (bf16_t)0.0f;
+    __syncthreads();
+    for (int idx = tid; idx < (int)T * GROWS; idx += kThreads) {
+      const int t = idx / GROWS, r = idx % GROWS;
+      if (r < rpw && row0 + r < B) {
+        const int64_t b = (int64_t)t * B + row0 + r;
+        bf16_t* row_s = dzs + idx * DZROW;
+        bf16_t* row_g = tail.dz_out + b * tail.ld_dz;
+        mippo_sampler::bwd_row(b, tail.sb, [&](int a, float v) {
+          const bf16_t q = (bf16_t)v;
+          row_s[a] = q;
+          row_g[a] = q;
+        });
+        for (int a = tail.N_out; a < (int)tail.ld_dz; ++a) row_g[a] = (bf16_t)0.0f;
+      }
+    }
+    __syncthreads();
+  }
 
   // W_h rows of this wave's units: A[i = unit tile * 16 + li][k = j] = W_h[unit][j]
   bf16x8 wf[UTW][KS];
@@ -352,30 +701,49 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
       wf[ui][ks] = f;
     }
   }
+  // TAIL: the head's backward fragments of this wave's unit tiles (columns = units)
+  bf16x8 wob[UTW];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int ui = 0; ui < UTW; ++ui) {
+      const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+      wob[ui] = *reinterpret_cast<const bf16x8*>(tail.wo_b + ((size_t)ut << 9) + lane * 8);
+    }
+  }
   const int64_t row = row0 + li;
-  const bool valid = !GUARD || row < B;
+  const bool valid = !GUARD || (li < rpw && row < B);
   const unsigned rowc = (unsigned)(valid ? row : B - 1);
   unsigned ucol[UTW];
   f32x4 dh[UTW];
+  const RowLanes sl(lane, row0, B, rpw, GUARD);  // the arrangement the global stores go out in
+  unsigned scol[UTW];
 #pragma unroll
   for (int ui = 0; ui < UTW; ++ui) {
     const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
     ucol[ui] = (unsigned)(ut * 16 + 4 * lq);
+    scol[ui] = (unsigned)(ut * 16) + 4 * sl.chunk;
     dh[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // per-step operands of the owned elements: (r, z, n, qn, g_h, h_prev), done; ring of PFW
+  Packed pk;
+  if constexpr (PACK > 0) {
+    OutArray arr[N_OUT_ARR];
+    int k = 0;
+    arr[k++] = {dgi, 0, 12 * H};
+    if constexpr (F32) arr[k++] = {dgh, OFF_GH, 12 * H};
+    if constexpr (BF) arr[k++] = {dgh_bf, OFF_GB, 6 * H};
+    pk.init(stg, arr, tid, row0, B, T - 1, -1);
+  }
+  // per-step operands of the owned elements: (r, z, n, qn, g_h, h_prev); ring of PFW (the done
+  // flags: DoneWindow)
   struct In {
     f32x4 v[UTW][6];
-    unsigned dn;
   };
   In inq[PFW];
-  const uint8_t* const done_c = done ? done : reinterpret_cast<const uint8_t*>(w_h);
   auto load_in = [&](int64_t t, In& dst) {
     const int64_t tc = t > 0 ? t : 0;  // before the start: reload step 0
     const float* gt = gates + tc * B * 4 * H;
-    const float* ght = g_h + tc * B * H;
+    const float* ght = TAIL ? nullptr : g_h + tc * B * H;
     const float* hpt = h_prev + tc * B * H;
-    dst.dn = done_c[done ? tc * B + rowc : 0];  // raw: tested where it is used
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       const unsigned og = rowc * (unsigned)(4 * H) + ucol[ui];
@@ -384,24 +752,34 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
       dst.v[ui][1] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)H);
       dst.v[ui][2] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(2 * H));
       dst.v[ui][3] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(3 * H));
-      dst.v[ui][4] = *reinterpret_cast<const f32x4*>(ght + o);
+      if constexpr (!TAIL) dst.v[ui][4] = *reinterpret_cast<const f32x4*>(ght + o);
       dst.v[ui][5] = *reinterpret_cast<const f32x4*>(hpt + o);
     }
   };
 #pragma unroll
   for (int d = 0; d < PFW; ++d) load_in(T - 1 - d, inq[d]);
+  if (done) dwin.stage(done, T - DONE_WIN, T, B, row0, rpw, tid);
   bf16_t* dg = dg0;
   bf16_t* dgn_buf = dg1;
   auto step = [&](int64_t t, In& in) {
-    const bool reset = done != nullptr && in.dn != 0;
+    const bool reset = done != nullptr && dwin.at(t, li);
     f32x4 dhp[UTW];
+    if constexpr (TAIL) {  // g_h[t] = dz_out[t] . W_out^T: one k-step, D[unit 4 lq + e][row li]
+      const bf16x8 dzf = *reinterpret_cast<const bf16x8*>(dzs + ((int)t * GROWS + li) * DZROW +
+                                                          8 * lq);
+#pragma unroll
+      for (int ui = 0; ui < UTW; ++ui)
+        in.v[ui][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            wob[ui], dzf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
     float* gio = dgi + t * B * H3;
     float* gho = F32 ? dgh + t * B * H3 : nullptr;
     // bf16 image of dgh [T*B][3H]: the dz operand of the recurrent kernel's dW launch
     bf16_t* ghb = BF ? dgh_bf + t * B * H3 : nullptr;
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
-      if (wave + 4 * ui >= UT) continue;  // wave-uniform (never taken when UT % 4 == 0)
+      if constexpr (UT % 4 != 0)
+        if (wave + 4 * ui >= UT) continue;  // wave-uniform (a branch: see RowLanes)
       f32x4 a_r, a_z, a_n, g_n;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -424,38 +802,52 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
         g_n[e] = valid ? dgn : 0.0f;
         dhp[ui][e] = valid ? dp : 0.0f;
       }
-      if (valid) {
-        const unsigned o3 = rowc * (unsigned)H3 + ucol[ui];
-        *reinterpret_cast<f32x4*>(gio + o3) = a_r;
-        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)H) = a_z;
-        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)(2 * H)) = a_n;
+      if constexpr (PACK > 0) {  // into this row's record (PackedStores)
+        if (li < PACK) {
+          unsigned char* rc = pk.rec((int)(t & 1), li) + 4 * ucol[ui];
+          *reinterpret_cast<f32x4*>(rc) = a_r;
+          *reinterpret_cast<f32x4*>(rc + 4 * H) = a_z;
+          *reinterpret_cast<f32x4*>(rc + 8 * H) = a_n;
+          if constexpr (F32) {
+            *reinterpret_cast<f32x4*>(rc + OFF_GH) = a_r;
+            *reinterpret_cast<f32x4*>(rc + OFF_GH + 4 * H) = a_z;
+            *reinterpret_cast<f32x4*>(rc + OFF_GH + 8 * H) = g_n;
+          }
+          if constexpr (BF) {
+            unsigned char* rb = rc + OFF_GB - 2 * ucol[ui];
+            *reinterpret_cast<bf16x4*>(rb) = to_bf16x4(a_r);
+            *reinterpret_cast<bf16x4*>(rb + 2 * H) = to_bf16x4(a_z);
+            *reinterpret_cast<bf16x4*>(rb + 4 * H) = to_bf16x4(g_n);
+          }
+        }
+      } else {  // out through the row-major lane arrangement (RowLanes)
+        const f32x4 s_r = sl(a_r), s_z = sl(a_z), s_n = sl(a_n);
+        f32x4 s_g = s_n;
+        if constexpr (F32 || BF) s_g = sl(g_n);
+        const unsigned o3 = sl.rowc * (unsigned)H3 + scol[ui];
+        *reinterpret_cast<f32x4*>(gio + o3) = s_r;
+        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)H) = s_z;
+        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)(2 * H)) = s_n;
         if constexpr (F32) {
-          *reinterpret_cast<f32x4*>(gho + o3) = a_r;
-          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)H) = a_z;
-          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)(2 * H)) = g_n;
+          *reinterpret_cast<f32x4*>(gho + o3) = s_r;
+          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)H) = s_z;
+          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)(2 * H)) = s_g;
+        }
+        if constexpr (BF) {
+          *reinterpret_cast<bf16x4*>(ghb + o3) = to_bf16x4(s_r);
+          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)H) = to_bf16x4(s_z);
+          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)(2 * H)) = to_bf16x4(s_g);
         }
       }
-      bf16x4 b_r, b_z, b_n;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        b_r[e] = (bf16_t)a_r[e];
-        b_z[e] = (bf16_t)a_z[e];
-        b_n[e] = (bf16_t)g_n[e];
-      }
-      if constexpr (BF) {
-        if (valid) {
-          const unsigned o3 = rowc * (unsigned)H3 + ucol[ui];
-          *reinterpret_cast<bf16x4*>(ghb + o3) = b_r;
-          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)H) = b_z;
-          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)(2 * H)) = b_n;
-        }
-      }
+      const bf16x4 b_r = to_bf16x4(a_r), b_z = to_bf16x4(a_z), b_n = to_bf16x4(g_n);
       *reinterpret_cast<bf16x4*>(dg + li * GROW + ucol[ui]) = b_r;
       *reinterpret_cast<bf16x4*>(dg + li * GROW + H + ucol[ui]) = b_z;
       *reinterpret_cast<bf16x4*>(dg + li * GROW + 2 * H + ucol[ui]) = b_n;
     }
+    __builtin_amdgcn_sched_barrier(0);  // (as in the forward: the refill stays behind its slot's use)
     load_in(t - PFW, in);  // refill this slot: consumed PFW steps from now
     __syncthreads();
+    if constexpr (PACK > 0) pk.sweep((int)(t & 1), tid);
     f32x4 acc[UTW];
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -475,10 +867,18 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
     dgn_buf = tmp;
   };
   int64_t t0 = T - 1;
-  for (; t0 - (PFW - 1) >= 0; t0 -= PFW) {
+  if (T >= PFW) {  // the first group peeled, the loop inside its branch (see the forward)
 #pragma unroll
     for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
+    for (t0 -= PFW; t0 - (PFW - 1) >= 0; t0 -= PFW) {
+      if (done && !dwin.holds(t0 - (PFW - 1), t0))
+        dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
+#pragma unroll
+      for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
+    }
   }
+  if (done && t0 >= 0 && !dwin.holds(0, t0))
+    dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
 #pragma unroll
   for (int d = 0; d < PFW; ++d)
     if (t0 - d >= 0) step(t0 - d, inq[d]);
@@ -492,6 +892,21 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
 }
 
 bool mfma_shape_ok(int64_t H) { return H >= 32 && H <= 128 && H % 32 == 0; }
+constexpr int kPack = 4;  // rows per workgroup of the packed-store instantiations
+
+// Rows of its 16-row tile a workgroup fills.  A time step is a short dependent chain (LDS
+// exchange, 2 KS MFMAs per gate, the gate math) whose length does not depend on the fill, and a
+// CU drains the step's stores at ~20 B/clk (T = 30, B = 1024, H = 64 training forward: 15 us with
+// the stores compiled out, 33 us with them, on 64 of the 256 CUs).  So a batch that would leave
+// CUs idle is spread thinner: fewer rows per workgroup, more workgroups.  MIPPO_GRU_ROWS pins it.
+int rows_per_group(int64_t B) {
+  const char* e = getenv("MIPPO_GRU_ROWS");  // read per launch: the tests switch it
+  const int pinned = e ? atoi(e) : 0;
+  if (pinned == 4 || pinned == 8 || pinned == 16) return pinned;
+  // full tiles once they cover the chip; below that 4 rows, whose stores go out packed
+  // (PackedStores) — 8 rows with the direct stores measured no better than 16 in the forward
+  return mippo::ceil_div(B, (int64_t)GROWS) >= 256 ? GROWS : kPack;
+}
 
 }  // namespace
 
@@ -509,40 +924,47 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
              "mi_gru_seq_fwd_bf16: null pointer");
   MI_REQUIRE((h_prev_out == nullptr) == (gates_out == nullptr),
              "mi_gru_seq_fwd_bf16: h_prev_out and gates_out go together");
-  const size_t lds = (size_t)2 * GROWS * (H + 8) * sizeof(bf16_t);
-  const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
-  hipStream_t st = mippo::as_stream(stream);
-  const bool guard = B % GROWS != 0;
+  const int rpw = rows_per_group(B);
+  const bool pack = rpw == kPack;
   bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
-#define MI_GRU_FWD(TRAIN, HH, GUARD, BF)                                                       \
-  hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, HH, GUARD, BF>), grid, dim3(kThreads), lds, st, \
-                     gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final, hpb, T, B,  \
-                     GruTail{})
-#define MI_GRU_FWD_H(HH)                                                       \
-  if (H == HH) {                                                               \
-    if (!h_prev_out) {                                                         \
-      if (guard) MI_GRU_FWD(false, HH, true, false);                           \
-      else MI_GRU_FWD(false, HH, false, false);                                \
-    } else if (hpb) {                                                          \
-      if (guard) MI_GRU_FWD(true, HH, true, true);                             \
-      else MI_GRU_FWD(true, HH, false, true);                                  \
-    } else {                                                                   \
-      if (guard) MI_GRU_FWD(true, HH, true, false);                            \
-      else MI_GRU_FWD(true, HH, false, false);                                 \
-    }                                                                          \
+  const size_t lds =
+      (size_t)2 * GROWS * (H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
+      (pack ? packed_lds(fwd_rec_bytes((int)H, h_prev_out != nullptr, hpb != nullptr, false), kPack)
+            : 0);
+  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
+  hipStream_t st = mippo::as_stream(stream);
+  const bool guard = rpw < GROWS || B % GROWS != 0;
+#define MI_GRU_FWD(TRAIN, HH, GUARD, BF, PACK)                                                  \
+  hipLaunchKernelGGL((gru_fwd_mfma_kernel<TRAIN, HH, GUARD, BF, false, PACK>), grid,            \
+                     dim3(kThreads), lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out,       \
+                     gates_out, h_final, hpb, T, B, rpw, GruTail{})
+#define MI_GRU_FWD_G(TRAIN, HH, BF)                    \
+  {                                                    \
+    if (pack) MI_GRU_FWD(TRAIN, HH, true, BF, kPack);  \
+    else if (guard) MI_GRU_FWD(TRAIN, HH, true, BF, 0); \
+    else MI_GRU_FWD(TRAIN, HH, false, BF, 0);          \
+  }
+#define MI_GRU_FWD_H(HH)                              \
+  if (H == HH) {                                      \
+    if (!h_prev_out) MI_GRU_FWD_G(false, HH, false)   \
+    else if (hpb) MI_GRU_FWD_G(true, HH, true)        \
+    else MI_GRU_FWD_G(true, HH, false)                \
   }
   MI_GRU_FWD_H(32)
   MI_GRU_FWD_H(64)
   MI_GRU_FWD_H(96)
   MI_GRU_FWD_H(128)
 #undef MI_GRU_FWD_H
+#undef MI_GRU_FWD_G
 #undef MI_GRU_FWD
   return mippo::check_launch("mi_gru_seq_fwd_bf16");
 }
 
 // LDS of the TAIL form: the two carry tiles + the T x 16-row history + the head's rows
 static size_t gru_tail_lds(int64_t T, int64_t H, int64_t N_out) {
-  return (size_t)(2 + T) * GROWS * (H + 8) * sizeof(bf16_t) + (size_t)T * GROWS * N_out * 4;
+  return (size_t)(2 + T) * GROWS * (H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
+         packed_lds(fwd_rec_bytes((int)H, true, true, true), kPack) +  // (whether packed or not)
+         (size_t)T * GROWS * N_out * 4;
 }
 
 extern "C" int mi_gru_seq_fwd_tail_supported(int64_t T, int64_t H, int64_t N_out) {
@@ -577,24 +999,26 @@ extern "C" int mi_gru_seq_fwd_tail_bf16(
                    loglik, reg, (int)(N_out / 2), min_std, std_scale, entropy_weight, 0},
                   (int)N_out};
   const size_t lds = gru_tail_lds(T, H, N_out);
-  const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
+  const int rpw = rows_per_group(B);
+  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
   hipStream_t st = mippo::as_stream(stream);
-  const bool guard = B % GROWS != 0;
+  const bool guard = rpw < GROWS || B % GROWS != 0;
   bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
-#define MI_GRU_TAIL(HH, GUARD)                                                                   \
+#define MI_GRU_TAIL(HH, GUARD, PACK)                                                             \
   {                                                                                              \
     static const hipError_t attr = hipFuncSetAttribute(                                          \
-        reinterpret_cast<const void*>(&gru_fwd_mfma_kernel<true, HH, GUARD, true, true>),        \
+        reinterpret_cast<const void*>(&gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK>),  \
         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
     MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
-    hipLaunchKernelGGL((gru_fwd_mfma_kernel<true, HH, GUARD, true, true>), grid, dim3(kThreads), \
-                       lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out, gates_out, h_final,  \
-                       hpb, T, B, tail);                                                         \
+    hipLaunchKernelGGL((gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK>), grid,           \
+                       dim3(kThreads), lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out,      \
+                       gates_out, h_final, hpb, T, B, rpw, tail);                                \
   }
-#define MI_GRU_TAIL_H(HH)            \
-  if (H == HH) {                     \
-    if (guard) MI_GRU_TAIL(HH, true) \
-    else MI_GRU_TAIL(HH, false)      \
+#define MI_GRU_TAIL_H(HH)                            \
+  if (H == HH) {                                     \
+    if (rpw == kPack) MI_GRU_TAIL(HH, true, kPack)   \
+    else if (guard) MI_GRU_TAIL(HH, true, 0)         \
+    else MI_GRU_TAIL(HH, false, 0)                   \
   }
   MI_GRU_TAIL_H(32)
   MI_GRU_TAIL_H(64)
@@ -613,32 +1037,104 @@ extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const f
              "mi_gru_seq_bwd_bf16: bad shape");
   MI_REQUIRE(g_h && gates && h_prev && w_h && dgi && (dgh || dgh_bf),
              "mi_gru_seq_bwd_bf16: null pointer (dgh or its bf16 image is required)");
-  const size_t lds = (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t);
-  const dim3 grid((unsigned)mippo::ceil_div(B, GROWS));
-  hipStream_t st = mippo::as_stream(stream);
-  const bool guard = B % GROWS != 0;
+  const int rpw = rows_per_group(B);
+  const bool pack = rpw == kPack;
   bf16_t* gb = static_cast<bf16_t*>(dgh_bf);
-#define MI_GRU_BWD(HH, GUARD, F32, BF)                                                       \
-  hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, F32, BF>), grid, dim3(kThreads), lds, st, \
-                     g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, gb, T, B)
-#define MI_GRU_BWD_H(HH)                                      \
-  if (H == HH) {                                              \
-    if (dgh && gb) {                                          \
-      if (guard) MI_GRU_BWD(HH, true, true, true);            \
-      else MI_GRU_BWD(HH, false, true, true);                 \
-    } else if (gb) {                                          \
-      if (guard) MI_GRU_BWD(HH, true, false, true);           \
-      else MI_GRU_BWD(HH, false, false, true);                \
-    } else {                                                  \
-      if (guard) MI_GRU_BWD(HH, true, true, false);           \
-      else MI_GRU_BWD(HH, false, true, false);                \
-    }                                                         \
+  const size_t lds =
+      (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
+      (pack ? packed_lds(bwd_rec_bytes((int)H, dgh != nullptr, gb != nullptr), kPack) : 0);
+  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
+  hipStream_t st = mippo::as_stream(stream);
+  const bool guard = rpw < GROWS || B % GROWS != 0;
+#define MI_GRU_BWD(HH, GUARD, F32, BF, PACK)                                                    \
+  hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, F32, BF, false, PACK>), grid,              \
+                     dim3(kThreads), lds, st, g_h, gates, h_prev, w_h, done, dgi, dgh, dh0, gb, \
+                     T, B, rpw, GruBwdTail{})
+#define MI_GRU_BWD_G(HH, F32, BF)                     \
+  {                                                   \
+    if (pack) MI_GRU_BWD(HH, true, F32, BF, kPack);   \
+    else if (guard) MI_GRU_BWD(HH, true, F32, BF, 0); \
+    else MI_GRU_BWD(HH, false, F32, BF, 0);           \
+  }
+#define MI_GRU_BWD_H(HH)                        \
+  if (H == HH) {                                \
+    if (dgh && gb) MI_GRU_BWD_G(HH, true, true) \
+    else if (gb) MI_GRU_BWD_G(HH, false, true)  \
+    else MI_GRU_BWD_G(HH, true, false)          \
   }
   MI_GRU_BWD_H(32)
   MI_GRU_BWD_H(64)
   MI_GRU_BWD_H(96)
   MI_GRU_BWD_H(128)
 #undef MI_GRU_BWD_H
+#undef MI_GRU_BWD_G
 #undef MI_GRU_BWD
   return mippo::check_launch("mi_gru_seq_bwd_bf16");
+}
+
+static size_t gru_bwd_tail_lds(int64_t T, int64_t H) {
+  return (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
+         packed_lds(bwd_rec_bytes((int)H, false, true), kPack) +  // (whether packed or not)
+         (size_t)T * GROWS * (32 + 8) * 2;
+}
+
+extern "C" int mi_gru_seq_bwd_tail_supported(int64_t T, int64_t H, int64_t N_out) {
+  return T >= 1 && mfma_shape_ok(H) && N_out >= 2 && N_out <= 16 && N_out % 2 == 0 &&
+         gru_bwd_tail_lds(T, H) <= 96 * 1024;
+}
+
+// mi_gru_seq_bwd_bf16 (bf16 image of dgh out) with the sampler's backward and the head's dX in
+// front of it INSIDE the launch — see GruBwdTail.  w_out_bwd: backward fragment-major image of
+// the head's kernel; ms / extras / rng / g_ll / g_reg: mi_tanh_gauss_bwd_f32's operands with
+// rows t * B + env; dz_out_bf [T*B, pad8(N_out)]: the head's output-gradient image (its dW
+// operand), written here.
+extern "C" int mi_gru_seq_bwd_tail_bf16(
+    const float* gates, const float* h_prev, const float* w_h, const uint8_t* done, float* dgi,
+    float* dh0, void* dgh_bf, const void* w_out_bwd, int64_t N_out, const float* mean_and_std,
+    const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
+    const float* g_loglik, float g_reg, float min_std, float std_scale, float entropy_weight,
+    void* dz_out_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
+  const char* who = "mi_gru_seq_bwd_tail_bf16";
+  MI_REQUIRE(B >= 1 && B * 4 * H < (1LL << 31) && mi_gru_seq_bwd_tail_supported(T, H, N_out),
+             "%s: T=%lld H=%lld N_out=%lld outside the supported class", who, (long long)T,
+             (long long)H, (long long)N_out);
+  MI_REQUIRE(gates && h_prev && w_h && dgi && dgh_bf && w_out_bwd && mean_and_std && extras &&
+                 dz_out_bf,
+             "%s: null pointer", who);
+  MI_REQUIRE(rng_state || eps2, "%s: need rng_state or injected entropy noise", who);
+  MI_REQUIRE(al16(w_out_bwd) && al16(dz_out_bf), "%s: buffers must be 16-byte aligned", who);
+  GruBwdTail tail = {static_cast<const bf16_t*>(w_out_bwd), static_cast<bf16_t*>(dz_out_bf),
+                     mippo::ceil_div(N_out, 8) * 8,
+                     {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
+                      (int)(N_out / 2), min_std, std_scale, entropy_weight},
+                     (int)N_out};
+  const size_t lds = gru_bwd_tail_lds(T, H);
+  const int rpw = rows_per_group(B);
+  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
+  hipStream_t st = mippo::as_stream(stream);
+  const bool guard = rpw < GROWS || B % GROWS != 0;
+  bf16_t* gb = static_cast<bf16_t*>(dgh_bf);
+#define MI_GRU_BT(HH, GUARD, PACK)                                                               \
+  {                                                                                              \
+    static const hipError_t attr = hipFuncSetAttribute(                                          \
+        reinterpret_cast<const void*>(&gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
+    MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
+    hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK>), grid,          \
+                       dim3(kThreads), lds, st, nullptr, gates, h_prev, w_h, done, dgi, nullptr, \
+                       dh0, gb, T, B, rpw, tail);                                                \
+  }
+#define MI_GRU_BT_H(HH)                          \
+  if (H == HH) {                                 \
+    if (rpw == kPack) MI_GRU_BT(HH, true, kPack) \
+    else if (guard) MI_GRU_BT(HH, true, 0)       \
+    else MI_GRU_BT(HH, false, 0)                 \
+  }
+  MI_GRU_BT_H(32)
+  MI_GRU_BT_H(64)
+  MI_GRU_BT_H(96)
+  MI_GRU_BT_H(128)
+#undef MI_GRU_BT_H
+#undef MI_GRU_BT
+  return mippo::check_launch(who);
 }

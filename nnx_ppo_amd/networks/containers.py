@@ -8,7 +8,7 @@ from typing import Any
 
 import torch
 
-from .. import config
+from .. import config, ops
 from .types import ModuleState, StatefulModule, StatefulModuleOutput, add_reg, zero_scalar
 
 
@@ -25,6 +25,9 @@ BOOTSTRAP_IN_CHAIN = os.environ.get("MIPPO_BOOTSTRAP_IN_CHAIN", "1") != "0"
 # a linear head + sampler behind a recurrent layer inside its sequence launch
 # (recurrent.GRU.replay(tail=...)); MIPPO_REC_TAIL=0: their own launches (A/B, bit-identity tests)
 REC_TAIL = os.environ.get("MIPPO_REC_TAIL", "1") != "0"
+# ... and their backward in front of the BPTT inside ITS launch (GRU.replay_backward_tail);
+# MIPPO_REC_TAIL_BWD=0: mi_tanh_gauss_bwd_f32 + mi_mlp_bwd_dx_bf16 + mi_gru_seq_bwd_bf16
+REC_TAIL_BWD = os.environ.get("MIPPO_REC_TAIL_BWD", "1") != "0"
 
 
 class Sequential(StatefulModule):
@@ -159,8 +162,13 @@ class Sequential(StatefulModule):
                     i = j + 1
                     if tail is not None:
                         head_ctx, samp_ctx, out_d, reg_s = res[4]
-                        ctxs.append(("chain", j + 1, j + 2, head_ctx, lead))
-                        ctxs.append(("layer", j + 2, samp_ctx))
+                        if REC_TAIL_BWD and ops.gru_seq_bwd_tail_supported(
+                                lead[0], rec.hidden_features, self.layers[j + 1].out_features):
+                            # the mirror image in the backward: one entry, one launch
+                            ctxs[-1] = ("chain+rec+tail", *ctxs[-1][1:], head_ctx, samp_ctx)
+                        else:
+                            ctxs.append(("chain", j + 1, j + 2, head_ctx, lead))
+                            ctxs.append(("layer", j + 2, samp_ctx))
                         final_state.extend([state0[j + 1], ()])
                         reg = add_reg(reg, reg_s)
                         x = out_d
@@ -242,12 +250,16 @@ class Sequential(StatefulModule):
     def replay_backward(self, ctxs, g_out, g_reg):
         g = g_out
         for entry in reversed(ctxs):
-            if entry[0] == "chain+rec":
+            if entry[0] in ("chain+rec", "chain+rec+tail"):
                 from . import dense_chain
 
-                _, i, j, cctx, lead, rctx = entry
+                _, i, j, cctx, lead, rctx = entry[:6]
                 rec = self.layers[j]
-                dgi = rec.replay_backward(rctx, g, g_reg)
+                if entry[0] == "chain+rec+tail":
+                    dgi = rec.replay_backward_tail(rctx, self.layers[j + 1], entry[6],
+                                                   self.layers[j + 2], entry[7], g, g_reg)
+                else:
+                    dgi = rec.replay_backward(rctx, g, g_reg)
                 d2 = dgi.reshape(-1, dgi.shape[-1])
                 gi = dense_chain.backward(list(self.layers[i:j]) + [rec.chain_projection()], cctx,
                                           d2 if d2.is_contiguous() else d2.contiguous())

@@ -169,6 +169,25 @@ class GRU(StatefulModule):
         ctx = (x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx)
         return ctx, h_out, None, h_final
 
+    def replay_backward_tail(self, ctx, head, head_ctx, sampler, samp_ctx, g_out, g_reg):
+        """`replay_backward` of a `replay(tail=...)`: the sampler's backward and the head's dX
+        run in front of the BPTT inside its launch (`mi_gru_seq_bwd_tail_bf16`); the head's
+        dW joins the step's grouped dW requests.  `g_out`: the sampler's output gradient dict.
+        Returns the gradient w.r.t. `gi_seq`."""
+        x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx
+        ms2, ex2, off, eps2, _ = samp_ctx
+        H = self.hidden_features
+        g_ll = g_out["log_likelihood"]
+        g_ll = None if g_ll is None else g_ll.reshape(T * B).contiguous()
+        dgi, dgh_bf, dz_bf = ops.gru_seq_bwd_tail(
+            gates, h_prev, self.w_h.data, done_seq.contiguous(), head._fb, head.out_features,
+            ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, eps2=eps2, **sampler._kw())
+        ops.dense_bwd_dw_grouped_bf16([(head_ctx[0][0][0], dz_bf, head.kernel.grad,
+                                        head.bias.grad)], accumulate=True)
+        ops.dense_bwd_dw_grouped_bf16([(h_prev.bf16_image, dgh_bf, self.w_h.grad,
+                                        self.b_hn.grad)], accumulate=True, bias_first=[2 * H])
+        return dgi
+
     def replay_backward(self, ctx, g_out, g_reg):
         x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx
         H = self.hidden_features

@@ -417,7 +417,8 @@ def _dw_group(grp: list, accumulate: bool, fold) -> None:
     Ns = [g[2].shape[1] for g in grp]
     for (x_bf, dz_bf, g_w, g_b), K, N in zip(grp, Ks, Ns):
         _need(x_bf.shape == (M, pad8(K)) and dz_bf.shape == (M, pad8(N)),
-              "dense_bwd_dw_grouped_bf16: operands must be [M, pad8(K)] / [M, pad8(N)]")
+              "dense_bwd_dw_grouped_bf16: operands must be [M, pad8(K)] / [M, pad8(N)], got "
+              f"{tuple(x_bf.shape)} / {tuple(dz_bf.shape)} for M={M} K={K} N={N}")
     P = ctypes.c_void_p * n
     I = ctypes.c_int64 * n
     Kc, Nc = I(*Ks), I(*Ns)
@@ -1739,6 +1740,37 @@ def gru_seq_fwd_tail(gi, w_h, b_hn, h0, done, w_out_ff, b_out, N_out: int, extra
         "mi_gru_seq_fwd_tail_bf16")
     h_prev.bf16_image = hp_bf
     return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg
+
+
+def gru_seq_bwd_tail_supported(T: int, H: int, N_out: int) -> bool:
+    return bool(lib().mi_gru_seq_bwd_tail_supported(int(T), int(H), int(N_out)))
+
+
+def gru_seq_bwd_tail(gates, h_prev, w_h, done, w_out_fb, N_out: int, mean_and_std, extras,
+                     rng_state, offset_add: int, g_ll, g_reg: float, *, min_std: float,
+                     std_scale: float, entropy_weight: float, eps2=None):
+    """`gru_seq_bwd(mfma=True, dgh_as_bf16=True)` with the sampler's backward and the head's dX
+    in front of the BPTT inside the launch (`mi_gru_seq_bwd_tail_bf16`).  Returns
+    (dgi [T,B,3H], dgh bf16 image [T*B, 3H], dz_out bf16 image [T*B, pad8(N_out)] — the
+    head's dW operand)."""
+    T, B, H = h_prev.shape
+    dev = h_prev.device
+    M = T * B
+    _need(mean_and_std.shape == (M, N_out) and extras.shape == (M, N_out // 2),
+          "gru_seq_bwd_tail: sampler operands must be [T*B, N_out] / [T*B, A]")
+    if g_ll is not None:
+        _need(g_ll.shape == (M,) and g_ll.is_contiguous(), "gru_seq_bwd_tail: g_ll must be [T*B]")
+    dgi = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
+    dgh_bf = torch.empty(M, 3 * H, dtype=bf16, device=dev)
+    dz_bf = torch.empty(M, (N_out + 7) // 8 * 8, dtype=bf16, device=dev)
+    d = None if done is None else _as_u8(done)
+    check(lib().mi_gru_seq_bwd_tail_bf16(
+        ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d), ptr(dgi, f32), None,
+        ptr(dgh_bf), ptr(w_out_fb, bf16), int(N_out), ptr(mean_and_std, f32), ptr(extras, f32),
+        ptr(rng_state), int(offset_add), ptr(eps2, f32), ptr(g_ll, f32), float(g_reg),
+        float(min_std), float(std_scale), float(entropy_weight), ptr(dz_bf), T, B, H, stream()),
+        "mi_gru_seq_bwd_tail_bf16")
+    return dgi, dgh_bf, dz_bf
 
 
 def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False, dgh_as_bf16: bool = False):

@@ -206,3 +206,25 @@ def test_gru_matrix_core_path_vs_oracle(dev, T, B, I, H):
             assert close(p_.grad, w)
     finally:
         config.set_compute_dtype(prev)
+
+
+@pytest.mark.parametrize("T,B,H", [(30, 1024, 64), (7, 37, 96), (3, 4099, 128)])
+def test_gru_matrix_core_rows_per_workgroup(dev, monkeypatch, T, B, H):
+    """`rows_per_group` (csrc/gru_mfma.hip): a small batch is spread over more workgroups by
+    filling only 8 or 4 rows of each 16-row tile.  Rows do not interact, so the sequence kernels
+    — forward (training form) and BPTT — must return the same bits whatever the fill."""
+    from nnx_ppo_amd import ops
+
+    gen = torch.Generator(device="cpu").manual_seed(T * B + H)
+    r = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    gi, w_h, b, h0, g_h = r(T, B, 3 * H), r(H, 3 * H) / H ** 0.5, r(H), r(B, H), r(T, B, H)
+    done = (torch.rand(T, B, generator=gen) < 0.2).to(dev)
+    outs = []
+    for rows in ("16", "8", "4", ""):
+        monkeypatch.setenv("MIPPO_GRU_ROWS", rows)
+        h_out, h_prev, gates, h_final = ops.gru_seq_fwd(gi, w_h, b, h0, done, True, True)
+        dgi, dgh = ops.gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma=True, dgh_as_bf16=True)
+        outs.append((h_out, h_prev, h_prev.bf16_image, gates, h_final, dgi, dgh))
+    for other in outs[1:]:
+        for a, b_ in zip(outs[0], other):
+            assert torch.equal(a, b_)

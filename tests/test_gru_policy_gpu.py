@@ -181,7 +181,8 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
     in the sequence launch (containers.Sequential.replay, REC_TAIL).  Against the launches they
     replace — same network, same rollout, same minibatch: every loss scalar and every parameter
     gradient bit for bit (the head's MFMA tiles, k order and the sampler's row function are the
-    same), and the launch list."""
+    same), and the launch list.  The same for the backward mirror, `mi_gru_seq_bwd_tail_bf16`
+    (sampler backward + the head's dX in front of the BPTT, REC_TAIL_BWD)."""
     from nnx_ppo_amd import _lib, config
     from nnx_ppo_amd.algorithms import ppo
     from nnx_ppo_amd.envs import cartpole_shaped
@@ -189,10 +190,11 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
     from nnx_ppo_amd.networks.types import Rngs
     from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
 
-    out = []
+    out, n_launch = [], []
     with config.use_compute_dtype("bf16"):
-        for tail in (True, False):
+        for tail, tail_bwd in ((True, True), (True, False), (False, False)):
             monkeypatch.setattr(containers, "REC_TAIL", tail)
+            monkeypatch.setattr(containers, "REC_TAIL_BWD", tail_bwd)
             env = EpisodeWrapper(cartpole_shaped(max_steps=5), 1000)
             net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(9))
             ts = ppo.new_training_state(env, net, 512, 9, 3e-4, device=dev)
@@ -205,7 +207,14 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
                 assert ("mi_gru_seq_fwd_tail_bf16" in used) == tail, used
                 if tail:
                     assert "mi_tanh_gauss_fwd_f32" not in used and "mi_gru_seq_fwd_bf16" not in used
+                # ... and `mi_gru_seq_bwd_tail_bf16` their backward (REC_TAIL_BWD)
+                assert ("mi_gru_seq_bwd_tail_bf16" in used) == tail_bwd, used
+                if tail_bwd:
+                    assert not {"mi_tanh_gauss_bwd_f32", "mi_gru_seq_bwd_bf16"} & used, used
+            n_launch.append(sum(not name.endswith("_supported") for name, *_ in prof.records))
             out.append((ts.optimizer.params.clone(), ts.optimizer.m.clone(), ms))
-    (pa, ma, la), (pb, mb, lb) = out
-    assert la == lb
-    assert torch.equal(pa, pb) and torch.equal(ma, mb)
+    # 2 epochs x 2 minibatches, two launches fewer per gradient step each time
+    assert n_launch[1] - n_launch[0] == 8 and n_launch[2] - n_launch[1] == 8, n_launch
+    for (pa, ma, la), (pb, mb, lb) in zip(out, out[1:]):
+        assert la == lb
+        assert torch.equal(pa, pb) and torch.equal(ma, mb)
