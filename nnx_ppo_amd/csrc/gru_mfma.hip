@@ -713,80 +713,78 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
   const int64_t row = row0 + li;
   const bool valid = !GUARD || (li < rpw && row < B);
   const unsigned rowc = (unsigned)(valid ? row : B - 1);
-  unsigned ucol[UTW];
-  f32x4 dh[UTW];
-  const RowLanes sl(lane, row0, B, rpw, GUARD);  // the arrangement the global stores go out in
-  unsigned scol[UTW];
-#pragma unroll
-  for (int ui = 0; ui < UTW; ++ui) {
-    const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
-    ucol[ui] = (unsigned)(ut * 16 + 4 * lq);
-    scol[ui] = (unsigned)(ut * 16) + 4 * sl.chunk;
-    dh[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  Packed pk;
   if constexpr (PACK > 0) {
-    OutArray arr[N_OUT_ARR];
-    int k = 0;
-    arr[k++] = {dgi, 0, 12 * H};
-    if constexpr (F32) arr[k++] = {dgh, OFF_GH, 12 * H};
-    if constexpr (BF) arr[k++] = {dgh_bf, OFF_GB, 6 * H};
-    pk.init(stg, arr, tid, row0, B, T - 1, -1);
-  }
-  // per-step operands of the owned elements: (r, z, n, qn, g_h, h_prev); ring of PFW (the done
-  // flags: DoneWindow)
-  struct In {
-    f32x4 v[UTW][6];
-  };
-  In inq[PFW];
-  auto load_in = [&](int64_t t, In& dst) {
-    const int64_t tc = t > 0 ? t : 0;  // before the start: reload step 0
-    const float* gt = gates + tc * B * 4 * H;
-    const float* ght = TAIL ? nullptr : g_h + tc * B * H;
-    const float* hpt = h_prev + tc * B * H;
+    // ---- a small batch spread thin (rpw == PACK == 4): one element per lane, results through
+    // per-row LDS records — the forward's PACK form, same expressions per element as below
+    static_assert(PACK == 4, "the spread form is written for 4 rows per workgroup");
+    const int rr = li & 3;
+    const int64_t srow = row0 + rr;
+    const bool svalid = srow < B;
+    const unsigned srowc = (unsigned)(svalid ? srow : B - 1);
+    for (int i = tid; i < 2 * GROWS * GROW; i += kThreads) dg0[i] = (bf16_t)0.0f;  // dead rows
+    unsigned ucol[UTW];
+    float dh[UTW];
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
-      const unsigned og = rowc * (unsigned)(4 * H) + ucol[ui];
-      const unsigned o = rowc * (unsigned)H + ucol[ui];
-      dst.v[ui][0] = *reinterpret_cast<const f32x4*>(gt + og);
-      dst.v[ui][1] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)H);
-      dst.v[ui][2] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(2 * H));
-      dst.v[ui][3] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(3 * H));
-      if constexpr (!TAIL) dst.v[ui][4] = *reinterpret_cast<const f32x4*>(ght + o);
-      dst.v[ui][5] = *reinterpret_cast<const f32x4*>(hpt + o);
+      const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+      ucol[ui] = (unsigned)(ut * 16 + 4 * lq + (li >> 2));
+      dh[ui] = 0.0f;
     }
-  };
-#pragma unroll
-  for (int d = 0; d < PFW; ++d) load_in(T - 1 - d, inq[d]);
-  if (done) dwin.stage(done, T - DONE_WIN, T, B, row0, rpw, tid);
-  bf16_t* dg = dg0;
-  bf16_t* dgn_buf = dg1;
-  auto step = [&](int64_t t, In& in) {
-    const bool reset = done != nullptr && dwin.at(t, li);
-    f32x4 dhp[UTW];
-    if constexpr (TAIL) {  // g_h[t] = dz_out[t] . W_out^T: one k-step, D[unit 4 lq + e][row li]
-      const bf16x8 dzf = *reinterpret_cast<const bf16x8*>(dzs + ((int)t * GROWS + li) * DZROW +
-                                                          8 * lq);
-#pragma unroll
-      for (int ui = 0; ui < UTW; ++ui)
-        in.v[ui][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            wob[ui], dzf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    Packed pk;
+    {
+      OutArray arr[N_OUT_ARR];
+      int k = 0;
+      arr[k++] = {dgi, 0, 12 * H};
+      if constexpr (F32) arr[k++] = {dgh, OFF_GH, 12 * H};
+      if constexpr (BF) arr[k++] = {dgh_bf, OFF_GB, 6 * H};
+      pk.init(stg, arr, tid, row0, B, T - 1, -1);
     }
-    float* gio = dgi + t * B * H3;
-    float* gho = F32 ? dgh + t * B * H3 : nullptr;
-    // bf16 image of dgh [T*B][3H]: the dz operand of the recurrent kernel's dW launch
-    bf16_t* ghb = BF ? dgh_bf + t * B * H3 : nullptr;
+    struct In {
+      float v[UTW][6];  // r, z, n, qn, g_h, h_prev of the owned element
+    };
+    In inq[PFW];
+    auto load_in = [&](int64_t t, In& dst) {
+      const int64_t tc = t > 0 ? t : 0;  // before the start: reload step 0
+      const float* gt = gates + tc * B * 4 * H;
+      const float* ght = TAIL ? nullptr : g_h + tc * B * H;
+      const float* hpt = h_prev + tc * B * H;
 #pragma unroll
-    for (int ui = 0; ui < UTW; ++ui) {
-      if constexpr (UT % 4 != 0)
-        if (wave + 4 * ui >= UT) continue;  // wave-uniform (a branch: see RowLanes)
-      f32x4 a_r, a_z, a_n, g_n;
+      for (int ui = 0; ui < UTW; ++ui) {
+        const unsigned og = srowc * (unsigned)(4 * H) + ucol[ui];
+        const unsigned o = srowc * (unsigned)H + ucol[ui];
+        dst.v[ui][0] = gt[og];
+        dst.v[ui][1] = gt[og + (unsigned)H];
+        dst.v[ui][2] = gt[og + (unsigned)(2 * H)];
+        dst.v[ui][3] = gt[og + (unsigned)(3 * H)];
+        if constexpr (!TAIL) dst.v[ui][4] = ght[o];
+        dst.v[ui][5] = hpt[o];
+      }
+    };
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float r = in.v[ui][0][e], z = in.v[ui][1][e], n = in.v[ui][2][e],
-                    qn = in.v[ui][3][e];
-        const float dht = in.v[ui][4][e] + (reset ? 0.0f : dh[ui][e]);
-        const float hp = in.v[ui][5][e];
+    for (int d = 0; d < PFW; ++d) load_in(T - 1 - d, inq[d]);
+    if (done) dwin.stage(done, T - DONE_WIN, T, B, row0, rpw, tid);
+    __syncthreads();  // the zeroed tiles
+    bf16_t* dg = dg0;
+    bf16_t* dgn_buf = dg1;
+    auto step = [&](int64_t t, In& in) {
+      const bool reset = done != nullptr && dwin.at(t, rr);
+      float dhp[UTW];
+      if constexpr (TAIL) {  // g_h[t] = dz_out[t] . W_out^T: one k-step, D[unit 4 lq + e][row li]
+        const bf16x8 dzf = *reinterpret_cast<const bf16x8*>(dzs + ((int)t * GROWS + li) * DZROW +
+                                                            8 * lq);
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui)
+          in.v[ui][4] = spread4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              wob[ui], dzf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0));
+      }
+      unsigned char* const rc0 = pk.rec((int)(t & 1), rr);
+#pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        if constexpr (UT % 4 != 0)
+          if (wave + 4 * ui >= UT) continue;  // wave-uniform
+        const float r = in.v[ui][0], z = in.v[ui][1], n = in.v[ui][2], qn = in.v[ui][3];
+        const float dht = in.v[ui][4] + (reset ? 0.0f : dh[ui]);
+        const float hp = in.v[ui][5];
         const float dn = dht * (1.0f - z);
         const float dz = dht * (hp - n);
         const float dp = dht * z;
@@ -795,98 +793,221 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
         const float da_z = dz * z * (1.0f - z);
         const float da_r = dr * r * (1.0f - r);
         const float dgn = da_n * r;
-        // rows past B (GUARD) contribute nothing
-        a_r[e] = valid ? da_r : 0.0f;
-        a_z[e] = valid ? da_z : 0.0f;
-        a_n[e] = valid ? da_n : 0.0f;
-        g_n[e] = valid ? dgn : 0.0f;
-        dhp[ui][e] = valid ? dp : 0.0f;
-      }
-      if constexpr (PACK > 0) {  // into this row's record (PackedStores)
-        if (li < PACK) {
-          unsigned char* rc = pk.rec((int)(t & 1), li) + 4 * ucol[ui];
-          *reinterpret_cast<f32x4*>(rc) = a_r;
-          *reinterpret_cast<f32x4*>(rc + 4 * H) = a_z;
-          *reinterpret_cast<f32x4*>(rc + 8 * H) = a_n;
-          if constexpr (F32) {
-            *reinterpret_cast<f32x4*>(rc + OFF_GH) = a_r;
-            *reinterpret_cast<f32x4*>(rc + OFF_GH + 4 * H) = a_z;
-            *reinterpret_cast<f32x4*>(rc + OFF_GH + 8 * H) = g_n;
-          }
-          if constexpr (BF) {
-            unsigned char* rb = rc + OFF_GB - 2 * ucol[ui];
-            *reinterpret_cast<bf16x4*>(rb) = to_bf16x4(a_r);
-            *reinterpret_cast<bf16x4*>(rb + 2 * H) = to_bf16x4(a_z);
-            *reinterpret_cast<bf16x4*>(rb + 4 * H) = to_bf16x4(g_n);
-          }
-        }
-      } else {  // out through the row-major lane arrangement (RowLanes)
-        const f32x4 s_r = sl(a_r), s_z = sl(a_z), s_n = sl(a_n);
-        f32x4 s_g = s_n;
-        if constexpr (F32 || BF) s_g = sl(g_n);
-        const unsigned o3 = sl.rowc * (unsigned)H3 + scol[ui];
-        *reinterpret_cast<f32x4*>(gio + o3) = s_r;
-        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)H) = s_z;
-        *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)(2 * H)) = s_n;
+        // rows past B contribute nothing
+        const float a_r = svalid ? da_r : 0.0f, a_z = svalid ? da_z : 0.0f;
+        const float a_n = svalid ? da_n : 0.0f, g_n = svalid ? dgn : 0.0f;
+        dhp[ui] = svalid ? dp : 0.0f;
+        unsigned char* const rc = rc0 + 4 * ucol[ui];
+        *reinterpret_cast<float*>(rc) = a_r;
+        *reinterpret_cast<float*>(rc + 4 * H) = a_z;
+        *reinterpret_cast<float*>(rc + 8 * H) = a_n;
         if constexpr (F32) {
-          *reinterpret_cast<f32x4*>(gho + o3) = s_r;
-          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)H) = s_z;
-          *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)(2 * H)) = s_g;
+          *reinterpret_cast<float*>(rc + OFF_GH) = a_r;
+          *reinterpret_cast<float*>(rc + OFF_GH + 4 * H) = a_z;
+          *reinterpret_cast<float*>(rc + OFF_GH + 8 * H) = g_n;
         }
+        const bf16_t b_r = (bf16_t)a_r, b_z = (bf16_t)a_z, b_n = (bf16_t)g_n;
         if constexpr (BF) {
-          *reinterpret_cast<bf16x4*>(ghb + o3) = to_bf16x4(s_r);
-          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)H) = to_bf16x4(s_z);
-          *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)(2 * H)) = to_bf16x4(s_g);
+          unsigned char* const rb = rc + OFF_GB - 2 * ucol[ui];
+          *reinterpret_cast<bf16_t*>(rb) = b_r;
+          *reinterpret_cast<bf16_t*>(rb + 2 * H) = b_z;
+          *reinterpret_cast<bf16_t*>(rb + 4 * H) = b_n;
         }
+        dg[rr * GROW + ucol[ui]] = b_r;
+        dg[rr * GROW + H + ucol[ui]] = b_z;
+        dg[rr * GROW + 2 * H + ucol[ui]] = b_n;
       }
-      const bf16x4 b_r = to_bf16x4(a_r), b_z = to_bf16x4(a_z), b_n = to_bf16x4(g_n);
-      *reinterpret_cast<bf16x4*>(dg + li * GROW + ucol[ui]) = b_r;
-      *reinterpret_cast<bf16x4*>(dg + li * GROW + H + ucol[ui]) = b_z;
-      *reinterpret_cast<bf16x4*>(dg + li * GROW + 2 * H + ucol[ui]) = b_n;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (as in the forward: the refill stays behind its slot's use)
-    load_in(t - PFW, in);  // refill this slot: consumed PFW steps from now
-    __syncthreads();
-    if constexpr (PACK > 0) pk.sweep((int)(t & 1), tid);
-    f32x4 acc[UTW];
+      __builtin_amdgcn_sched_barrier(0);  // (the refill stays behind its slot's use)
+      load_in(t - PFW, in);
+      __syncthreads();
+      pk.sweep((int)(t & 1), tid);
+      f32x4 acc[UTW];
 #pragma unroll
-    for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
 #pragma unroll
-      for (int ui = 0; ui < UTW; ++ui)  // D[unit = 4*lq + e][row = li]
-        acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][ks], af, acc[ui], 0, 0, 0);
-    }
+        for (int ui = 0; ui < UTW; ++ui)  // D[unit = 4*lq + e][row = li]
+          acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][ks], af, acc[ui], 0, 0, 0);
+      }
 #pragma unroll
-    for (int ui = 0; ui < UTW; ++ui)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dh[ui][e] = dhp[ui][e] + acc[ui][e];
-    bf16_t* tmp = dg;  // the next step writes the other tile: one barrier per step
-    dg = dgn_buf;
-    dgn_buf = tmp;
-  };
-  int64_t t0 = T - 1;
-  if (T >= PFW) {  // the first group peeled, the loop inside its branch (see the forward)
-#pragma unroll
-    for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
-    for (t0 -= PFW; t0 - (PFW - 1) >= 0; t0 -= PFW) {
-      if (done && !dwin.holds(t0 - (PFW - 1), t0))
-        dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
+      for (int ui = 0; ui < UTW; ++ui) dh[ui] = dhp[ui] + spread4(acc[ui]);
+      bf16_t* tmp = dg;  // the next step writes the other tile: one barrier per step
+      dg = dgn_buf;
+      dgn_buf = tmp;
+    };
+    int64_t t0 = T - 1;
+    if (T >= PFW) {  // the first group peeled, the loop inside its branch (see the forward)
 #pragma unroll
       for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
+      for (t0 -= PFW; t0 - (PFW - 1) >= 0; t0 -= PFW) {
+        if (done && !dwin.holds(t0 - (PFW - 1), t0))
+          dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
+#pragma unroll
+        for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
+      }
     }
-  }
-  if (done && t0 >= 0 && !dwin.holds(0, t0))
-    dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
+    if (done && t0 >= 0 && !dwin.holds(0, t0))
+      dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
 #pragma unroll
-  for (int d = 0; d < PFW; ++d)
-    if (t0 - d >= 0) step(t0 - d, inq[d]);
-  if (dh0) {
+    for (int d = 0; d < PFW; ++d)
+      if (t0 - d >= 0) step(t0 - d, inq[d]);
+    if (dh0) {
 #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        if (wave + 4 * ui >= UT) continue;
+        if (svalid) dh0[srowc * (unsigned)H + ucol[ui]] = dh[ui];
+      }
+    }
+  } else {
+    unsigned ucol[UTW];
+    f32x4 dh[UTW];
+    const RowLanes sl(lane, row0, B, rpw, GUARD);  // the arrangement the global stores go out in
+    unsigned scol[UTW];
+  #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
-      if (wave + 4 * ui >= UT) continue;
-      if (valid) *reinterpret_cast<f32x4*>(dh0 + rowc * (unsigned)H + ucol[ui]) = dh[ui];
+      const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+      ucol[ui] = (unsigned)(ut * 16 + 4 * lq);
+      scol[ui] = (unsigned)(ut * 16) + 4 * sl.chunk;
+      dh[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // per-step operands of the owned elements: (r, z, n, qn, g_h, h_prev); ring of PFW (the done
+    // flags: DoneWindow)
+    struct In {
+      f32x4 v[UTW][6];
+    };
+    In inq[PFW];
+    auto load_in = [&](int64_t t, In& dst) {
+      const int64_t tc = t > 0 ? t : 0;  // before the start: reload step 0
+      const float* gt = gates + tc * B * 4 * H;
+      const float* ght = TAIL ? nullptr : g_h + tc * B * H;
+      const float* hpt = h_prev + tc * B * H;
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        const unsigned og = rowc * (unsigned)(4 * H) + ucol[ui];
+        const unsigned o = rowc * (unsigned)H + ucol[ui];
+        dst.v[ui][0] = *reinterpret_cast<const f32x4*>(gt + og);
+        dst.v[ui][1] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)H);
+        dst.v[ui][2] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(2 * H));
+        dst.v[ui][3] = *reinterpret_cast<const f32x4*>(gt + og + (unsigned)(3 * H));
+        if constexpr (!TAIL) dst.v[ui][4] = *reinterpret_cast<const f32x4*>(ght + o);
+        dst.v[ui][5] = *reinterpret_cast<const f32x4*>(hpt + o);
+      }
+    };
+  #pragma unroll
+    for (int d = 0; d < PFW; ++d) load_in(T - 1 - d, inq[d]);
+    if (done) dwin.stage(done, T - DONE_WIN, T, B, row0, rpw, tid);
+    bf16_t* dg = dg0;
+    bf16_t* dgn_buf = dg1;
+    auto step = [&](int64_t t, In& in) {
+      const bool reset = done != nullptr && dwin.at(t, li);
+      f32x4 dhp[UTW];
+      if constexpr (TAIL) {  // g_h[t] = dz_out[t] . W_out^T: one k-step, D[unit 4 lq + e][row li]
+        const bf16x8 dzf = *reinterpret_cast<const bf16x8*>(dzs + ((int)t * GROWS + li) * DZROW +
+                                                            8 * lq);
+  #pragma unroll
+        for (int ui = 0; ui < UTW; ++ui)
+          in.v[ui][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              wob[ui], dzf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+      float* gio = dgi + t * B * H3;
+      float* gho = F32 ? dgh + t * B * H3 : nullptr;
+      // bf16 image of dgh [T*B][3H]: the dz operand of the recurrent kernel's dW launch
+      bf16_t* ghb = BF ? dgh_bf + t * B * H3 : nullptr;
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        if constexpr (UT % 4 != 0)
+          if (wave + 4 * ui >= UT) continue;  // wave-uniform (a branch: see RowLanes)
+        f32x4 a_r, a_z, a_n, g_n;
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r = in.v[ui][0][e], z = in.v[ui][1][e], n = in.v[ui][2][e],
+                      qn = in.v[ui][3][e];
+          const float dht = in.v[ui][4][e] + (reset ? 0.0f : dh[ui][e]);
+          const float hp = in.v[ui][5][e];
+          const float dn = dht * (1.0f - z);
+          const float dz = dht * (hp - n);
+          const float dp = dht * z;
+          const float da_n = dn * (1.0f - n * n);
+          const float dr = da_n * qn;
+          const float da_z = dz * z * (1.0f - z);
+          const float da_r = dr * r * (1.0f - r);
+          const float dgn = da_n * r;
+          // rows past B (GUARD) contribute nothing
+          a_r[e] = valid ? da_r : 0.0f;
+          a_z[e] = valid ? da_z : 0.0f;
+          a_n[e] = valid ? da_n : 0.0f;
+          g_n[e] = valid ? dgn : 0.0f;
+          dhp[ui][e] = valid ? dp : 0.0f;
+        }
+        {  // out through the row-major lane arrangement (RowLanes)
+          const f32x4 s_r = sl(a_r), s_z = sl(a_z), s_n = sl(a_n);
+          f32x4 s_g = s_n;
+          if constexpr (F32 || BF) s_g = sl(g_n);
+          const unsigned o3 = sl.rowc * (unsigned)H3 + scol[ui];
+          *reinterpret_cast<f32x4*>(gio + o3) = s_r;
+          *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)H) = s_z;
+          *reinterpret_cast<f32x4*>(gio + o3 + (unsigned)(2 * H)) = s_n;
+          if constexpr (F32) {
+            *reinterpret_cast<f32x4*>(gho + o3) = s_r;
+            *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)H) = s_z;
+            *reinterpret_cast<f32x4*>(gho + o3 + (unsigned)(2 * H)) = s_g;
+          }
+          if constexpr (BF) {
+            *reinterpret_cast<bf16x4*>(ghb + o3) = to_bf16x4(s_r);
+            *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)H) = to_bf16x4(s_z);
+            *reinterpret_cast<bf16x4*>(ghb + o3 + (unsigned)(2 * H)) = to_bf16x4(s_g);
+          }
+        }
+        const bf16x4 b_r = to_bf16x4(a_r), b_z = to_bf16x4(a_z), b_n = to_bf16x4(g_n);
+        *reinterpret_cast<bf16x4*>(dg + li * GROW + ucol[ui]) = b_r;
+        *reinterpret_cast<bf16x4*>(dg + li * GROW + H + ucol[ui]) = b_z;
+        *reinterpret_cast<bf16x4*>(dg + li * GROW + 2 * H + ucol[ui]) = b_n;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (as in the forward: the refill stays behind its slot's use)
+      load_in(t - PFW, in);  // refill this slot: consumed PFW steps from now
+      __syncthreads();
+      f32x4 acc[UTW];
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
+  #pragma unroll
+        for (int ui = 0; ui < UTW; ++ui)  // D[unit = 4*lq + e][row = li]
+          acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][ks], af, acc[ui], 0, 0, 0);
+      }
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui)
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) dh[ui][e] = dhp[ui][e] + acc[ui][e];
+      bf16_t* tmp = dg;  // the next step writes the other tile: one barrier per step
+      dg = dgn_buf;
+      dgn_buf = tmp;
+    };
+    int64_t t0 = T - 1;
+    if (T >= PFW) {  // the first group peeled, the loop inside its branch (see the forward)
+  #pragma unroll
+      for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
+      for (t0 -= PFW; t0 - (PFW - 1) >= 0; t0 -= PFW) {
+        if (done && !dwin.holds(t0 - (PFW - 1), t0))
+          dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
+  #pragma unroll
+        for (int d = 0; d < PFW; ++d) step(t0 - d, inq[d]);
+      }
+    }
+    if (done && t0 >= 0 && !dwin.holds(0, t0))
+      dwin.stage(done, t0 - (DONE_WIN - 1), T, B, row0, rpw, tid);
+  #pragma unroll
+    for (int d = 0; d < PFW; ++d)
+      if (t0 - d >= 0) step(t0 - d, inq[d]);
+    if (dh0) {
+  #pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        if (wave + 4 * ui >= UT) continue;
+        if (valid) *reinterpret_cast<f32x4*>(dh0 + rowc * (unsigned)H + ucol[ui]) = dh[ui];
+      }
     }
   }
 }
