@@ -345,6 +345,31 @@ int mi_gru_seq_bwd_tail_bf16(
     const float* g_loglik, float g_reg, float min_std, float std_scale, float entropy_weight,
     void* dz_out_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
 
+/* The tail forms with the input projection inside as well (`recurrent.py:89-117`: gi = x W_i + b_i
+ * is the first line of the cell): forward, gi_t is evaluated per step from y_bf [T*B, ldy], the
+ * bf16 image of the GRU's input (the x operand of W_i's dW launch), w_i = forward fragment-major
+ * image of W_i, b_i [3H] — fp32 gi [T, B, 3H] is neither written by the Dense chain in front nor
+ * read here; backward, dgi leaves as its bf16 image dgi_bf [T*B, 3H] and the gradient of the relu
+ * layer in front as dz0_bf [T*B, H] = bf16((dgi_bf . W_i^T) . relu'(y)) (w_i_bwd = backward
+ * fragment-major image), the dz operands of the two dW problems — the chain's backward launch
+ * goes.  Class: mi_gru_seq_proj_supported (the tail forms' class, K_in == H, ldy == H, and a
+ * batch that runs in the 4-rows-per-workgroup form).  Bit-identical to the launches replaced. */
+int mi_gru_seq_proj_supported(int64_t T, int64_t B, int64_t H, int64_t K_in, int64_t N_out);
+int mi_gru_seq_fwd_proj_tail_bf16(
+    const void* y_bf, int64_t ldy, const void* w_i, const float* b_i, const float* w_h,
+    const float* b_hn, const float* h0, const uint8_t* done, float* h_out, float* h_prev_out,
+    float* gates_out, float* h_final, void* h_prev_bf, const void* w_out, const float* b_out,
+    int64_t N_out, float* ms_out, void* h_bf_out, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, float min_std, float std_scale, float entropy_weight,
+    float* loglik, float* reg, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+int mi_gru_seq_bwd_proj_tail_bf16(
+    const void* y_bf, int64_t ldy, const void* w_i_bwd, void* dgi_bf, void* dz0_bf,
+    const float* gates, const float* h_prev, const float* w_h, const uint8_t* done, float* dh0,
+    void* dgh_bf, const void* w_out_bwd, int64_t N_out, const float* mean_and_std,
+    const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
+    const float* g_loglik, float g_reg, float min_std, float std_scale, float entropy_weight,
+    void* dz_out_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+
 /* mi_gru_seq_fwd_bf16 (training form) with the layers BEHIND the recurrence of
  * make_gru_actor_critic's actor in the same launch: Dense(H -> N_out = 2A) (`feedforward.py:42-51`;
  * w_out = its forward fragment-major image) and NormalTanhSampler in replay mode

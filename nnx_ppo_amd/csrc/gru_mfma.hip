@@ -176,8 +176,8 @@ struct PackedStores {
 constexpr int fwd_rec_bytes(int H, bool TRAIN, bool BF, bool TAIL) {
   return 4 * H + (TRAIN ? 20 * H : 0) + (TRAIN && BF ? 2 * H : 0) + (TAIL ? 2 * H : 0);
 }
-constexpr int bwd_rec_bytes(int H, bool F32, bool BF) {
-  return 12 * H + (F32 ? 12 * H : 0) + (BF ? 6 * H : 0);
+constexpr int bwd_rec_bytes(int H, bool F32, bool BF, bool PROJ = false) {
+  return PROJ ? 12 * H : 12 * H + (F32 ? 12 * H : 0) + (BF ? 6 * H : 0);  // PROJ: two bf16 images
 }
 constexpr int packed_lds(int rec_bytes, int pack) { return 2 * pack * (rec_bytes + 16); }
 
@@ -202,7 +202,20 @@ constexpr int packed_lds(int rec_bytes, int pack) { return 2 * pack * (rec_bytes
 // its T x 16 rows in parallel.  Two launches (a 1024-row-tile chain walk and the sampler)
 // leave the critical path of every gradient step; same MFMA tiles, same k order, same row
 // function: bit-identical to them.
+// PROJ (with TAIL, PACK): the input projection gi_t = y_t W_i + b_i is evaluated per step from
+// the bf16 image of the layer in front (the x operand of W_i's dW launch, which exists anyway)
+// instead of being read back as fp32 [T, B, 3H]: the Dense chain in front stops one layer
+// earlier and 2 x 12 H bytes per row and step never touch memory.  Same MFMA tiles and k order
+// as the chain kernel's last layer, bias added to the finished sum: the same bits.
+struct GruProj {
+  const bf16_t* y;   // [T * B][ldy] bf16 image of the GRU's input (in_features == H)
+  int64_t ldy;
+  const bf16_t* wi;  // forward fragment-major image of W_i [H -> 3H]
+  const float* bi;   // [3H]
+};
+
 struct GruTail {
+  GruProj proj;
   const bf16_t* wo;   // forward fragment-major image of the head's kernel [H -> N_out <= 16]
   const float* bo;    // [N_out] or null
   float* ms_out;      // [T * B][N_out] fp32: the head's rows (the sampler backward's input)
@@ -211,7 +224,8 @@ struct GruTail {
   int N_out;
 };
 
-template <bool TRAIN, int H, bool GUARD, bool BF, bool TAIL = false, int PACK = 0>
+template <bool TRAIN, int H, bool GUARD, bool BF, bool TAIL = false, int PACK = 0,
+          bool PROJ = false>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
@@ -326,14 +340,44 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
       pk.init(stg, arr, tid, row0, B, 0, +1);
     }
     const int64_t last_t = T - 1;
-    float gq[PFW][UTW][3];  // gi of steps t .. t+PFW-1 for the owned elements
-    auto load_step = [&](int64_t t, float (&dst)[UTW][3]) {
+    // per-step operands, PFW steps ahead: gi of the owned elements — or (PROJ) the B operand of
+    // the projection, the 8 inputs of tile row li per k-step
+    struct Slot {
+      float g[UTW][3];
+      bf16x8 y[KS];
+    };
+    Slot gq[PFW];
+    bf16x8 wif[PROJ ? UTW : 1][3][KS];
+    float biv[PROJ ? UTW : 1][3];
+    if constexpr (PROJ) {
+      static_assert(TAIL, "PROJ comes with TAIL");
+#pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          biv[ui][g] = tail.proj.bi[g * H + ucol[ui]];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)  // block (column tile g UT + ut, ks) of the image
+            wif[ui][g][ks] = *reinterpret_cast<const bf16x8*>(
+                tail.proj.wi + ((size_t)((g * UT + ut) * KS + ks) << 9) + lane * 8);
+        }
+      }
+    }
+    auto load_step = [&](int64_t t, Slot& dst) {
       const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
-      const float* gt = gi + tc * B * H3;
+      if constexpr (PROJ) {
+        const bf16_t* yt = tail.proj.y + (tc * B + rowc) * tail.proj.ldy + 8 * lq;
 #pragma unroll
-      for (int ui = 0; ui < UTW; ++ui)
+        for (int ks = 0; ks < KS; ++ks) dst.y[ks] = *reinterpret_cast<const bf16x8*>(yt + ks * 32);
+      } else {
+        const float* gt = gi + tc * B * H3;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) dst[ui][g] = gt[srowc * (unsigned)H3 + (unsigned)(g * H) + ucol[ui]];
+        for (int ui = 0; ui < UTW; ++ui)
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            dst.g[ui][g] = gt[srowc * (unsigned)H3 + (unsigned)(g * H) + ucol[ui]];
+      }
     };
 #pragma unroll
     for (int d = 0; d < PFW; ++d) load_step(d, gq[d]);
@@ -341,8 +385,20 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     __syncthreads();
     bf16_t* hb = hb0;
     bf16_t* hbn = hb1;
-    auto step = [&](int64_t t, float (&gcur)[UTW][3]) {
+    auto step = [&](int64_t t, Slot& gcur) {
       const bool reset = done != nullptr && dwin.at(t, rr);
+      if constexpr (PROJ) {  // gi of this step (does not wait for the carry)
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wif[ui][g][ks], gcur.y[ks], a, 0, 0, 0);
+            gcur.g[ui][g] = spread4(a) + biv[ui][g];
+          }
+      }
       f32x4 acc[UTW][3];
 #pragma unroll
       for (int ui = 0; ui < UTW; ++ui)
@@ -364,10 +420,10 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
         if constexpr (UT % 4 != 0)
           if (wave + 4 * ui >= UT) continue;  // wave-uniform
         const float hp = hc[ui];
-        const float r = fast_sigmoid(gcur[ui][0] + spread4(acc[ui][0]));
-        const float z = fast_sigmoid(gcur[ui][1] + spread4(acc[ui][1]));
+        const float r = fast_sigmoid(gcur.g[ui][0] + spread4(acc[ui][0]));
+        const float z = fast_sigmoid(gcur.g[ui][1] + spread4(acc[ui][1]));
         const float qn = spread4(acc[ui][2]) + bnv[ui];
-        const float n = fast_tanh(gcur[ui][2] + r * qn);
+        const float n = fast_tanh(gcur.g[ui][2] + r * qn);
         const float hnew = (1.0f - z) * n + z * hp;
         unsigned char* const rc = rc0 + 4 * ucol[ui];
         *reinterpret_cast<float*>(rc) = hnew;
@@ -615,7 +671,22 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 // is one MFMA k-step of that tile against the head's backward fragments (g_h = dz . W_out^T,
 // the product mi_mlp_bwd_dx_bf16 makes), in the lane that consumes it.  Bit-identical to the
 // three launches.
+// PROJ (mirror of the forward's GruProj): the backward of the input projection rides along.
+// dgi leaves as its bf16 image only (what the chain kernel's first act was to make of the fp32
+// tensor: the dz operand of W_i's dW), and d loss / d (pre-activation of the relu layer in front)
+// = (dgi_bf . W_i^T) . relu'(y) — the product the chain kernel made, 3H / 32 k-steps on the tile
+// of dgi this step has in LDS anyway — leaves as ITS bf16 image: the dz operand of that layer's
+// dW.  The Dense chain's backward launch, its read of fp32 dgi and the write of it here all go.
+struct GruBwdProj {
+  const bf16_t* y;     // [T * B][ldy] bf16 image of the GRU's input (post-relu)
+  int64_t ldy;
+  const bf16_t* wi_b;  // backward fragment-major image of W_i (columns = the H inputs)
+  bf16_t* dgi_bf;      // [T * B][3H]
+  bf16_t* dz0_bf;      // [T * B][ldy]
+};
+
 struct GruBwdTail {
+  GruBwdProj proj;
   const bf16_t* wo_b;  // backward fragment-major image of the head's kernel (columns = H inputs)
   bf16_t* dz_out;      // [T * B][ld_dz] bf16 image of the head's output gradient (its dW operand)
   int64_t ld_dz;       // pad8(N_out)
@@ -623,7 +694,8 @@ struct GruBwdTail {
   int N_out;
 };
 
-template <int H, bool GUARD, bool F32, bool BF, bool TAIL = false, int PACK = 0>
+template <int H, bool GUARD, bool F32, bool BF, bool TAIL = false, int PACK = 0,
+          bool PROJ = false>
 __global__ void __launch_bounds__(kThreads)
 gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gates,
                     const float* __restrict__ h_prev, const float* __restrict__ w_h,
@@ -646,10 +718,15 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
   // PACK: the output records (PackedStores); rpw == PACK
   constexpr int OFF_GH = 12 * H, OFF_GB = OFF_GH + (F32 ? 12 * H : 0);
   constexpr int N_OUT_ARR = 1 + (F32 ? 1 : 0) + (BF ? 1 : 0);
-  using Packed = PackedStores<N_OUT_ARR, bwd_rec_bytes(H, F32, BF), PACK ? PACK : 1>;
+  using Packed = PackedStores<PROJ ? 2 : N_OUT_ARR, bwd_rec_bytes(H, F32, BF, PROJ), PACK ? PACK : 1>;
+  using Packed0 = PackedStores<1, 2 * H, PACK ? PACK : 1>;  // PROJ: the rows of dz0
   unsigned char* const stg = reinterpret_cast<unsigned char*>(dg1 + GROWS * GROW) + DONE_WIN * GROWS;
+  // PROJ: the n columns of dgi [2][16][H + 8] (its r and z columns are dgh's), the dz0 records
+  constexpr int DNROW = H + 8;
+  bf16_t* const dn0 = reinterpret_cast<bf16_t*>(stg + (PACK ? Packed::LDS_BYTES : 0));
+  unsigned char* const stg0 = reinterpret_cast<unsigned char*>(dn0 + (PROJ ? 2 * GROWS * DNROW : 0));
   // TAIL: [T][16][DZROW]
-  bf16_t* const dzs = reinterpret_cast<bf16_t*>(stg + (PACK ? Packed::LDS_BYTES : 0));
+  bf16_t* const dzs = reinterpret_cast<bf16_t*>(stg0 + (PROJ ? Packed0::LDS_BYTES : 0));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -722,6 +799,8 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
     const bool svalid = srow < B;
     const unsigned srowc = (unsigned)(svalid ? srow : B - 1);
     for (int i = tid; i < 2 * GROWS * GROW; i += kThreads) dg0[i] = (bf16_t)0.0f;  // dead rows
+    if constexpr (PROJ)
+      for (int i = tid; i < 2 * GROWS * DNROW; i += kThreads) dn0[i] = (bf16_t)0.0f;
     unsigned ucol[UTW];
     float dh[UTW];
 #pragma unroll
@@ -731,7 +810,24 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
       dh[ui] = 0.0f;
     }
     Packed pk;
-    {
+    Packed0 pk0;
+    bf16x8 wib[PROJ ? UTW : 1][KS];
+    if constexpr (PROJ) {
+      static_assert(TAIL && BF && !F32, "PROJ comes with TAIL (bf16 image of dgh only)");
+      OutArray arr[2] = {{tail.proj.dgi_bf, 0, 6 * H}, {dgh_bf, 6 * H, 6 * H}};
+      pk.init(stg, arr, tid, row0, B, T - 1, -1);
+      OutArray arr0[1] = {{tail.proj.dz0_bf, 0, 2 * H}};
+      // (rows of dz0 are ldy wide; ldy == H is required, so a row is its 2H bytes)
+      pk0.init(stg0, arr0, tid, row0, B, T - 1, -1);
+#pragma unroll
+      for (int ui = 0; ui < UTW; ++ui) {
+        const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          wib[ui][ks] = *reinterpret_cast<const bf16x8*>(
+              tail.proj.wi_b + ((size_t)(ut * KS + ks) << 9) + lane * 8);
+      }
+    } else {
       OutArray arr[N_OUT_ARR];
       int k = 0;
       arr[k++] = {dgi, 0, 12 * H};
@@ -741,6 +837,7 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
     }
     struct In {
       float v[UTW][6];  // r, z, n, qn, g_h, h_prev of the owned element
+      bf16_t y[UTW];    // PROJ: the projection's input at the owned element (relu' mask)
     };
     In inq[PFW];
     auto load_in = [&](int64_t t, In& dst) {
@@ -758,6 +855,7 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
         dst.v[ui][3] = gt[og + (unsigned)(3 * H)];
         if constexpr (!TAIL) dst.v[ui][4] = ght[o];
         dst.v[ui][5] = hpt[o];
+        if constexpr (PROJ) dst.y[ui] = tail.proj.y[(tc * B + srowc) * tail.proj.ldy + ucol[ui]];
       }
     };
 #pragma unroll
@@ -766,9 +864,15 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
     __syncthreads();  // the zeroed tiles
     bf16_t* dg = dg0;
     bf16_t* dgn_buf = dg1;
+    bf16_t* dnb = dn0;  // PROJ: this step's n columns of dgi (alternates with the other tile)
     auto step = [&](int64_t t, In& in) {
       const bool reset = done != nullptr && dwin.at(t, rr);
       float dhp[UTW];
+      bf16_t ycur[UTW];  // (the slot is refilled before its relu' mask is used)
+      if constexpr (PROJ) {
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui) ycur[ui] = in.y[ui];
+      }
       if constexpr (TAIL) {  // g_h[t] = dz_out[t] . W_out^T: one k-step, D[unit 4 lq + e][row li]
         const bf16x8 dzf = *reinterpret_cast<const bf16x8*>(dzs + ((int)t * GROWS + li) * DZROW +
                                                             8 * lq);
@@ -797,21 +901,33 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
         const float a_r = svalid ? da_r : 0.0f, a_z = svalid ? da_z : 0.0f;
         const float a_n = svalid ? da_n : 0.0f, g_n = svalid ? dgn : 0.0f;
         dhp[ui] = svalid ? dp : 0.0f;
-        unsigned char* const rc = rc0 + 4 * ucol[ui];
-        *reinterpret_cast<float*>(rc) = a_r;
-        *reinterpret_cast<float*>(rc + 4 * H) = a_z;
-        *reinterpret_cast<float*>(rc + 8 * H) = a_n;
-        if constexpr (F32) {
-          *reinterpret_cast<float*>(rc + OFF_GH) = a_r;
-          *reinterpret_cast<float*>(rc + OFF_GH + 4 * H) = a_z;
-          *reinterpret_cast<float*>(rc + OFF_GH + 8 * H) = g_n;
-        }
         const bf16_t b_r = (bf16_t)a_r, b_z = (bf16_t)a_z, b_n = (bf16_t)g_n;
-        if constexpr (BF) {
-          unsigned char* const rb = rc + OFF_GB - 2 * ucol[ui];
+        if constexpr (PROJ) {  // record = bf16 images of dgi and dgh
+          const bf16_t b_an = (bf16_t)a_n;
+          unsigned char* const rb = rc0 + 2 * ucol[ui];
           *reinterpret_cast<bf16_t*>(rb) = b_r;
           *reinterpret_cast<bf16_t*>(rb + 2 * H) = b_z;
-          *reinterpret_cast<bf16_t*>(rb + 4 * H) = b_n;
+          *reinterpret_cast<bf16_t*>(rb + 4 * H) = b_an;
+          *reinterpret_cast<bf16_t*>(rb + 6 * H) = b_r;
+          *reinterpret_cast<bf16_t*>(rb + 8 * H) = b_z;
+          *reinterpret_cast<bf16_t*>(rb + 10 * H) = b_n;
+          dnb[rr * DNROW + ucol[ui]] = b_an;
+        } else {
+          unsigned char* const rc = rc0 + 4 * ucol[ui];
+          *reinterpret_cast<float*>(rc) = a_r;
+          *reinterpret_cast<float*>(rc + 4 * H) = a_z;
+          *reinterpret_cast<float*>(rc + 8 * H) = a_n;
+          if constexpr (F32) {
+            *reinterpret_cast<float*>(rc + OFF_GH) = a_r;
+            *reinterpret_cast<float*>(rc + OFF_GH + 4 * H) = a_z;
+            *reinterpret_cast<float*>(rc + OFF_GH + 8 * H) = g_n;
+          }
+          if constexpr (BF) {
+            unsigned char* const rb = rc + OFF_GB - 2 * ucol[ui];
+            *reinterpret_cast<bf16_t*>(rb) = b_r;
+            *reinterpret_cast<bf16_t*>(rb + 2 * H) = b_z;
+            *reinterpret_cast<bf16_t*>(rb + 4 * H) = b_n;
+          }
         }
         dg[rr * GROW + ucol[ui]] = b_r;
         dg[rr * GROW + H + ucol[ui]] = b_z;
@@ -821,18 +937,44 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
       load_in(t - PFW, in);
       __syncthreads();
       pk.sweep((int)(t & 1), tid);
-      f32x4 acc[UTW];
+      if constexpr (PROJ)  // the dz0 rows of the step before (written behind ITS barrier)
+        if (t != T - 1) pk0.sweep((int)((t + 1) & 1), tid);
+      f32x4 acc[UTW], acc0[PROJ ? UTW : 1];
 #pragma unroll
       for (int ui = 0; ui < UTW; ++ui) acc[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PROJ) {
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui) acc0[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(dg + li * GROW + ks * 32 + 8 * lq);
 #pragma unroll
         for (int ui = 0; ui < UTW; ++ui)  // D[unit = 4*lq + e][row = li]
           acc[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][ks], af, acc[ui], 0, 0, 0);
+        if constexpr (PROJ) {  // dgi . W_i^T: dgi = (dgh's r and z columns | its own n columns)
+          bf16x8 ai = af;
+          if (ks >= 2 * H / 32)
+            ai = *reinterpret_cast<const bf16x8*>(dnb + li * DNROW + (ks - 2 * H / 32) * 32 + 8 * lq);
+#pragma unroll
+          for (int ui = 0; ui < UTW; ++ui)
+            acc0[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wib[ui][ks], ai, acc0[ui], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int ui = 0; ui < UTW; ++ui) dh[ui] = dhp[ui] + spread4(acc[ui]);
+      if constexpr (PROJ) {
+        unsigned char* const r0 = pk0.rec((int)(t & 1), rr);
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui) {
+          if constexpr (UT % 4 != 0)
+            if (wave + 4 * ui >= UT) continue;
+          float v = spread4(acc0[ui]);
+          v *= ((float)ycur[ui] > 0.0f ? 1.0f : 0.0f);  // relu' (the chain kernel's expression)
+          *reinterpret_cast<bf16_t*>(r0 + 2 * ucol[ui]) = (bf16_t)v;
+        }
+        dnb = dnb == dn0 ? dn0 + GROWS * DNROW : dn0;
+      }
       bf16_t* tmp = dg;  // the next step writes the other tile: one barrier per step
       dg = dgn_buf;
       dgn_buf = tmp;
@@ -853,6 +995,10 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
 #pragma unroll
     for (int d = 0; d < PFW; ++d)
       if (t0 - d >= 0) step(t0 - d, inq[d]);
+    if constexpr (PROJ) {  // the dz0 rows of step 0
+      __syncthreads();
+      pk0.sweep(0, tid);
+    }
     if (dh0) {
 #pragma unroll
       for (int ui = 0; ui < UTW; ++ui) {
@@ -1093,6 +1239,71 @@ extern "C" int mi_gru_seq_fwd_tail_supported(int64_t T, int64_t H, int64_t N_out
          gru_tail_lds(T, H, N_out) <= 96 * 1024;
 }
 
+extern "C" int mi_gru_seq_bwd_tail_supported(int64_t T, int64_t H, int64_t N_out);
+
+namespace {
+
+// The TAIL launches: `proj` null = gi read from memory, else the projection inside (PROJ).
+int gru_fwd_tail_launch(const char* who, const GruProj* proj, const float* gi, const float* w_h,
+                        const float* b_hn, const float* h0, const uint8_t* done, float* h_out,
+                        float* h_prev_out, float* gates_out, float* h_final, void* h_prev_bf,
+                        const void* w_out, const float* b_out, int64_t N_out, float* ms_out,
+                        void* h_bf_out, const float* extras, const uint64_t* rng_state,
+                        uint64_t offset_add, const float* eps2, float min_std, float std_scale,
+                        float entropy_weight, float* loglik, float* reg, int64_t T, int64_t B,
+                        int64_t H, mi_stream_t stream) {
+  MI_REQUIRE(B >= 1 && B * 4 * H < (1LL << 31) && mi_gru_seq_fwd_tail_supported(T, H, N_out),
+             "%s: T=%lld H=%lld N_out=%lld outside the supported class", who, (long long)T,
+             (long long)H, (long long)N_out);
+  MI_REQUIRE((gi || proj) && w_h && b_hn && h0 && h_out && h_prev_out && gates_out && h_final &&
+                 h_prev_bf && w_out && ms_out && h_bf_out && extras && loglik && reg,
+             "%s: null pointer", who);
+  MI_REQUIRE(rng_state || eps2, "%s: need rng_state or injected entropy noise", who);
+  MI_REQUIRE(al16(w_out) && al16(h_bf_out), "%s: buffers must be 16-byte aligned", who);
+  GruTail tail = {proj ? *proj : GruProj{},
+                  static_cast<const bf16_t*>(w_out),
+                  b_out,
+                  ms_out,
+                  static_cast<bf16_t*>(h_bf_out),
+                  {extras, {rng_state, offset_add, eps2, eps2}, nullptr, nullptr, nullptr, nullptr,
+                   loglik, reg, (int)(N_out / 2), min_std, std_scale, entropy_weight, 0},
+                  (int)N_out};
+  const size_t lds = gru_tail_lds(T, H, N_out);
+  const int rpw = rows_per_group(B);
+  MI_REQUIRE(!proj || rpw == kPack, "%s: the projection rides in the small-batch form only", who);
+  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
+  hipStream_t st = mippo::as_stream(stream);
+  const bool guard = rpw < GROWS || B % GROWS != 0;
+  bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
+#define MI_GRU_TAIL(HH, GUARD, PACK, PROJ)                                                         \
+  {                                                                                                \
+    static const hipError_t attr = hipFuncSetAttribute(                                            \
+        reinterpret_cast<const void*>(                                                             \
+            &gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK, PROJ>),                        \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
+    MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                         \
+    hipLaunchKernelGGL((gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK, PROJ>), grid,       \
+                       dim3(kThreads), lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out,        \
+                       gates_out, h_final, hpb, T, B, rpw, tail);                                  \
+  }
+#define MI_GRU_TAIL_H(HH)                                  \
+  if (H == HH) {                                           \
+    if (proj) MI_GRU_TAIL(HH, true, kPack, true)           \
+    else if (rpw == kPack) MI_GRU_TAIL(HH, true, kPack, false) \
+    else if (guard) MI_GRU_TAIL(HH, true, 0, false)        \
+    else MI_GRU_TAIL(HH, false, 0, false)                  \
+  }
+  MI_GRU_TAIL_H(32)
+  MI_GRU_TAIL_H(64)
+  MI_GRU_TAIL_H(96)
+  MI_GRU_TAIL_H(128)
+#undef MI_GRU_TAIL_H
+#undef MI_GRU_TAIL
+  return mippo::check_launch(who);
+}
+
+}  // namespace
+
 // mi_gru_seq_fwd_bf16 (training form, bf16 image of h_prev) with the head Dense(H -> N_out)
 // and the tanh-Gaussian sampler in replay mode (stored raw actions `extras` scored: log-
 // likelihood and entropy regulariser out) inside the launch — see GruTail.  w_out: forward
@@ -1105,49 +1316,42 @@ extern "C" int mi_gru_seq_fwd_tail_bf16(
     const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
     float min_std, float std_scale, float entropy_weight, float* loglik, float* reg, int64_t T,
     int64_t B, int64_t H, mi_stream_t stream) {
-  const char* who = "mi_gru_seq_fwd_tail_bf16";
-  MI_REQUIRE(B >= 1 && B * 4 * H < (1LL << 31) && mi_gru_seq_fwd_tail_supported(T, H, N_out),
-             "%s: T=%lld H=%lld N_out=%lld outside the supported class", who, (long long)T,
-             (long long)H, (long long)N_out);
-  MI_REQUIRE(gi && w_h && b_hn && h0 && h_out && h_prev_out && gates_out && h_final &&
-                 h_prev_bf && w_out && ms_out && h_bf_out && extras && loglik && reg,
-             "%s: null pointer", who);
-  MI_REQUIRE(rng_state || eps2, "%s: need rng_state or injected entropy noise", who);
-  MI_REQUIRE(al16(w_out) && al16(h_bf_out), "%s: buffers must be 16-byte aligned", who);
-  GruTail tail = {static_cast<const bf16_t*>(w_out), b_out, ms_out,
-                  static_cast<bf16_t*>(h_bf_out),
-                  {extras, {rng_state, offset_add, eps2, eps2}, nullptr, nullptr, nullptr, nullptr,
-                   loglik, reg, (int)(N_out / 2), min_std, std_scale, entropy_weight, 0},
-                  (int)N_out};
-  const size_t lds = gru_tail_lds(T, H, N_out);
-  const int rpw = rows_per_group(B);
-  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
-  hipStream_t st = mippo::as_stream(stream);
-  const bool guard = rpw < GROWS || B % GROWS != 0;
-  bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
-#define MI_GRU_TAIL(HH, GUARD, PACK)                                                             \
-  {                                                                                              \
-    static const hipError_t attr = hipFuncSetAttribute(                                          \
-        reinterpret_cast<const void*>(&gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK>),  \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
-    MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
-    hipLaunchKernelGGL((gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK>), grid,           \
-                       dim3(kThreads), lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out,      \
-                       gates_out, h_final, hpb, T, B, rpw, tail);                                \
-  }
-#define MI_GRU_TAIL_H(HH)                            \
-  if (H == HH) {                                     \
-    if (rpw == kPack) MI_GRU_TAIL(HH, true, kPack)   \
-    else if (guard) MI_GRU_TAIL(HH, true, 0)         \
-    else MI_GRU_TAIL(HH, false, 0)                   \
-  }
-  MI_GRU_TAIL_H(32)
-  MI_GRU_TAIL_H(64)
-  MI_GRU_TAIL_H(96)
-  MI_GRU_TAIL_H(128)
-#undef MI_GRU_TAIL_H
-#undef MI_GRU_TAIL
-  return mippo::check_launch(who);
+  MI_REQUIRE(gi, "mi_gru_seq_fwd_tail_bf16: null gi");
+  return gru_fwd_tail_launch("mi_gru_seq_fwd_tail_bf16", nullptr, gi, w_h, b_hn, h0, done, h_out,
+                             h_prev_out, gates_out, h_final, h_prev_bf, w_out, b_out, N_out,
+                             ms_out, h_bf_out, extras, rng_state, offset_add, eps2, min_std,
+                             std_scale, entropy_weight, loglik, reg, T, B, H, stream);
+}
+
+// 1 when the input projection can ride in the sequence launches too (mi_gru_seq_fwd_proj_tail_bf16
+// / mi_gru_seq_bwd_proj_tail_bf16): the tail forms' class, a GRU whose input is as wide as its
+// state, and a batch small enough for the 4-rows-per-workgroup form (`rows_per_group`).
+extern "C" int mi_gru_seq_proj_supported(int64_t T, int64_t B, int64_t H, int64_t K_in,
+                                         int64_t N_out) {
+  return B >= 1 && K_in == H && mi_gru_seq_fwd_tail_supported(T, H, N_out) &&
+         mi_gru_seq_bwd_tail_supported(T, H, N_out) && rows_per_group(B) == kPack;
+}
+
+// mi_gru_seq_fwd_tail_bf16 with gi = y W_i + b_i evaluated inside the launch — see GruProj.
+// y_bf [T*B, ldy]: bf16 image of the GRU's input (K_in == H); w_i: forward fragment-major image
+// of W_i; b_i [3H].  Bit-identical to the Dense chain's last layer + mi_gru_seq_fwd_tail_bf16.
+extern "C" int mi_gru_seq_fwd_proj_tail_bf16(
+    const void* y_bf, int64_t ldy, const void* w_i, const float* b_i, const float* w_h,
+    const float* b_hn, const float* h0, const uint8_t* done, float* h_out, float* h_prev_out,
+    float* gates_out, float* h_final, void* h_prev_bf, const void* w_out, const float* b_out,
+    int64_t N_out, float* ms_out, void* h_bf_out, const float* extras, const uint64_t* rng_state,
+    uint64_t offset_add, const float* eps2, float min_std, float std_scale, float entropy_weight,
+    float* loglik, float* reg, int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
+  const char* who = "mi_gru_seq_fwd_proj_tail_bf16";
+  MI_REQUIRE(y_bf && w_i && b_i && ldy >= H && ldy % 8 == 0 && al16(y_bf) && al16(w_i),
+             "%s: projection operands missing or misaligned", who);
+  MI_REQUIRE(mi_gru_seq_proj_supported(T, B, H, H, N_out), "%s: outside the supported class", who);
+  const GruProj proj = {static_cast<const bf16_t*>(y_bf), ldy, static_cast<const bf16_t*>(w_i),
+                        b_i};
+  return gru_fwd_tail_launch(who, &proj, nullptr, w_h, b_hn, h0, done, h_out, h_prev_out,
+                             gates_out, h_final, h_prev_bf, w_out, b_out, N_out, ms_out, h_bf_out,
+                             extras, rng_state, offset_add, eps2, min_std, std_scale,
+                             entropy_weight, loglik, reg, T, B, H, stream);
 }
 
 extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const float* h_prev,
@@ -1196,6 +1400,7 @@ extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const f
 static size_t gru_bwd_tail_lds(int64_t T, int64_t H) {
   return (size_t)2 * GROWS * (3 * H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
          packed_lds(bwd_rec_bytes((int)H, false, true), kPack) +  // (whether packed or not)
+         (size_t)2 * GROWS * (H + 8) * sizeof(bf16_t) + packed_lds(2 * (int)H, kPack) +  // (PROJ)
          (size_t)T * GROWS * (32 + 8) * 2;
 }
 
@@ -1203,6 +1408,67 @@ extern "C" int mi_gru_seq_bwd_tail_supported(int64_t T, int64_t H, int64_t N_out
   return T >= 1 && mfma_shape_ok(H) && N_out >= 2 && N_out <= 16 && N_out % 2 == 0 &&
          gru_bwd_tail_lds(T, H) <= 96 * 1024;
 }
+
+namespace {
+
+// The BPTT TAIL launches: `proj` null = fp32 dgi out, else the projection's backward inside.
+int gru_bwd_tail_launch(const char* who, const GruBwdProj* proj, const float* gates,
+                        const float* h_prev, const float* w_h, const uint8_t* done, float* dgi,
+                        float* dh0, void* dgh_bf, const void* w_out_bwd, int64_t N_out,
+                        const float* mean_and_std, const float* extras, const uint64_t* rng_state,
+                        uint64_t offset_add, const float* eps2, const float* g_loglik, float g_reg,
+                        float min_std, float std_scale, float entropy_weight, void* dz_out_bf,
+                        int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
+  MI_REQUIRE(B >= 1 && B * 4 * H < (1LL << 31) && mi_gru_seq_bwd_tail_supported(T, H, N_out),
+             "%s: T=%lld H=%lld N_out=%lld outside the supported class", who, (long long)T,
+             (long long)H, (long long)N_out);
+  MI_REQUIRE(gates && h_prev && w_h && (dgi || proj) && dgh_bf && w_out_bwd && mean_and_std &&
+                 extras && dz_out_bf,
+             "%s: null pointer", who);
+  MI_REQUIRE(rng_state || eps2, "%s: need rng_state or injected entropy noise", who);
+  MI_REQUIRE(al16(w_out_bwd) && al16(dz_out_bf), "%s: buffers must be 16-byte aligned", who);
+  GruBwdTail tail = {proj ? *proj : GruBwdProj{},
+                     static_cast<const bf16_t*>(w_out_bwd),
+                     static_cast<bf16_t*>(dz_out_bf),
+                     mippo::ceil_div(N_out, 8) * 8,
+                     {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
+                      (int)(N_out / 2), min_std, std_scale, entropy_weight},
+                     (int)N_out};
+  const size_t lds = gru_bwd_tail_lds(T, H);
+  const int rpw = rows_per_group(B);
+  MI_REQUIRE(!proj || rpw == kPack, "%s: the projection rides in the small-batch form only", who);
+  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
+  hipStream_t st = mippo::as_stream(stream);
+  const bool guard = rpw < GROWS || B % GROWS != 0;
+  bf16_t* gb = static_cast<bf16_t*>(dgh_bf);
+#define MI_GRU_BT(HH, GUARD, PACK, PROJ)                                                         \
+  {                                                                                              \
+    static const hipError_t attr = hipFuncSetAttribute(                                          \
+        reinterpret_cast<const void*>(                                                           \
+            &gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK, PROJ>),                     \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
+    MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
+    hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK, PROJ>), grid,    \
+                       dim3(kThreads), lds, st, nullptr, gates, h_prev, w_h, done, dgi, nullptr, \
+                       dh0, gb, T, B, rpw, tail);                                                \
+  }
+#define MI_GRU_BT_H(HH)                                      \
+  if (H == HH) {                                             \
+    if (proj) MI_GRU_BT(HH, true, kPack, true)               \
+    else if (rpw == kPack) MI_GRU_BT(HH, true, kPack, false) \
+    else if (guard) MI_GRU_BT(HH, true, 0, false)            \
+    else MI_GRU_BT(HH, false, 0, false)                      \
+  }
+  MI_GRU_BT_H(32)
+  MI_GRU_BT_H(64)
+  MI_GRU_BT_H(96)
+  MI_GRU_BT_H(128)
+#undef MI_GRU_BT_H
+#undef MI_GRU_BT
+  return mippo::check_launch(who);
+}
+
+}  // namespace
 
 // mi_gru_seq_bwd_bf16 (bf16 image of dgh out) with the sampler's backward and the head's dX in
 // front of it INSIDE the launch — see GruBwdTail.  w_out_bwd: backward fragment-major image of
@@ -1215,47 +1481,35 @@ extern "C" int mi_gru_seq_bwd_tail_bf16(
     const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
     const float* g_loglik, float g_reg, float min_std, float std_scale, float entropy_weight,
     void* dz_out_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
-  const char* who = "mi_gru_seq_bwd_tail_bf16";
-  MI_REQUIRE(B >= 1 && B * 4 * H < (1LL << 31) && mi_gru_seq_bwd_tail_supported(T, H, N_out),
-             "%s: T=%lld H=%lld N_out=%lld outside the supported class", who, (long long)T,
-             (long long)H, (long long)N_out);
-  MI_REQUIRE(gates && h_prev && w_h && dgi && dgh_bf && w_out_bwd && mean_and_std && extras &&
-                 dz_out_bf,
-             "%s: null pointer", who);
-  MI_REQUIRE(rng_state || eps2, "%s: need rng_state or injected entropy noise", who);
-  MI_REQUIRE(al16(w_out_bwd) && al16(dz_out_bf), "%s: buffers must be 16-byte aligned", who);
-  GruBwdTail tail = {static_cast<const bf16_t*>(w_out_bwd), static_cast<bf16_t*>(dz_out_bf),
-                     mippo::ceil_div(N_out, 8) * 8,
-                     {mean_and_std, extras, {rng_state, offset_add, eps2, eps2}, g_loglik, g_reg,
-                      (int)(N_out / 2), min_std, std_scale, entropy_weight},
-                     (int)N_out};
-  const size_t lds = gru_bwd_tail_lds(T, H);
-  const int rpw = rows_per_group(B);
-  const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
-  hipStream_t st = mippo::as_stream(stream);
-  const bool guard = rpw < GROWS || B % GROWS != 0;
-  bf16_t* gb = static_cast<bf16_t*>(dgh_bf);
-#define MI_GRU_BT(HH, GUARD, PACK)                                                               \
-  {                                                                                              \
-    static const hipError_t attr = hipFuncSetAttribute(                                          \
-        reinterpret_cast<const void*>(&gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
-    MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
-    hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK>), grid,          \
-                       dim3(kThreads), lds, st, nullptr, gates, h_prev, w_h, done, dgi, nullptr, \
-                       dh0, gb, T, B, rpw, tail);                                                \
-  }
-#define MI_GRU_BT_H(HH)                          \
-  if (H == HH) {                                 \
-    if (rpw == kPack) MI_GRU_BT(HH, true, kPack) \
-    else if (guard) MI_GRU_BT(HH, true, 0)       \
-    else MI_GRU_BT(HH, false, 0)                 \
-  }
-  MI_GRU_BT_H(32)
-  MI_GRU_BT_H(64)
-  MI_GRU_BT_H(96)
-  MI_GRU_BT_H(128)
-#undef MI_GRU_BT_H
-#undef MI_GRU_BT
-  return mippo::check_launch(who);
+  MI_REQUIRE(dgi, "mi_gru_seq_bwd_tail_bf16: null dgi");
+  return gru_bwd_tail_launch("mi_gru_seq_bwd_tail_bf16", nullptr, gates, h_prev, w_h, done, dgi,
+                             dh0, dgh_bf, w_out_bwd, N_out, mean_and_std, extras, rng_state,
+                             offset_add, eps2, g_loglik, g_reg, min_std, std_scale,
+                             entropy_weight, dz_out_bf, T, B, H, stream);
+}
+
+// mi_gru_seq_bwd_tail_bf16 with the backward of the input projection inside — see GruBwdProj.
+// y_bf [T*B, ldy == H]: the post-relu bf16 image the forward read; w_i_bwd: backward
+// fragment-major image of W_i.  Out: dgi_bf [T*B, 3H] (instead of fp32 dgi) and dz0_bf [T*B, H],
+// the dz operands of W_i's and of the relu layer's dW.  Bit-identical to
+// mi_gru_seq_bwd_tail_bf16 + the Dense chain's backward (mi_mlp_bwd_dx_bf16) on its dgi.
+extern "C" int mi_gru_seq_bwd_proj_tail_bf16(
+    const void* y_bf, int64_t ldy, const void* w_i_bwd, void* dgi_bf, void* dz0_bf,
+    const float* gates, const float* h_prev, const float* w_h, const uint8_t* done, float* dh0,
+    void* dgh_bf, const void* w_out_bwd, int64_t N_out, const float* mean_and_std,
+    const float* extras, const uint64_t* rng_state, uint64_t offset_add, const float* eps2,
+    const float* g_loglik, float g_reg, float min_std, float std_scale, float entropy_weight,
+    void* dz_out_bf, int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
+  const char* who = "mi_gru_seq_bwd_proj_tail_bf16";
+  MI_REQUIRE(y_bf && w_i_bwd && dgi_bf && dz0_bf && ldy == H && al16(w_i_bwd) && al16(dgi_bf) &&
+                 al16(dz0_bf),
+             "%s: projection operands missing, misaligned or ldy != H", who);
+  MI_REQUIRE(mi_gru_seq_proj_supported(T, B, H, H, N_out), "%s: outside the supported class", who);
+  const GruBwdProj proj = {static_cast<const bf16_t*>(y_bf), ldy,
+                           static_cast<const bf16_t*>(w_i_bwd), static_cast<bf16_t*>(dgi_bf),
+                           static_cast<bf16_t*>(dz0_bf)};
+  return gru_bwd_tail_launch(who, &proj, gates, h_prev, w_h, done, nullptr, dh0, dgh_bf,
+                             w_out_bwd, N_out, mean_and_std, extras, rng_state, offset_add, eps2,
+                             g_loglik, g_reg, min_std, std_scale, entropy_weight, dz_out_bf, T, B,
+                             H, stream);
 }

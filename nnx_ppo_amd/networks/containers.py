@@ -28,6 +28,11 @@ REC_TAIL = os.environ.get("MIPPO_REC_TAIL", "1") != "0"
 # ... and their backward in front of the BPTT inside ITS launch (GRU.replay_backward_tail);
 # MIPPO_REC_TAIL_BWD=0: mi_tanh_gauss_bwd_f32 + mi_mlp_bwd_dx_bf16 + mi_gru_seq_bwd_bf16
 REC_TAIL_BWD = os.environ.get("MIPPO_REC_TAIL_BWD", "1") != "0"
+# ... and the recurrent layer's INPUT projection inside the sequence launches as well, forward
+# and backward (GRU.replay(proj=...): no fp32 gi / dgi round trip, the Dense chain in front
+# stops one layer earlier and its backward launch goes); MIPPO_REC_PROJ=0: the projection as
+# the chain's last layer
+REC_PROJ = os.environ.get("MIPPO_REC_PROJ", "1") != "0"
 
 
 class Sequential(StatefulModule):
@@ -135,9 +140,7 @@ class Sequential(StatefulModule):
                 if proj is not None and x.dim() == 3:
                     lead = x.shape[:-1]
                     x2 = x.reshape(-1, x.shape[-1])
-                    chain = list(self.layers[i:j]) + [proj]
-                    cctx, gi2 = dense_chain.forward_train(
-                        chain, x2 if x2.is_contiguous() else x2.contiguous(), upstream_needs)
+                    x2 = x2 if x2.is_contiguous() else x2.contiguous()
                     layer_extras = None if extras_seq is None else extras_seq[j]
                     # ... and a linear head + tanh-Gaussian sampler right behind the recurrent
                     # layer (make_gru_actor_critic's actor) ride in ITS launch: two launches
@@ -149,10 +152,31 @@ class Sequential(StatefulModule):
                             and rec.replay_tail_supported(lead[0], self.layers[j + 1],
                                                           self.layers[j + 2])):
                         tail = (self.layers[j + 1], self.layers[j + 2], extras_seq[j + 2])
-                    res = rec.replay(state0[j], None, done_seq, layer_extras,
-                                     need_input_grad=True,
-                                     gi_seq=gi2.view(*lead, gi2.shape[-1]),
-                                     **({"tail": tail} if tail is not None else {}))
+                    # ... and the projection itself inside the sequence launches when the run
+                    # is ONE relu Dense of the GRU's width whose input needs no gradient
+                    # (csrc/gru_mfma.hip: GruProj)
+                    y_bf = None
+                    if (REC_PROJ and REC_TAIL_BWD and tail is not None and j - i == 1
+                            and not upstream_needs
+                            and rec.replay_proj_supported(lead[0], lead[1], self.layers[i],
+                                                          self.layers[j + 1])
+                            and ops.gru_seq_bwd_tail_supported(
+                                lead[0], rec.hidden_features, self.layers[j + 1].out_features)):
+                        cctx, _ = dense_chain.forward_train([self.layers[i]], x2, False)
+                        y_bf = cctx[0][-1][1]  # the post-relu bf16 image
+                        if y_bf is None or tuple(y_bf.shape) != (x2.shape[0], rec.hidden_features):
+                            y_bf = None
+                    if y_bf is not None:
+                        res = rec.replay(state0[j], None, done_seq, layer_extras,
+                                         need_input_grad=True, tail=tail,
+                                         proj=(y_bf, (lead[0], lead[1])))
+                    else:
+                        chain = list(self.layers[i:j]) + [proj]
+                        cctx, gi2 = dense_chain.forward_train(chain, x2, upstream_needs)
+                        res = rec.replay(state0[j], None, done_seq, layer_extras,
+                                         need_input_grad=True,
+                                         gi_seq=gi2.view(*lead, gi2.shape[-1]),
+                                         **({"tail": tail} if tail is not None else {}))
                     rctx, x, r, fs = res[:4]
                     ctxs.append(("chain+rec", i, j, cctx, lead, rctx))
                     final_state.extend(state0[i:j])
@@ -162,7 +186,9 @@ class Sequential(StatefulModule):
                     i = j + 1
                     if tail is not None:
                         head_ctx, samp_ctx, out_d, reg_s = res[4]
-                        if REC_TAIL_BWD and ops.gru_seq_bwd_tail_supported(
+                        if y_bf is not None:
+                            ctxs[-1] = ("chain+rec+proj", *ctxs[-1][1:], head_ctx, samp_ctx)
+                        elif REC_TAIL_BWD and ops.gru_seq_bwd_tail_supported(
                                 lead[0], rec.hidden_features, self.layers[j + 1].out_features):
                             # the mirror image in the backward: one entry, one launch
                             ctxs[-1] = ("chain+rec+tail", *ctxs[-1][1:], head_ctx, samp_ctx)
@@ -250,6 +276,17 @@ class Sequential(StatefulModule):
     def replay_backward(self, ctxs, g_out, g_reg):
         g = g_out
         for entry in reversed(ctxs):
+            if entry[0] == "chain+rec+proj":
+                # sampler, head, BPTT and the projection's backward in one launch; what is left
+                # of the chain in front is the dW of its one relu layer
+                _, i, j, cctx, lead, rctx, head_ctx, samp_ctx = entry
+                rec, front = self.layers[j], self.layers[i]
+                dz0_bf = rec.replay_backward_proj_tail(rctx, self.layers[j + 1], head_ctx,
+                                                       self.layers[j + 2], samp_ctx, g, g_reg)
+                ops.dense_bwd_dw_grouped_bf16(
+                    [(cctx[0][0][0], dz0_bf, front.kernel.grad,
+                      front.bias.grad if front.bias is not None else None)], accumulate=True)
+                return None
             if entry[0] in ("chain+rec", "chain+rec+tail"):
                 from . import dense_chain
 

@@ -116,8 +116,19 @@ class GRU(StatefulModule):
                 and not sampler.deterministic
                 and ops.gru_seq_fwd_tail_supported(T, self.hidden_features, head.out_features))
 
+    def replay_proj_supported(self, T: int, B: int, front, head) -> bool:
+        """True when `replay(..., tail=..., proj=...)` can evaluate the input projection inside
+        the sequence launches too (`mi_gru_seq_fwd_proj_tail_bf16`): `front`, the layer whose
+        output this GRU reads, is a relu Dense of this GRU's width."""
+        from .feedforward import Dense
+
+        return (type(front) is Dense and front.act_code == ops.ACT_RELU
+                and front.out_features == self.in_features == self.hidden_features
+                and ops.gru_seq_proj_supported(T, B, self.hidden_features, self.in_features,
+                                               head.out_features))
+
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None,
-               tail=None):
+               tail=None, proj=None):
         """`gi_seq` [T, B, 3H]: the input projection, already evaluated by the caller as the
         last layer of the preceding Dense chain (`x_seq` is then unused and
         `replay_backward` returns the gradient w.r.t. `gi_seq`).
@@ -128,6 +139,29 @@ class GRU(StatefulModule):
         H = self.hidden_features
         mfma = self._mfma()
         pctx = None
+        if proj is not None:
+            # `proj` = (y_bf [T*B, H], (T, B)): the bf16 image of this layer's input; gi is
+            # evaluated inside the sequence launch (with `tail`)
+            from . import dense_chain
+
+            y_bf, (T, B) = proj
+            head, sampler, raw_seq = tail
+            pl = self._proj()
+            dense_chain.refresh([pl, head])
+            A2 = head.out_features
+            ex2 = raw_seq.reshape(T * B, A2 // 2)
+            if not ex2.is_contiguous():
+                ex2 = ex2.contiguous()
+            off = sampler._next_offset()
+            h_out, h_prev, gates, h_final, ms2, h_bf, ll, reg = ops.gru_seq_fwd_proj_tail(
+                y_bf, pl._ff, self.b_i.data, self.w_h.data, self.b_hn.data, state0.contiguous(),
+                done_seq.contiguous(), head._ff, head.bias.data, A2, ex2,
+                sampler._state(y_bf.device), off, T, **sampler._kw())
+            ctx = (None, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, ("proj", y_bf))
+            head_ctx = ([(h_bf, None, dense_chain._shadows(head)[0])], T * B, True)
+            samp_ctx = (ms2, ex2, off, None, (T, B, A2))
+            out = {"action": None, "log_likelihood": ll.view(T, B)}
+            return ctx, h_out, None, h_final, (head_ctx, samp_ctx, out, reg.view(T, B))
         if gi_seq is not None:
             T, B, _ = gi_seq.shape
             x2, pctx = None, "external"
@@ -187,6 +221,29 @@ class GRU(StatefulModule):
         ops.dense_bwd_dw_grouped_bf16([(h_prev.bf16_image, dgh_bf, self.w_h.grad,
                                         self.b_hn.grad)], accumulate=True, bias_first=[2 * H])
         return dgi
+
+    def replay_backward_proj_tail(self, ctx, head, head_ctx, sampler, samp_ctx, g_out, g_reg):
+        """`replay_backward_tail` for a `replay(..., proj=...)`: the projection's backward rides
+        in the BPTT launch too.  Queues the dW of the head, of W_h and of W_i; returns dz0_bf
+        [T*B, H], the bf16 image of the gradient w.r.t. the pre-activation of the relu layer
+        in front (the dz operand of ITS dW, which the caller owns)."""
+        _, h_prev, gates, done_seq, (T, B), _, _, (_, y_bf) = ctx
+        ms2, ex2, off, eps2, _ = samp_ctx
+        H = self.hidden_features
+        g_ll = g_out["log_likelihood"]
+        g_ll = None if g_ll is None else g_ll.reshape(T * B).contiguous()
+        pl = self._proj()
+        dgi_bf, dz0_bf, dgh_bf, dz_bf = ops.gru_seq_bwd_proj_tail(
+            y_bf, pl._fb, gates, h_prev, self.w_h.data, done_seq.contiguous(), head._fb,
+            head.out_features, ms2, ex2, sampler._state(ms2.device), off, g_ll, g_reg, eps2=eps2,
+            **sampler._kw())
+        ops.dense_bwd_dw_grouped_bf16([(head_ctx[0][0][0], dz_bf, head.kernel.grad,
+                                        head.bias.grad)], accumulate=True)
+        ops.dense_bwd_dw_grouped_bf16([(h_prev.bf16_image, dgh_bf, self.w_h.grad,
+                                        self.b_hn.grad)], accumulate=True, bias_first=[2 * H])
+        ops.dense_bwd_dw_grouped_bf16([(y_bf, dgi_bf, self.w_i.grad, self.b_i.grad)],
+                                      accumulate=True)
+        return dz0_bf
 
     def replay_backward(self, ctx, g_out, g_reg):
         x2, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, pctx = ctx

@@ -1742,6 +1742,75 @@ def gru_seq_fwd_tail(gi, w_h, b_hn, h0, done, w_out_ff, b_out, N_out: int, extra
     return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg
 
 
+def gru_seq_proj_supported(T: int, B: int, H: int, K_in: int, N_out: int) -> bool:
+    return bool(lib().mi_gru_seq_proj_supported(int(T), int(B), int(H), int(K_in), int(N_out)))
+
+
+def gru_seq_fwd_proj_tail(y_bf, w_i_ff, b_i, w_h, b_hn, h0, done, w_out_ff, b_out, N_out: int,
+                          extras, rng_state, offset_add: int, T: int, *, min_std: float,
+                          std_scale: float, entropy_weight: float, eps2=None):
+    """`gru_seq_fwd_tail` with gi = y W_i + b_i evaluated inside the launch from `y_bf`
+    [T*B, H], the bf16 image of the GRU's input (`mi_gru_seq_fwd_proj_tail_bf16`).  Same
+    returns."""
+    M, H = y_bf.shape
+    B = M // T
+    _need(w_h.shape == (H, 3 * H) and b_hn.shape == (H,) and h0.shape == (B, H)
+          and b_i.shape == (3 * H,) and y_bf.dtype == bf16 and y_bf.is_contiguous(),
+          "gru_seq_fwd_proj_tail: shapes")
+    dev = y_bf.device
+    h_out = torch.empty(T, B, H, dtype=f32, device=dev)
+    h_prev = torch.empty(T, B, H, dtype=f32, device=dev)
+    gates = torch.empty(T, B, 4 * H, dtype=f32, device=dev)
+    h_final = torch.empty(B, H, dtype=f32, device=dev)
+    hp_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    h_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    ms = torch.empty(M, N_out, dtype=f32, device=dev)
+    ll = torch.empty(M, dtype=f32, device=dev)
+    reg = torch.empty(M, dtype=f32, device=dev)
+    d = None if done is None else _as_u8(done)
+    _need(extras.shape == (M, N_out // 2) and extras.is_contiguous(),
+          "gru_seq_fwd_proj_tail: extras must be a contiguous [T*B, A]")
+    check(lib().mi_gru_seq_fwd_proj_tail_bf16(
+        ptr(y_bf), H, ptr(w_i_ff, bf16), ptr(b_i, f32), ptr(w_h, f32), ptr(b_hn, f32),
+        ptr(h0, f32), ptr(d), ptr(h_out, f32), ptr(h_prev, f32), ptr(gates, f32),
+        ptr(h_final, f32), ptr(hp_bf), ptr(w_out_ff, bf16), ptr(b_out, f32), int(N_out),
+        ptr(ms, f32), ptr(h_bf), ptr(extras, f32), ptr(rng_state), int(offset_add),
+        ptr(eps2, f32), float(min_std), float(std_scale), float(entropy_weight), ptr(ll, f32),
+        ptr(reg, f32), T, B, H, stream()), "mi_gru_seq_fwd_proj_tail_bf16")
+    h_prev.bf16_image = hp_bf
+    return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg
+
+
+def gru_seq_bwd_proj_tail(y_bf, w_i_fb, gates, h_prev, w_h, done, w_out_fb, N_out: int,
+                          mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float, *,
+                          min_std: float, std_scale: float, entropy_weight: float, eps2=None):
+    """`gru_seq_bwd_tail` with the input projection's backward inside
+    (`mi_gru_seq_bwd_proj_tail_bf16`).  Returns the bf16 images (dgi [T*B, 3H], dz0 [T*B, H],
+    dgh [T*B, 3H], dz_out [T*B, pad8(N_out)])."""
+    T, B, H = h_prev.shape
+    dev = h_prev.device
+    M = T * B
+    _need(y_bf.shape == (M, H) and y_bf.dtype == bf16 and y_bf.is_contiguous(),
+          "gru_seq_bwd_proj_tail: y_bf must be the contiguous [T*B, H] image")
+    _need(mean_and_std.shape == (M, N_out) and extras.shape == (M, N_out // 2),
+          "gru_seq_bwd_proj_tail: sampler operands must be [T*B, N_out] / [T*B, A]")
+    if g_ll is not None:
+        _need(g_ll.shape == (M,) and g_ll.is_contiguous(),
+              "gru_seq_bwd_proj_tail: g_ll must be [T*B]")
+    dgi_bf = torch.empty(M, 3 * H, dtype=bf16, device=dev)
+    dz0_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    dgh_bf = torch.empty(M, 3 * H, dtype=bf16, device=dev)
+    dz_bf = torch.empty(M, (N_out + 7) // 8 * 8, dtype=bf16, device=dev)
+    d = None if done is None else _as_u8(done)
+    check(lib().mi_gru_seq_bwd_proj_tail_bf16(
+        ptr(y_bf), H, ptr(w_i_fb, bf16), ptr(dgi_bf), ptr(dz0_bf), ptr(gates, f32),
+        ptr(h_prev, f32), ptr(w_h, f32), ptr(d), None, ptr(dgh_bf), ptr(w_out_fb, bf16),
+        int(N_out), ptr(mean_and_std, f32), ptr(extras, f32), ptr(rng_state), int(offset_add),
+        ptr(eps2, f32), ptr(g_ll, f32), float(g_reg), float(min_std), float(std_scale),
+        float(entropy_weight), ptr(dz_bf), T, B, H, stream()), "mi_gru_seq_bwd_proj_tail_bf16")
+    return dgi_bf, dz0_bf, dgh_bf, dz_bf
+
+
 def gru_seq_bwd_tail_supported(T: int, H: int, N_out: int) -> bool:
     return bool(lib().mi_gru_seq_bwd_tail_supported(int(T), int(H), int(N_out)))
 

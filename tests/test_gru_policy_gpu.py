@@ -182,7 +182,10 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
     replace — same network, same rollout, same minibatch: every loss scalar and every parameter
     gradient bit for bit (the head's MFMA tiles, k order and the sampler's row function are the
     same), and the launch list.  The same for the backward mirror, `mi_gru_seq_bwd_tail_bf16`
-    (sampler backward + the head's dX in front of the BPTT, REC_TAIL_BWD)."""
+    (sampler backward + the head's dX in front of the BPTT, REC_TAIL_BWD), and for the input
+    projection inside both (`mi_gru_seq_fwd_proj_tail_bf16` / `mi_gru_seq_bwd_proj_tail_bf16`,
+    REC_PROJ: gi = y W_i + b_i per step from the bf16 image of the relu layer in front, its
+    backward behind the BPTT step)."""
     from nnx_ppo_amd import _lib, config
     from nnx_ppo_amd.algorithms import ppo
     from nnx_ppo_amd.envs import cartpole_shaped
@@ -192,9 +195,11 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
 
     out, n_launch = [], []
     with config.use_compute_dtype("bf16"):
-        for tail, tail_bwd in ((True, True), (True, False), (False, False)):
+        for tail, tail_bwd, proj in ((True, True, True), (True, True, False),
+                                     (True, False, False), (False, False, False)):
             monkeypatch.setattr(containers, "REC_TAIL", tail)
             monkeypatch.setattr(containers, "REC_TAIL_BWD", tail_bwd)
+            monkeypatch.setattr(containers, "REC_PROJ", proj)
             env = EpisodeWrapper(cartpole_shaped(max_steps=5), 1000)
             net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(9))
             ts = ppo.new_training_state(env, net, 512, 9, 3e-4, device=dev)
@@ -204,17 +209,21 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
                     ts, m = ppo.ppo_step(env, ts, 512, 30, 0.95, 0.99, 0.2, True, False, 2, 2)
                 ms.append({k: float(v) for k, v in m.items()})
                 used = {name for name, *_ in prof.records}
-                assert ("mi_gru_seq_fwd_tail_bf16" in used) == tail, used
+                assert ("mi_gru_seq_fwd_tail_bf16" in used) == (tail and not proj), used
+                # ... and `mi_gru_seq_*_proj_tail_bf16` the input projection too (REC_PROJ)
+                assert ("mi_gru_seq_fwd_proj_tail_bf16" in used) == proj, used
+                assert ("mi_gru_seq_bwd_proj_tail_bf16" in used) == proj, used
                 if tail:
                     assert "mi_tanh_gauss_fwd_f32" not in used and "mi_gru_seq_fwd_bf16" not in used
                 # ... and `mi_gru_seq_bwd_tail_bf16` their backward (REC_TAIL_BWD)
-                assert ("mi_gru_seq_bwd_tail_bf16" in used) == tail_bwd, used
+                assert ("mi_gru_seq_bwd_tail_bf16" in used) == (tail_bwd and not proj), used
                 if tail_bwd:
                     assert not {"mi_tanh_gauss_bwd_f32", "mi_gru_seq_bwd_bf16"} & used, used
             n_launch.append(sum(not name.endswith("_supported") for name, *_ in prof.records))
             out.append((ts.optimizer.params.clone(), ts.optimizer.m.clone(), ms))
-    # 2 epochs x 2 minibatches, two launches fewer per gradient step each time
-    assert n_launch[1] - n_launch[0] == 8 and n_launch[2] - n_launch[1] == 8, n_launch
+    # 2 epochs x 2 minibatches: the chain's backward launch goes with the projection inside, then
+    # two launches fewer per gradient step each time
+    assert [b - a for a, b in zip(n_launch, n_launch[1:])] == [4, 8, 8], n_launch
     for (pa, ma, la), (pb, mb, lb) in zip(out, out[1:]):
         assert la == lb
         assert torch.equal(pa, pb) and torch.equal(ma, mb)
