@@ -80,6 +80,11 @@ int mi_gae_stats_f32(const float* rewards, const float* values,
 int mi_normalize_fwd_f32(const float* x, const float* mean, const float* m2,
                          const float* counter, float epsilon, float* out,
                          int64_t M, int64_t F, mi_stream_t stream);
+/* The same over [x ; x_tail] into one out [M + M_tail, F]: a replay's T x B observation rows and
+ * the bootstrap observation behind them (`ppo.py:433-437`) in one launch. */
+int mi_normalize_fwd_tail_f32(const float* x, const float* x_tail, const float* mean,
+                              const float* m2, const float* counter, float epsilon, float* out,
+                              int64_t M, int64_t M_tail, int64_t F, mi_stream_t stream);
 
 /* Gradient of the above w.r.t. x (statistics are constants): g_x = g_out / std. */
 int mi_normalize_bwd_f32(const float* g_out, const float* m2, const float* counter,

@@ -17,10 +17,13 @@ __device__ inline float norm_std(float m2, float counter, float eps) {
   return counter > 0.0f ? sqrtf(fmaxf(m2 / counter, eps)) : 10.0f;
 }
 
+// (x_tail: rows M .. M + M_tail - 1 of `out` come from a second source — the bootstrap
+// observation behind the T x B rows of a replay, one launch instead of two)
 __global__ void __launch_bounds__(kThreads)
 normalize_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                      const float* __restrict__ m2, const float* __restrict__ counter,
-                     float eps, float* __restrict__ out, int64_t M, int64_t F) {
+                     float eps, float* __restrict__ out, int64_t M, int64_t F,
+                     const float* __restrict__ x_tail, int64_t M_tail) {
   extern __shared__ float lds[];  // mean[Fc], std[Fc] when F fits
   const float cnt = *counter;
   const bool cached = F <= 2048;
@@ -31,13 +34,14 @@ normalize_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean
     }
     __syncthreads();
   }
-  const int64_t total = M * F;
+  const int64_t head = M * F, total = (M + M_tail) * F;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * kThreads) {
     const int64_t f = i % F;
     const float mu = cached ? lds[f] : mean[f];
     const float sd = cached ? lds[F + f] : norm_std(m2[f], cnt, eps);
-    out[i] = (x[i] - mu) / sd;
+    const float v = i < head ? x[i] : x_tail[i - head];
+    out[i] = (v - mu) / sd;
   }
 }
 
@@ -185,8 +189,25 @@ extern "C" int mi_normalize_fwd_f32(const float* x, const float* mean, const flo
   MI_REQUIRE(x && mean && m2 && counter && out, "mi_normalize_fwd_f32: null pointer");
   const size_t lds = F <= 2048 ? (size_t)(2 * F) * sizeof(float) : 0;
   hipLaunchKernelGGL(normalize_fwd_kernel, dim3(stream_grid(M * F)), dim3(kThreads), lds,
-                     mippo::as_stream(stream), x, mean, m2, counter, epsilon, out, M, F);
+                     mippo::as_stream(stream), x, mean, m2, counter, epsilon, out, M, F, nullptr,
+                     (int64_t)0);
   return mippo::check_launch("mi_normalize_fwd_f32");
+}
+
+// mi_normalize_fwd_f32 of [x ; x_tail]: out [M + M_tail, F] (the same expression per element).
+extern "C" int mi_normalize_fwd_tail_f32(const float* x, const float* x_tail, const float* mean,
+                                         const float* m2, const float* counter, float epsilon,
+                                         float* out, int64_t M, int64_t M_tail, int64_t F,
+                                         mi_stream_t stream) {
+  MI_REQUIRE(M >= 0 && M_tail >= 0 && F >= 1, "mi_normalize_fwd_tail_f32: bad shape");
+  if (M + M_tail == 0) return 0;
+  MI_REQUIRE((x || M == 0) && (x_tail || M_tail == 0) && mean && m2 && counter && out,
+             "mi_normalize_fwd_tail_f32: null pointer");
+  const size_t lds = F <= 2048 ? (size_t)(2 * F) * sizeof(float) : 0;
+  hipLaunchKernelGGL(normalize_fwd_kernel, dim3(stream_grid((M + M_tail) * F)), dim3(kThreads),
+                     lds, mippo::as_stream(stream), x, mean, m2, counter, epsilon, out, M, F,
+                     x_tail, M_tail);
+  return mippo::check_launch("mi_normalize_fwd_tail_f32");
 }
 
 extern "C" int mi_normalize_bwd_f32(const float* g_out, const float* m2,

@@ -261,10 +261,9 @@ class Sequential(StatefulModule):
         cnt = norm.counter.value
         from .. import ops
 
-        ops.normalize_fwd(x_seq if x_seq.is_contiguous() else x_seq.contiguous(),
-                          norm.mean.value, norm.M2.value, cnt, norm.epsilon, out=x_ext[:T])
-        ops.normalize_fwd(last_obs if last_obs.is_contiguous() else last_obs.contiguous(),
-                          norm.mean.value, norm.M2.value, cnt, norm.epsilon, out=x_ext[T])
+        ops.normalize_fwd_tail(x_seq if x_seq.is_contiguous() else x_seq.contiguous(),
+                               last_obs if last_obs.is_contiguous() else last_obs.contiguous(),
+                               norm.mean.value, norm.M2.value, cnt, norm.epsilon, x_ext)
         a_ctx, out, reg, fs = adapter.replay(state0[1], x_ext[:T], done_seq, extras_seq[1],
                                              need_input_grad=False, x_value=x_ext)
         v_ext = out.value_estimates  # [T + 1, B(, n)]: the value port saw the extra step

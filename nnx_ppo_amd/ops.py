@@ -103,6 +103,18 @@ def normalize_fwd(x, mean, m2, counter, epsilon: float, out=None):
     return out
 
 
+def normalize_fwd_tail(x, x_tail, mean, m2, counter, epsilon: float, out):
+    """`normalize_fwd` of [x ; x_tail] into the contiguous `out` [M + M_tail, F] in one launch."""
+    F = mean.numel()
+    M, Mt = x.numel() // F, x_tail.numel() // F
+    _need(out.is_contiguous() and out.numel() == (M + Mt) * F and x.is_contiguous()
+          and x_tail.is_contiguous(), "normalize_fwd_tail: contiguous [M + M_tail, F] output")
+    check(lib().mi_normalize_fwd_tail_f32(
+        ptr(x, f32), ptr(x_tail, f32), ptr(mean, f32), ptr(m2, f32), ptr(counter, f32),
+        float(epsilon), ptr(out, f32), M, Mt, F, stream()), "mi_normalize_fwd_tail_f32")
+    return out
+
+
 def normalize_bwd(g_out, m2, counter, epsilon: float):
     F = m2.numel()
     M = g_out.numel() // F

@@ -38,6 +38,12 @@ def test_normalize_fwd(dev, M, F):
             std = np.full(F, 10.0)
         want = (x.astype(np.float64) - mean) / std
         assert np.allclose(out.cpu().numpy(), want, rtol=2e-6, atol=1e-6)
+        # [x ; x_tail] in one launch (`mi_normalize_fwd_tail_f32`): the same bits, row for row
+        k = max(1, M // 3)
+        both = torch.empty(M + k, F, dtype=torch.float32, device=dev)
+        ops.normalize_fwd_tail(_g(x, dev), _g(x[:k], dev), _g(mean, dev), _g(m2, dev),
+                               _g([cnt], dev), 1e-6, both)
+        assert torch.equal(both[:M], out) and torch.equal(both[M:], out[:k])
     g = rng.normal(size=(M, F)).astype(np.float32)
     gx = ops.normalize_bwd(_g(g, dev), _g(m2, dev), _g([37.0], dev), 1e-6)
     assert np.allclose(gx.cpu().numpy(), g / np.sqrt(np.maximum(m2 / 37.0, 1e-6)), rtol=2e-6)
