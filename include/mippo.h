@@ -243,7 +243,8 @@ int mi_dense_bwd_dw_grouped_bf16(int64_t n, const void* const* x_bf, const void*
  * every layer with the activations resident in LDS, output columns split over
  * the waves, weight fragments global -> VGPR, one barrier per layer.  Training
  * stores (arrays nullable, entries nullable): y_bf[l] [M][pad8 N_l], pre_bf[l]
- * [M][pad8 N_l]; x_bf [M][pad8 K_0] = bf16 copy of the input. */
+ * [M][pad8 N_l]; x_bf [M][pad8 K_0] = bf16 copy of the input.  `out` may be null when
+ * y_bf[L-1] is given (a caller that reads the last layer's bf16 image only). */
 int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void* const* wt_bf,
                     const float* const* bias, const int64_t* dims, const int64_t* acts,
                     float* out, void* const* y_bf, void* const* pre_bf, void* x_bf,

@@ -960,7 +960,8 @@ extern "C" int mi_mlp_fwd_bf16(const float* x, int64_t M, int64_t L, const void*
                                void* const* pre_bf, void* x_bf, mi_stream_t stream) {
   MI_REQUIRE(M >= 0, "mi_mlp_fwd_bf16: bad M");
   if (M == 0) return 0;
-  MI_REQUIRE(out, "mi_mlp_fwd_bf16: null pointer");
+  // (out may be null when the last layer leaves its bf16 image: a caller that only reads that)
+  MI_REQUIRE(out || (y_bf && L >= 1 && y_bf[L - 1]), "mi_mlp_fwd_bf16: null pointer");
   Chain c;
   int maxw = 0;
   int rc = fill_fwd_chain(c, "mi_mlp_fwd_bf16", x, M, L, wt_bf, bias, dims, acts, out, y_bf,

@@ -162,7 +162,8 @@ class Sequential(StatefulModule):
                                                           self.layers[j + 1])
                             and ops.gru_seq_bwd_tail_supported(
                                 lead[0], rec.hidden_features, self.layers[j + 1].out_features)):
-                        cctx, _ = dense_chain.forward_train([self.layers[i]], x2, False)
+                        cctx, _ = dense_chain.forward_train([self.layers[i]], x2, False,
+                                                            want_out=False)
                         y_bf = cctx[0][-1][1]  # the post-relu bf16 image
                         if y_bf is None or tuple(y_bf.shape) != (x2.shape[0], rec.hidden_features):
                             y_bf = None

@@ -168,13 +168,18 @@ def forward_infer(layers, x2: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def forward_train(layers, x2: torch.Tensor, need_input_grad: bool):
+def forward_train(layers, x2: torch.Tensor, need_input_grad: bool, want_out: bool = True):
     """Returns (ctx, fp32 output [M, N_last]).  ctx keeps, per layer, the bf16 input
-    (dW operand), the tensor its act' is evaluated on, and the bf16 W shadow."""
+    (dW operand), the tensor its act' is evaluated on, and the bf16 W shadow.
+    `want_out=False`: the caller reads the last layer's bf16 image (ctx) only; the fp32 output
+    may come back as None."""
     M = x2.shape[0]
     if _fusable(layers, M, need_input_grad):
-        fwd = ops.mlp_ws_fwd_bf16 if _ws(layers, M, need_input_grad) else ops.mlp_fwd_bf16
-        y, sv = fwd(x2, *_chain_args(layers), train=True)
+        if _ws(layers, M, need_input_grad):
+            y, sv = ops.mlp_ws_fwd_bf16(x2, *_chain_args(layers), train=True)
+        else:
+            y, sv = ops.mlp_fwd_bf16(x2, *_chain_args(layers), train=True,
+                                     want_out=want_out or layers[-1].act_code == ops.ACT_NONE)
         saved = [(xb, aux, _shadows(l)[0]) for (xb, aux), l in zip(sv, layers)]
         return (saved, M, need_input_grad), y
     refresh(layers)

@@ -573,7 +573,7 @@ def dense_bwd_dw_grouped_bf16(problems: list, accumulate: bool = True,
 
 
 def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: list, *,
-                 train: bool):
+                 train: bool, want_out: bool = True):
     """Fused MLP trunk forward.  Returns (out_f32 [M, N_last], saved) where `saved`
     (training only) is a list per layer of (x_bf, aux_bf) — the bf16 input of the
     layer and the tensor its activation derivative is evaluated on."""
@@ -581,7 +581,9 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
     L = len(wts)
     _need(len(dims) == L + 1 and dims[0] == K0 and len(acts) == L, "mlp_fwd_bf16: dims/acts")
     dev = x.device
-    out = torch.empty(M, dims[-1], dtype=f32, device=dev)
+    # `want_out=False` (training form whose last layer keeps its bf16 image): no fp32 output
+    _need(want_out or (train and acts[-1] != ACT_NONE), "mlp_fwd_bf16: nothing would be written")
+    out = torch.empty(M, dims[-1], dtype=f32, device=dev) if want_out else None
     P = ctypes.c_void_p * L
     I = ctypes.c_int64 * (L + 1)
     y_bf = [None] * L
@@ -603,7 +605,8 @@ def mlp_fwd_bf16(x: torch.Tensor, wts: list, biases: list, dims: list, acts: lis
         w_bytes = sum(2 * dims[l] * dims[l + 1] + 4 * dims[l + 1] for l in range(L))
         kept = sum(t.numel() * 2 for t in [x_bf, *y_bf, *pre_bf] if t is not None)
         # algorithmic HBM bytes: fp32 input + weights in, fp32 output + kept bf16 images out
-        profiler.next_bytes = 4.0 * M * K0 + w_bytes + 4.0 * M * dims[-1] + kept
+        profiler.next_bytes = (4.0 * M * K0 + w_bytes + (4.0 * M * dims[-1] if want_out else 0)
+                               + kept)
     check(lib().mi_mlp_fwd_bf16(
         ptr(x, f32), M, L, arr(wts), arr(biases), I(*[int(d) for d in dims]),
         (ctypes.c_int64 * L)(*[int(a) for a in acts]), ptr(out, f32),
