@@ -387,6 +387,14 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     bf16_t* hbn = hb1;
     auto step = [&](int64_t t, Slot& gcur) {
       const bool reset = done != nullptr && dwin.at(t, rr);
+      // the carry's operand reads first; while they are in flight the PREVIOUS step's records go
+      // out (their LDS reads and store issues sat behind the barrier, in front of these reads,
+      // on every step's chain)
+      bf16x8 af[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        af[ks] = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
+      if (t != 0) pk.sweep((int)((t - 1) & 1), tid);
       if constexpr (PROJ) {  // gi of this step (does not wait for the carry)
 #pragma unroll
         for (int ui = 0; ui < UTW; ++ui)
@@ -406,13 +414,12 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
         for (int g = 0; g < 3; ++g) acc[ui][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(hb + li * HROW + ks * 32 + 8 * lq);
 #pragma unroll
         for (int ui = 0; ui < UTW; ++ui)
 #pragma unroll
           for (int g = 0; g < 3; ++g)  // D[unit = 4*lq + e][row = li]
-            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af, acc[ui][g],
-                                                                0, 0, 0);
+            acc[ui][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ui][g][ks], af[ks],
+                                                                acc[ui][g], 0, 0, 0);
       }
       unsigned char* const rc0 = pk.rec((int)(t & 1), rr);
 #pragma unroll
@@ -443,13 +450,12 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
         hc[ui] = hcn;
         hbn[rr * HROW + ucol[ui]] = (bf16_t)hcn;
       }
+      __builtin_amdgcn_sched_barrier(0);  // (the refill behind its slot's use: see the other form)
+      load_step(t + PFW, gcur);
       __syncthreads();
-      pk.sweep((int)(t & 1), tid);
       bf16_t* tmp = hb;
       hb = hbn;
       hbn = tmp;
-      __builtin_amdgcn_sched_barrier(0);  // (the refill behind its slot's use: see the other form)
-      load_step(t + PFW, gcur);
     };
     int64_t t0 = 0;
     if (T >= PFW) {  // first group peeled, the loop inside its branch (see the other form)
@@ -465,6 +471,7 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 #pragma unroll
     for (int d = 0; d < PFW; ++d)
       if (t0 + d < T) step(t0 + d, gq[d]);
+    if (T > 0) pk.sweep((int)((T - 1) & 1), tid);  // the last step's records
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       if (wave + 4 * ui >= UT) continue;

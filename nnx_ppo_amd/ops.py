@@ -1857,27 +1857,31 @@ def gru_seq_bwd_tail(gates, h_prev, w_h, done, w_out_fb, N_out: int, mean_and_st
     return dgi, dgh_bf, dz_bf
 
 
-def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False, dgh_as_bf16: bool = False):
+def gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma: bool = False, dgh_as_bf16: bool = False,
+                dh0_out=None):
     """Returns (dgi [T,B,3H], dgh [T,B,3H]).  `dgh_as_bf16` (matrix-core path): dgh comes
     back as its bf16 image [T*B, 3H] — the dz operand of the recurrent kernel's dW launch —
-    and the fp32 tensor is not written."""
+    and the fp32 tensor is not written.  `dh0_out` [B, H] (optional) receives the gradient
+    w.r.t. the sequence's first carry."""
     T, B, H = g_h.shape
     dev = g_h.device
     dgi = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
     d = None if done is None else _as_u8(done)
+    if dh0_out is not None:
+        _need(dh0_out.shape == (B, H) and dh0_out.is_contiguous(), "gru_seq_bwd: dh0_out [B, H]")
     if mfma:
         as_bf = dgh_as_bf16 and (3 * H) % 8 == 0
         dgh = None if as_bf else torch.empty(T, B, 3 * H, dtype=f32, device=dev)
         dgh_bf = torch.empty(T * B, 3 * H, dtype=bf16, device=dev) if as_bf else None
         check(lib().mi_gru_seq_bwd_bf16(
             ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d),
-            ptr(dgi, f32), ptr(dgh, f32), None, ptr(dgh_bf), T, B, H, stream()),
+            ptr(dgi, f32), ptr(dgh, f32), ptr(dh0_out, f32), ptr(dgh_bf), T, B, H, stream()),
             "mi_gru_seq_bwd_bf16")
         return dgi, (dgh_bf if as_bf else dgh)
     dgh = torch.empty(T, B, 3 * H, dtype=f32, device=dev)
     check(lib().mi_gru_seq_bwd_f32(
         ptr(g_h, f32), ptr(gates, f32), ptr(h_prev, f32), ptr(w_h, f32), ptr(d),
-        ptr(dgi, f32), ptr(dgh, f32), None, T, B, H, stream()), "mi_gru_seq_bwd_f32")
+        ptr(dgi, f32), ptr(dgh, f32), ptr(dh0_out, f32), T, B, H, stream()), "mi_gru_seq_bwd_f32")
     return dgi, dgh
 
 

@@ -228,3 +228,51 @@ def test_gru_matrix_core_rows_per_workgroup(dev, monkeypatch, T, B, H):
     for other in outs[1:]:
         for a, b_ in zip(outs[0], other):
             assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,H,rows", [(8, 32, ""), (40, 64, "16"), (4100, 64, "")])
+def test_gru_matrix_core_long_sequence_equals_chunks(dev, monkeypatch, B, H, rows):
+    """Sequences longer than the kernels' 240-step window of done flags (`DoneWindow`) and not a
+    multiple of the look-ahead: one T = 611 call == the same steps in chunks of 97 with the carry
+    (forward) and the carry's gradient (BPTT) handed from chunk to chunk by the caller — exact,
+    because a step only sees its carry.  Covers the restaging of the window in both directions,
+    in the 4-row and the full-tile form."""
+    from nnx_ppo_amd import ops
+
+    monkeypatch.setenv("MIPPO_GRU_ROWS", rows)
+    T, C = 611, 97
+    gen = torch.Generator(device="cpu").manual_seed(B + H)
+    r = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    gi, w_h, b, h0, g_h = r(T, B, 3 * H), r(H, 3 * H) / H ** 0.5, r(H), r(B, H), r(T, B, H) * 0.1
+    done = (torch.rand(T, B, generator=gen) < 0.05).to(dev)
+    h_out, h_prev, gates, h_final = ops.gru_seq_fwd(gi, w_h, b, h0, done, True, True)
+    dh0 = torch.empty(B, H, device=dev)
+    dgi, dgh = ops.gru_seq_bwd(g_h, gates, h_prev, w_h, done, mfma=True, dh0_out=dh0)
+    # forward in chunks
+    h, outs = h0, []
+    for t0 in range(0, T, C):
+        o = ops.gru_seq_fwd(gi[t0:t0 + C].contiguous(), w_h, b, h, done[t0:t0 + C].contiguous(),
+                            True, True)
+        outs.append(o)
+        h = o[3]
+    assert torch.equal(torch.cat([o[0] for o in outs]), h_out)
+    assert torch.equal(torch.cat([o[1] for o in outs]), h_prev)
+    assert torch.equal(torch.cat([o[2] for o in outs]), gates)
+    assert torch.equal(h, h_final)
+    # BPTT in chunks, last chunk first: d loss / d carry enters the chunk before through its
+    # last step's output gradient (masked where that step ended an episode)
+    carry, pieces = None, []
+    starts = list(range(0, T, C))
+    for t0 in reversed(starts):
+        g = g_h[t0:t0 + C].clone()
+        if carry is not None:
+            g[-1] += torch.where(done[t0 + C - 1][:, None], torch.zeros_like(carry), carry)
+        d0 = torch.empty(B, H, device=dev)
+        pieces.append(ops.gru_seq_bwd(g, gates[t0:t0 + C].contiguous(),
+                                      h_prev[t0:t0 + C].contiguous(), w_h,
+                                      done[t0:t0 + C].contiguous(), mfma=True, dh0_out=d0))
+        carry = d0
+    pieces.reverse()
+    assert torch.equal(torch.cat([p[0] for p in pieces]), dgi)
+    assert torch.equal(torch.cat([p[1] for p in pieces]), dgh)
+    assert torch.equal(carry, dh0)
