@@ -176,7 +176,9 @@ def test_gru_bias_tail_gradient_folded_equals_reduced(dev, bf16):
     assert torch.equal(outs[0], outs[1])
 
 
-def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatch):
+@pytest.mark.parametrize("H,n_envs,T,A", [(64, 512, 30, 1), (32, 148, 12, 3), (96, 264, 9, 2),
+                                          (128, 512, 10, 1)])
+def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatch, H, n_envs, T, A):
     """`mi_gru_seq_fwd_tail_bf16`: the linear head and the sampler's replay behind the GRU ride
     in the sequence launch (containers.Sequential.replay, REC_TAIL).  Against the launches they
     replace — same network, same rollout, same minibatch: every loss scalar and every parameter
@@ -185,10 +187,12 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
     (sampler backward + the head's dX in front of the BPTT, REC_TAIL_BWD), and for the input
     projection inside both (`mi_gru_seq_fwd_proj_tail_bf16` / `mi_gru_seq_bwd_proj_tail_bf16`,
     REC_PROJ: gi = y W_i + b_i per step from the bf16 image of the relu layer in front, its
-    backward behind the BPTT step)."""
+    backward behind the BPTT step).  Every state width of the matrix-core GRU (H = 32 and 96:
+    waves without a unit tile; 128: two tiles per wave), ragged batches (74 and 132 rows per
+    minibatch) and several action sizes."""
     from nnx_ppo_amd import _lib, config
     from nnx_ppo_amd.algorithms import ppo
-    from nnx_ppo_amd.envs import cartpole_shaped
+    from nnx_ppo_amd.envs import MockEnv
     from nnx_ppo_amd.networks import containers, factories
     from nnx_ppo_amd.networks.types import Rngs
     from nnx_ppo_amd.wrappers.episode_wrapper import EpisodeWrapper
@@ -200,20 +204,20 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
             monkeypatch.setattr(containers, "REC_TAIL", tail)
             monkeypatch.setattr(containers, "REC_TAIL_BWD", tail_bwd)
             monkeypatch.setattr(containers, "REC_PROJ", proj)
-            env = EpisodeWrapper(cartpole_shaped(max_steps=5), 1000)
-            net = factories.make_gru_actor_critic(5, 1, 64, [256, 256], Rngs(9))
-            ts = ppo.new_training_state(env, net, 512, 9, 3e-4, device=dev)
+            env = EpisodeWrapper(MockEnv(5, A, max_steps=5), 1000)
+            net = factories.make_gru_actor_critic(5, A, H, [256, 256], Rngs(9))
+            ts = ppo.new_training_state(env, net, n_envs, 9, 3e-4, device=dev)
             ms = []
             for it in range(2):
                 with _lib.profiler as prof:
-                    ts, m = ppo.ppo_step(env, ts, 512, 30, 0.95, 0.99, 0.2, True, False, 2, 2)
+                    ts, m = ppo.ppo_step(env, ts, n_envs, T, 0.95, 0.99, 0.2, True, False, 2, 2)
                 ms.append({k: float(v) for k, v in m.items()})
                 used = {name for name, *_ in prof.records}
                 assert ("mi_gru_seq_fwd_tail_bf16" in used) == (tail and not proj), used
                 # ... and `mi_gru_seq_*_proj_tail_bf16` the input projection too (REC_PROJ)
                 assert ("mi_gru_seq_fwd_proj_tail_bf16" in used) == proj, used
                 assert ("mi_gru_seq_bwd_proj_tail_bf16" in used) == proj, used
-                if tail:
+                if tail and H == 64:  # (other widths roll out through the generic containers)
                     assert "mi_tanh_gauss_fwd_f32" not in used and "mi_gru_seq_fwd_bf16" not in used
                 # ... and `mi_gru_seq_bwd_tail_bf16` their backward (REC_TAIL_BWD)
                 assert ("mi_gru_seq_bwd_tail_bf16" in used) == (tail_bwd and not proj), used
