@@ -456,6 +456,16 @@ int nt256_launch(int epi, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t
 // covering at least four tiles, M a multiple of 32 and >= 8192.  dw256_plan decides the split for
 // the taken problems together; dw256_launch runs them in ONE launch and reports slab
 // positions / counts like the 128-row path.
+// a problem the kernel can take as part of a group of >= 4 tiles: whole 256-row / 256-column
+// tiles (a partial tile multiplies padding), training-size M
+bool dw256_candidate(int64_t K, int64_t N, int64_t M) {
+  static const int enabled = [] {
+    const char* e = getenv("MIPPO_GEMM256");
+    return !(e && e[0] == '0');
+  }();
+  return enabled && K % TB == 0 && N % TB == 0 && M >= 8192 && M % KB == 0;
+}
+
 bool dw256_takes(int64_t K, int64_t N, int64_t M) {
   static const int enabled = [] {
     const char* e = getenv("MIPPO_GEMM256");

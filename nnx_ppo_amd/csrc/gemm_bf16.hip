@@ -788,9 +788,11 @@ extern "C" int64_t mi_dense_bwd_dw_grouped_bf16_workspace_bytes(int64_t n, const
   for (int64_t l = 0; l < n; ++l) {
     int64_t rows, S;
     dw_split_plan(M, dw_tiles(K[l], N[l]), &rows, &S);
-    if (mippo_gemm::dw256_takes(K[l], N[l], M)) {  // (alone in its launch: the largest split)
+    if (mippo_gemm::dw256_takes(K[l], N[l], M) || mippo_gemm::dw256_candidate(K[l], N[l], M)) {
+      // (the largest split it can get: a group of exactly four tiles of the 256-row kernel)
       int64_t r2, S2;
-      mippo_gemm::dw256_plan(M, mippo_gemm::dw256_tiles(K[l], N[l]), &r2, &S2);
+      const int64_t t = mippo_gemm::dw256_tiles(K[l], N[l]);
+      mippo_gemm::dw256_plan(M, t > 4 ? t : 4, &r2, &S2);
       if (S2 > S) S = S2;
     }
     total += S * (K[l] * N[l] + N[l]);
@@ -823,9 +825,15 @@ static int dw_grouped_launch(const char* who, int64_t n, const void* const* x_bf
     float* sl[kMaxDwProblems];
     int64_t Kb[kMaxDwProblems], Nb[kMaxDwProblems];
     int64_t tiles_big = 0;
+    // (a square 256-wide layer is one tile: on its own the chip-filling split would cost more
+    // in slabs than the tile kernel does, beside three or more other tiles it does not)
     for (int64_t l = 0; l < n; ++l) {
-      big[l] = mippo_gemm::dw256_takes(K[l], N[l], M);
+      big[l] = mippo_gemm::dw256_takes(K[l], N[l], M) || mippo_gemm::dw256_candidate(K[l], N[l], M);
       if (big[l]) tiles_big += mippo_gemm::dw256_tiles(K[l], N[l]);
+    }
+    if (tiles_big < 4) {  // (a problem `dw256_takes` on its own has four tiles itself)
+      tiles_big = 0;
+      for (int64_t l = 0; l < n; ++l) big[l] = false;
     }
     if (tiles_big) {
       int64_t rows_b, S_b;

@@ -31,6 +31,7 @@ int nt256_launch(int epi, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t
 // dW on 256 x 256 tiles (gemm256_bf16.hip): which problems it takes, its split plan, its
 // launch (slabs[l]: [S][K * N + N] fp32, the layout the 128-row path leaves).
 bool dw256_takes(int64_t K, int64_t N, int64_t M);
+bool dw256_candidate(int64_t K, int64_t N, int64_t M);
 void dw256_plan(int64_t M, int64_t tiles, int64_t* rows, int64_t* S);
 int64_t dw256_tiles(int64_t K, int64_t N);
 int dw256_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, const int64_t* K,

@@ -1014,8 +1014,13 @@ extern "C" int mi_policy_fwd_bf16(
   const int maxw = wa > wc ? wa : wc;
   hipStream_t st = mippo::as_stream(stream);
   if (M + M_tail <= 8192) return launch_policy<1, 4, 1, 4>(a, wa, wc, st);
-  MI_REQUIRE(maxw <= 256, "mi_policy_fwd_bf16: trunks wider than 256 take at most 8192 rows "
-                          "(use mi_mlp_fwd_bf16 per trunk)");
+  // a trunk wider than 256 walks 32 rows per workgroup (its two activation buffers of 64 rows
+  // would not leave room for a second workgroup on the CU), the other keeps its 64
+  if (maxw > 256) {
+    if (wa > 256 && wc > 256) return launch_policy<2, 4, 2, 4>(a, wa, wc, st);
+    if (wc > 256) return launch_policy<4, 4, 2, 4>(a, wa, wc, st);
+    return launch_policy<2, 4, 4, 4>(a, wa, wc, st);
+  }
   const PolicyShape& ps = policy_shape_override();
   if (ps.set) {
 #define MI_X(RA, NA, RV, NV, IP, W)                                                       \
@@ -1172,8 +1177,11 @@ extern "C" int mi_policy_bwd_bf16(
   const int maxw = wa > wc ? wa : wc;
   hipStream_t st = mippo::as_stream(stream);
   if (M <= 8192) return launch_policy_bwd<1, 4, 1, 4>(a, wa, wc, st);
-  MI_REQUIRE(maxw <= 256, "mi_policy_bwd_bf16: trunks wider than 256 take at most 8192 rows "
-                          "(use mi_mlp_bwd_dx_bf16 per trunk)");
+  if (maxw > 256) {  // (as the forward: 32 rows per workgroup for a trunk wider than 256)
+    if (wa > 256 && wc > 256) return launch_policy_bwd<2, 4, 2, 4>(a, wa, wc, st);
+    if (wc > 256) return launch_policy_bwd<4, 4, 2, 4>(a, wa, wc, st);
+    return launch_policy_bwd<2, 4, 4, 4>(a, wa, wc, st);
+  }
   const PolicyShape& ps = policy_shape_override();
   if (ps.set) {
 #define MI_X(RA, NA, RV, NV, IP, W)                                                       \

@@ -176,8 +176,6 @@ class MLPActorCritic(Sequential):
             width = max(max(l.in_features, l.out_features) for l in layers)
             if len(layers) > dense_chain.FUSED_MAX_LAYERS:
                 return False
-            if width > 256 and M > 8192:  # mi_policy_*_bf16: 64-row workgroups up to 256 wide
-                return False
             if width > dense_chain.FUSED_MAX_WIDTH:
                 return False
         return True

@@ -79,9 +79,16 @@ def test_c3_shape_ppo_step_vs_oracle(dev, build):
                 ts, m = ppo.ppo_step(env, ts, N, T, 0.95, 0.99, 0.2, True, False, 2, 1)
             ots, info = op.ppo_step(oenv, ots, N, T, 0.95, 0.99, 0.2, True, 2, 1, okeys)
             # the kernels this shape is meant to exercise: whole-trunk forward / dX chain
-            # at M > 8192 and the grouped dW
+            # at M > 8192 and the grouped dW — per trunk for the hand-composed network, both
+            # trunks + normaliser + sampler (+ bootstrap rows) in ONE launch each way for the
+            # factory's (since round 3 also with a trunk wider than 256 at training sizes)
             used = _called(prof)
-            assert {"mi_mlp_fwd_bf16", "mi_mlp_bwd_dx_bf16"} <= used, used
+            if build == "by_hand":
+                assert {"mi_mlp_fwd_bf16", "mi_mlp_bwd_dx_bf16"} <= used, used
+            else:
+                assert {"mi_policy_fwd_bf16", "mi_policy_bwd_bf16"} <= used, used
+                assert not {"mi_tanh_gauss_fwd_f32", "mi_tanh_gauss_bwd_f32",
+                            "mi_normalize_fwd_f32"} & used, used
             # (its slab reduction rides on the Adam launch when nothing reads the
             # gradient in between)
             assert used & {"mi_dense_bwd_dw_grouped_bf16",
