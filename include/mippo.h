@@ -368,6 +368,20 @@ int mi_gru_seq_fwd_proj_tail_bf16(
     int64_t N_out, float* ms_out, void* h_bf_out, const float* extras, const uint64_t* rng_state,
     uint64_t offset_add, const float* eps2, float min_std, float std_scale, float entropy_weight,
     float* loglik, float* reg, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
+/* ... and with the relu Dense(K0 <= 8 -> H) in FRONT of the GRU inside the forward launch as well
+ * (`feedforward.py:42-51`): x [T*B, K0] fp32 its input, w_0 the forward fragment-major image of
+ * its kernel, b_0 [H]; out x_bf_out [T*B, 8] and y_bf_out [T*B, H], the bf16 images of its input
+ * and output (x operands of its own and of W_i's dW; y_bf_out is what
+ * mi_gru_seq_bwd_proj_tail_bf16 reads).  Bit-identical to mi_mlp_fwd_bf16 on that layer +
+ * mi_gru_seq_fwd_proj_tail_bf16. */
+int mi_gru_seq_fwd_front_proj_tail_bf16(
+    const float* x, int64_t K0, const void* w_0, const float* b_0, void* x_bf_out, void* y_bf_out,
+    const void* w_i, const float* b_i, const float* w_h, const float* b_hn, const float* h0,
+    const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out, float* h_final,
+    void* h_prev_bf, const void* w_out, const float* b_out, int64_t N_out, float* ms_out,
+    void* h_bf_out, const float* extras, const uint64_t* rng_state, uint64_t offset_add,
+    const float* eps2, float min_std, float std_scale, float entropy_weight, float* loglik,
+    float* reg, int64_t T, int64_t B, int64_t H, mi_stream_t stream);
 int mi_gru_seq_bwd_proj_tail_bf16(
     const void* y_bf, int64_t ldy, const void* w_i_bwd, void* dgi_bf, void* dz0_bf,
     const float* gates, const float* h_prev, const float* w_h, const uint8_t* done, float* dh0,

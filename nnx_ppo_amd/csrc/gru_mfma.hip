@@ -207,11 +207,25 @@ constexpr int packed_lds(int rec_bytes, int pack) { return 2 * pack * (rec_bytes
 // instead of being read back as fp32 [T, B, 3H]: the Dense chain in front stops one layer
 // earlier and 2 x 12 H bytes per row and step never touch memory.  Same MFMA tiles and k order
 // as the chain kernel's last layer, bias added to the finished sum: the same bits.
+// FRONT (PROJ == 2): the relu Dense(K0 <= 8 -> H) in front is evaluated here too.  The prologue
+// brings the workgroup's T x 4 input rows into LDS as bf16 (and leaves that image, the layer's
+// dW operand, in memory); y_{t+1} is made while step t waits for its carry — one MFMA per unit
+// tile — into an LDS history [T][4][H] that the projection of step t + 1 reads and that goes
+// out, whole rows at a time, after the loop (the x operand of W_i's dW, the BPTT's relu' mask).
+// Nothing of it touches memory inside the time loop: the first version, with the input rows in
+// the register ring and the y rows stored per step, cost the sequence kernel as much as the
+// chain launch it replaced (8 loads and 2 stores per step).  Same MFMA tile, bias and relu as
+// the chain kernel's layer: the same bits.
 struct GruProj {
-  const bf16_t* y;   // [T * B][ldy] bf16 image of the GRU's input (in_features == H)
+  const bf16_t* y;   // [T * B][ldy] bf16 image of the GRU's input (in_features == H); FRONT: out
   int64_t ldy;
   const bf16_t* wi;  // forward fragment-major image of W_i [H -> 3H]
   const float* bi;   // [3H]
+  const float* x;    // FRONT: [T * B][K0] fp32 input of the front layer
+  int K0;
+  const bf16_t* w0;  // FRONT: forward fragment-major image of the front kernel [K0 -> H]
+  const float* b0;   // FRONT: [H]
+  bf16_t* x_bf;      // FRONT: [T * B][8] bf16 image of x (the front layer's dW operand), out
 };
 
 struct GruTail {
@@ -225,7 +239,7 @@ struct GruTail {
 };
 
 template <bool TRAIN, int H, bool GUARD, bool BF, bool TAIL = false, int PACK = 0,
-          bool PROJ = false>
+          int PROJ = 0>
 __global__ void __launch_bounds__(kThreads)
 gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
                     const float* __restrict__ b_hn, const float* __restrict__ h0,
@@ -259,8 +273,12 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
   constexpr int N_OUT_ARR = 1 + (TRAIN ? 2 : 0) + (TRAIN && BF ? 1 : 0) + (TAIL ? 1 : 0);
   using Packed = PackedStores<N_OUT_ARR, fwd_rec_bytes(H, TRAIN, BF, TAIL), PACK ? PACK : 1>;
   unsigned char* const stg = reinterpret_cast<unsigned char*>(hb1 + GROWS * HROW) + DONE_WIN * GROWS;
+  // FRONT: the front layer's input rows [T][4][8] and output rows [T][4][H + 8] (bf16)
+  constexpr bool FRONT = PROJ == 2;
+  bf16_t* const xs = reinterpret_cast<bf16_t*>(stg + (PACK ? Packed::LDS_BYTES : 0));
+  bf16_t* const yhist = xs + (FRONT ? (size_t)T * 4 * 8 : 0);
   // TAIL: [T][16][H + 8], bf16(h_t)
-  bf16_t* const hist = reinterpret_cast<bf16_t*>(stg + (PACK ? Packed::LDS_BYTES : 0));
+  bf16_t* const hist = yhist + (FRONT ? (size_t)T * 4 * HROW : 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -347,6 +365,32 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
       bf16x8 y[KS];
     };
     Slot gq[PFW];
+    bf16x8 w0f[FRONT ? UTW : 1];
+    f32x4 b0v[FRONT ? UTW : 1];
+    // FRONT: y_t = relu(x_t W_0 + b_0) of this wave's unit tiles for the 16 tile rows, into the
+    // step's LDS tile and (live rows) out; wave 0 also leaves the bf16 image of x_t
+    auto front = [&](int64_t t) {
+      if constexpr (FRONT) {
+        // (tile rows 4 .. 15 repeat rows 0 .. 3: dead rows, never kept)
+        const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(xs + ((int)t * 4 + rr) * 8);
+        bf16x8 xf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[i] = lq == 0 ? x8[i] : (bf16_t)0.0f;
+#pragma unroll
+        for (int ui = 0; ui < UTW; ++ui) {
+          if constexpr (UT % 4 != 0)
+            if (wave + 4 * ui >= UT) continue;
+          const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              w0f[ui], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)fmaxf(a[e] + b0v[ui][e], 0.0f);
+          if (li < 4)
+            *reinterpret_cast<bf16x4*>(yhist + ((int)t * 4 + li) * HROW + (wave + 4 * ui) * 16 +
+                                       4 * lq) = v;
+        }
+      }
+    };
     bf16x8 wif[PROJ ? UTW : 1][3][KS];
     float biv[PROJ ? UTW : 1][3];
     if constexpr (PROJ) {
@@ -354,6 +398,10 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
 #pragma unroll
       for (int ui = 0; ui < UTW; ++ui) {
         const int ut = wave + 4 * ui < UT ? wave + 4 * ui : 0;
+        if constexpr (FRONT) {
+          w0f[ui] = *reinterpret_cast<const bf16x8*>(tail.proj.w0 + ((size_t)ut << 9) + lane * 8);
+          b0v[ui] = *reinterpret_cast<const f32x4*>(tail.proj.b0 + ut * 16 + 4 * lq);
+        }
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
           biv[ui][g] = tail.proj.bi[g * H + ucol[ui]];
@@ -366,7 +414,9 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     }
     auto load_step = [&](int64_t t, Slot& dst) {
       const int64_t tc = t < last_t ? t : last_t;  // past the end: reload the last step
-      if constexpr (PROJ) {
+      if constexpr (FRONT) {
+        // (nothing to load: the input rows are in LDS)
+      } else if constexpr (PROJ) {
         const bf16_t* yt = tail.proj.y + (tc * B + rowc) * tail.proj.ldy + 8 * lq;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) dst.y[ks] = *reinterpret_cast<const bf16x8*>(yt + ks * 32);
@@ -381,12 +431,34 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     };
 #pragma unroll
     for (int d = 0; d < PFW; ++d) load_step(d, gq[d]);
+    if constexpr (FRONT) {
+      // the workgroup's T x 4 input rows: bf16, zero-padded to 8, into LDS and out
+      for (int idx = tid; idx < (int)T * 4; idx += kThreads) {
+        const int t = idx >> 2, r = idx & 3;
+        const bool on = r < rpw && row0 + r < B;
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          v[i] = (bf16_t)((on && i < tail.proj.K0)
+                              ? tail.proj.x[((int64_t)t * B + row0 + r) * tail.proj.K0 + i]
+                              : 0.0f);
+        *reinterpret_cast<bf16x8*>(xs + idx * 8) = v;
+        if (on) *reinterpret_cast<bf16x8*>(tail.proj.x_bf + ((int64_t)t * B + row0 + r) * 8) = v;
+      }
+      __syncthreads();
+      front(0);  // y of step 0
+    }
     if (done) dwin.stage(done, 0, T, B, row0, rpw, tid);
     __syncthreads();
     bf16_t* hb = hb0;
     bf16_t* hbn = hb1;
     auto step = [&](int64_t t, Slot& gcur) {
       const bool reset = done != nullptr && dwin.at(t, rr);
+      if constexpr (FRONT) {  // this step's y rows (made during the step before)
+        const bf16_t* yt = yhist + ((int)t * 4 + rr) * HROW + 8 * lq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) gcur.y[ks] = *reinterpret_cast<const bf16x8*>(yt + ks * 32);
+      }
       // the carry's operand reads first; while they are in flight the PREVIOUS step's records go
       // out (their LDS reads and store issues sat behind the barrier, in front of these reads,
       // on every step's chain)
@@ -406,6 +478,8 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
               a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wif[ui][g][ks], gcur.y[ks], a, 0, 0, 0);
             gcur.g[ui][g] = spread4(a) + biv[ui][g];
           }
+        if constexpr (FRONT)
+          if (t + 1 < T) front(t + 1);  // the next step's y, off the carry's chain
       }
       f32x4 acc[UTW][3];
 #pragma unroll
@@ -472,6 +546,16 @@ gru_fwd_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ w_h,
     for (int d = 0; d < PFW; ++d)
       if (t0 + d < T) step(t0 + d, gq[d]);
     if (T > 0) pk.sweep((int)((T - 1) & 1), tid);  // the last step's records
+    if constexpr (FRONT) {  // the y history out: whole rows, 16 bytes per lane
+      constexpr int CPR = H / 8;
+      for (int idx = tid; idx < (int)T * 4 * CPR; idx += kThreads) {
+        const int c = idx % CPR, tr = idx / CPR, t = tr >> 2, r = tr & 3;
+        if (r < rpw && row0 + r < B)
+          *reinterpret_cast<u32x4*>(const_cast<bf16_t*>(tail.proj.y) +
+                                    ((int64_t)t * B + row0 + r) * tail.proj.ldy + c * 8) =
+              *reinterpret_cast<const u32x4*>(yhist + tr * HROW + c * 8);
+      }
+    }
 #pragma unroll
     for (int ui = 0; ui < UTW; ++ui) {
       if (wave + 4 * ui >= UT) continue;
@@ -1167,6 +1251,9 @@ gru_bwd_mfma_kernel(const float* __restrict__ g_h, const float* __restrict__ gat
 
 bool mfma_shape_ok(int64_t H) { return H >= 32 && H <= 128 && H % 32 == 0; }
 constexpr int kPack = 4;  // rows per workgroup of the packed-store instantiations
+// dynamic LDS the tail forms may ask for (one workgroup per CU at these sizes anyway): the
+// T x 16-row history of bf16(h_t) is most of it (T = 30, H = 64: 74 KB of ~100)
+constexpr int kGruTailLds = 128 * 1024;
 
 // Rows of its 16-row tile a workgroup fills.  A time step is a short dependent chain (LDS
 // exchange, 2 KS MFMAs per gate, the gate math) whose length does not depend on the fill, and a
@@ -1238,12 +1325,13 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
 static size_t gru_tail_lds(int64_t T, int64_t H, int64_t N_out) {
   return (size_t)(2 + T) * GROWS * (H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
          packed_lds(fwd_rec_bytes((int)H, true, true, true), kPack) +  // (whether packed or not)
+         (size_t)T * 4 * (8 + H + 8) * sizeof(bf16_t) +  // (FRONT: the x and y rows)
          (size_t)T * GROWS * N_out * 4;
 }
 
 extern "C" int mi_gru_seq_fwd_tail_supported(int64_t T, int64_t H, int64_t N_out) {
   return T >= 1 && mfma_shape_ok(H) && N_out >= 2 && N_out <= 16 && N_out % 2 == 0 &&
-         gru_tail_lds(T, H, N_out) <= 96 * 1024;
+         gru_tail_lds(T, H, N_out) <= kGruTailLds;
 }
 
 extern "C" int mi_gru_seq_bwd_tail_supported(int64_t T, int64_t H, int64_t N_out);
@@ -1287,7 +1375,7 @@ int gru_fwd_tail_launch(const char* who, const GruProj* proj, const float* gi, c
     static const hipError_t attr = hipFuncSetAttribute(                                            \
         reinterpret_cast<const void*>(                                                             \
             &gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK, PROJ>),                        \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
+        hipFuncAttributeMaxDynamicSharedMemorySize, kGruTailLds);                                    \
     MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                         \
     hipLaunchKernelGGL((gru_fwd_mfma_kernel<true, HH, GUARD, true, true, PACK, PROJ>), grid,       \
                        dim3(kThreads), lds, st, gi, w_h, b_hn, h0, done, h_out, h_prev_out,        \
@@ -1295,10 +1383,11 @@ int gru_fwd_tail_launch(const char* who, const GruProj* proj, const float* gi, c
   }
 #define MI_GRU_TAIL_H(HH)                                  \
   if (H == HH) {                                           \
-    if (proj) MI_GRU_TAIL(HH, true, kPack, true)           \
-    else if (rpw == kPack) MI_GRU_TAIL(HH, true, kPack, false) \
-    else if (guard) MI_GRU_TAIL(HH, true, 0, false)        \
-    else MI_GRU_TAIL(HH, false, 0, false)                  \
+    if (proj && proj->x) MI_GRU_TAIL(HH, true, kPack, 2)   \
+    else if (proj) MI_GRU_TAIL(HH, true, kPack, 1)         \
+    else if (rpw == kPack) MI_GRU_TAIL(HH, true, kPack, 0) \
+    else if (guard) MI_GRU_TAIL(HH, true, 0, 0)            \
+    else MI_GRU_TAIL(HH, false, 0, 0)                      \
   }
   MI_GRU_TAIL_H(32)
   MI_GRU_TAIL_H(64)
@@ -1354,7 +1443,41 @@ extern "C" int mi_gru_seq_fwd_proj_tail_bf16(
              "%s: projection operands missing or misaligned", who);
   MI_REQUIRE(mi_gru_seq_proj_supported(T, B, H, H, N_out), "%s: outside the supported class", who);
   const GruProj proj = {static_cast<const bf16_t*>(y_bf), ldy, static_cast<const bf16_t*>(w_i),
-                        b_i};
+                        b_i,     nullptr, 0, nullptr, nullptr, nullptr};
+  return gru_fwd_tail_launch(who, &proj, nullptr, w_h, b_hn, h0, done, h_out, h_prev_out,
+                             gates_out, h_final, h_prev_bf, w_out, b_out, N_out, ms_out, h_bf_out,
+                             extras, rng_state, offset_add, eps2, min_std, std_scale,
+                             entropy_weight, loglik, reg, T, B, H, stream);
+}
+
+// mi_gru_seq_fwd_proj_tail_bf16 with the relu Dense(K0 <= 8 -> H) in front of the GRU inside the
+// launch as well — see GruProj (FRONT).  x [T*B, K0] fp32: the front layer's input; w_0: forward
+// fragment-major image of its kernel; b_0 [H].  Out, besides mi_gru_seq_fwd_tail_bf16's: x_bf_out
+// [T*B, 8] and y_bf_out [T*B, H], the bf16 images of the layer's input and output (the x
+// operands of its own and of W_i's dW; y_bf_out is also what mi_gru_seq_bwd_proj_tail_bf16
+// reads).  Bit-identical to mi_mlp_fwd_bf16 on that layer + mi_gru_seq_fwd_proj_tail_bf16.
+extern "C" int mi_gru_seq_fwd_front_proj_tail_bf16(
+    const float* x, int64_t K0, const void* w_0, const float* b_0, void* x_bf_out, void* y_bf_out,
+    const void* w_i, const float* b_i, const float* w_h, const float* b_hn, const float* h0,
+    const uint8_t* done, float* h_out, float* h_prev_out, float* gates_out, float* h_final,
+    void* h_prev_bf, const void* w_out, const float* b_out, int64_t N_out, float* ms_out,
+    void* h_bf_out, const float* extras, const uint64_t* rng_state, uint64_t offset_add,
+    const float* eps2, float min_std, float std_scale, float entropy_weight, float* loglik,
+    float* reg, int64_t T, int64_t B, int64_t H, mi_stream_t stream) {
+  const char* who = "mi_gru_seq_fwd_front_proj_tail_bf16";
+  MI_REQUIRE(x && w_0 && b_0 && x_bf_out && y_bf_out && w_i && b_i && K0 >= 1 && K0 <= 8 &&
+                 al16(w_0) && al16(b_0) && al16(x_bf_out) && al16(y_bf_out) && al16(w_i),
+             "%s: front / projection operands missing, misaligned or K0 outside 1..8", who);
+  MI_REQUIRE(mi_gru_seq_proj_supported(T, B, H, H, N_out), "%s: outside the supported class", who);
+  const GruProj proj = {static_cast<const bf16_t*>(y_bf_out),
+                        H,
+                        static_cast<const bf16_t*>(w_i),
+                        b_i,
+                        x,
+                        (int)K0,
+                        static_cast<const bf16_t*>(w_0),
+                        b_0,
+                        static_cast<bf16_t*>(x_bf_out)};
   return gru_fwd_tail_launch(who, &proj, nullptr, w_h, b_hn, h0, done, h_out, h_prev_out,
                              gates_out, h_final, h_prev_bf, w_out, b_out, N_out, ms_out, h_bf_out,
                              extras, rng_state, offset_add, eps2, min_std, std_scale,
@@ -1413,7 +1536,7 @@ static size_t gru_bwd_tail_lds(int64_t T, int64_t H) {
 
 extern "C" int mi_gru_seq_bwd_tail_supported(int64_t T, int64_t H, int64_t N_out) {
   return T >= 1 && mfma_shape_ok(H) && N_out >= 2 && N_out <= 16 && N_out % 2 == 0 &&
-         gru_bwd_tail_lds(T, H) <= 96 * 1024;
+         gru_bwd_tail_lds(T, H) <= kGruTailLds;
 }
 
 namespace {
@@ -1453,7 +1576,7 @@ int gru_bwd_tail_launch(const char* who, const GruBwdProj* proj, const float* ga
     static const hipError_t attr = hipFuncSetAttribute(                                          \
         reinterpret_cast<const void*>(                                                           \
             &gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK, PROJ>),                     \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                  \
+        hipFuncAttributeMaxDynamicSharedMemorySize, kGruTailLds);                                  \
     MI_REQUIRE(attr == hipSuccess, "%s: cannot raise the LDS limit", who);                       \
     hipLaunchKernelGGL((gru_bwd_mfma_kernel<HH, GUARD, false, true, true, PACK, PROJ>), grid,    \
                        dim3(kThreads), lds, st, nullptr, gates, h_prev, w_h, done, dgi, nullptr, \

@@ -33,6 +33,10 @@ REC_TAIL_BWD = os.environ.get("MIPPO_REC_TAIL_BWD", "1") != "0"
 # stops one layer earlier and its backward launch goes); MIPPO_REC_PROJ=0: the projection as
 # the chain's last layer
 REC_PROJ = os.environ.get("MIPPO_REC_PROJ", "1") != "0"
+# ... and the relu Dense in front of that projection (at most 8 inputs: the first layer of
+# make_gru_actor_critic's actor) inside the forward sequence launch too — the actor's loss replay
+# is then TWO launches + its share of the dW launch; MIPPO_REC_FRONT=0: its own chain launch
+REC_FRONT = os.environ.get("MIPPO_REC_FRONT", "1") != "0"
 
 
 class Sequential(StatefulModule):
@@ -162,12 +166,22 @@ class Sequential(StatefulModule):
                                                           self.layers[j + 1])
                             and ops.gru_seq_bwd_tail_supported(
                                 lead[0], rec.hidden_features, self.layers[j + 1].out_features)):
-                        cctx, _ = dense_chain.forward_train([self.layers[i]], x2, False,
-                                                            want_out=False)
-                        y_bf = cctx[0][-1][1]  # the post-relu bf16 image
-                        if y_bf is None or tuple(y_bf.shape) != (x2.shape[0], rec.hidden_features):
-                            y_bf = None
-                    if y_bf is not None:
+                        if REC_FRONT and rec.replay_front_supported(self.layers[i]) \
+                                and x2.dtype == torch.float32:
+                            y_bf = "front"  # the relu layer inside the sequence launch too
+                        else:
+                            cctx, _ = dense_chain.forward_train([self.layers[i]], x2, False,
+                                                                want_out=False)
+                            y_bf = cctx[0][-1][1]  # the post-relu bf16 image
+                            if y_bf is None or tuple(y_bf.shape) != (x2.shape[0],
+                                                                     rec.hidden_features):
+                                y_bf = None
+                    if isinstance(y_bf, str):
+                        res = rec.replay(state0[j], None, done_seq, layer_extras,
+                                         need_input_grad=True, tail=tail,
+                                         proj=(None, (lead[0], lead[1]), self.layers[i], x2))
+                        cctx = res[4][4]
+                    elif y_bf is not None:
                         res = rec.replay(state0[j], None, done_seq, layer_extras,
                                          need_input_grad=True, tail=tail,
                                          proj=(y_bf, (lead[0], lead[1])))
@@ -186,7 +200,7 @@ class Sequential(StatefulModule):
                     upstream_needs = True
                     i = j + 1
                     if tail is not None:
-                        head_ctx, samp_ctx, out_d, reg_s = res[4]
+                        head_ctx, samp_ctx, out_d, reg_s = res[4][:4]
                         if y_bf is not None:
                             ctxs[-1] = ("chain+rec+proj", *ctxs[-1][1:], head_ctx, samp_ctx)
                         elif REC_TAIL_BWD and ops.gru_seq_bwd_tail_supported(

@@ -127,6 +127,12 @@ class GRU(StatefulModule):
                 and ops.gru_seq_proj_supported(T, B, self.hidden_features, self.in_features,
                                                head.out_features))
 
+    @staticmethod
+    def replay_front_supported(front) -> bool:
+        """... and `front` itself (`replay(proj=(None, (T, B), front, x2))`,
+        `mi_gru_seq_fwd_front_proj_tail_bf16`): at most 8 inputs, with a bias."""
+        return front.in_features <= 8 and front.bias is not None
+
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None,
                tail=None, proj=None):
         """`gi_seq` [T, B, 3H]: the input projection, already evaluated by the caller as the
@@ -144,7 +150,7 @@ class GRU(StatefulModule):
             # evaluated inside the sequence launch (with `tail`)
             from . import dense_chain
 
-            y_bf, (T, B) = proj
+            y_bf, (T, B) = proj[:2]
             head, sampler, raw_seq = tail
             pl = self._proj()
             dense_chain.refresh([pl, head])
@@ -153,15 +159,28 @@ class GRU(StatefulModule):
             if not ex2.is_contiguous():
                 ex2 = ex2.contiguous()
             off = sampler._next_offset()
-            h_out, h_prev, gates, h_final, ms2, h_bf, ll, reg = ops.gru_seq_fwd_proj_tail(
-                y_bf, pl._ff, self.b_i.data, self.w_h.data, self.b_hn.data, state0.contiguous(),
-                done_seq.contiguous(), head._ff, head.bias.data, A2, ex2,
-                sampler._state(y_bf.device), off, T, **sampler._kw())
+            front_ctx = None
+            if y_bf is None:
+                # proj = (None, (T, B), front Dense, x2 [T*B, K0]): the relu layer in front is
+                # evaluated inside the launch as well; its bf16 images come back
+                front, x2f = proj[2], proj[3]
+                dense_chain.refresh([front])
+                (h_out, h_prev, gates, h_final, ms2, h_bf, ll, reg, x_bf,
+                 y_bf) = ops.gru_seq_fwd_front_proj_tail(
+                    x2f, front._ff, front.bias.data, pl._ff, self.b_i.data, self.w_h.data,
+                    self.b_hn.data, state0.contiguous(), done_seq.contiguous(), head._ff,
+                    head.bias.data, A2, ex2, sampler._state(x2f.device), off, T, **sampler._kw())
+                front_ctx = ([(x_bf, y_bf, dense_chain._shadows(front)[0])], T * B, False)
+            else:
+                h_out, h_prev, gates, h_final, ms2, h_bf, ll, reg = ops.gru_seq_fwd_proj_tail(
+                    y_bf, pl._ff, self.b_i.data, self.w_h.data, self.b_hn.data,
+                    state0.contiguous(), done_seq.contiguous(), head._ff, head.bias.data, A2, ex2,
+                    sampler._state(y_bf.device), off, T, **sampler._kw())
             ctx = (None, h_prev, gates, done_seq, (T, B), need_input_grad, mfma, ("proj", y_bf))
             head_ctx = ([(h_bf, None, dense_chain._shadows(head)[0])], T * B, True)
             samp_ctx = (ms2, ex2, off, None, (T, B, A2))
             out = {"action": None, "log_likelihood": ll.view(T, B)}
-            return ctx, h_out, None, h_final, (head_ctx, samp_ctx, out, reg.view(T, B))
+            return ctx, h_out, None, h_final, (head_ctx, samp_ctx, out, reg.view(T, B), front_ctx)
         if gi_seq is not None:
             T, B, _ = gi_seq.shape
             x2, pctx = None, "external"

@@ -1796,6 +1796,45 @@ def gru_seq_fwd_proj_tail(y_bf, w_i_ff, b_i, w_h, b_hn, h0, done, w_out_ff, b_ou
     return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg
 
 
+def gru_seq_fwd_front_proj_tail(x2, w0_ff, b0, w_i_ff, b_i, w_h, b_hn, h0, done, w_out_ff, b_out,
+                                N_out: int, extras, rng_state, offset_add: int, T: int, *,
+                                min_std: float, std_scale: float, entropy_weight: float,
+                                eps2=None):
+    """`gru_seq_fwd_proj_tail` with the relu Dense(K0 <= 8 -> H) in front inside the launch too
+    (`mi_gru_seq_fwd_front_proj_tail_bf16`): x2 [T*B, K0] fp32 is that layer's input.  Returns
+    gru_seq_fwd_tail's tuple + (x_bf [T*B, 8], y_bf [T*B, H]), the layer's bf16 images."""
+    M, K0 = x2.shape
+    H = w_h.shape[0]
+    B = M // T
+    _need(w_h.shape == (H, 3 * H) and b_hn.shape == (H,) and h0.shape == (B, H)
+          and b_i.shape == (3 * H,) and b0.shape == (H,) and 1 <= K0 <= 8 and x2.is_contiguous()
+          and x2.dtype == f32, "gru_seq_fwd_front_proj_tail: shapes")
+    dev = x2.device
+    h_out = torch.empty(T, B, H, dtype=f32, device=dev)
+    h_prev = torch.empty(T, B, H, dtype=f32, device=dev)
+    gates = torch.empty(T, B, 4 * H, dtype=f32, device=dev)
+    h_final = torch.empty(B, H, dtype=f32, device=dev)
+    hp_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    h_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    x_bf = torch.empty(M, 8, dtype=bf16, device=dev)
+    y_bf = torch.empty(M, H, dtype=bf16, device=dev)
+    ms = torch.empty(M, N_out, dtype=f32, device=dev)
+    ll = torch.empty(M, dtype=f32, device=dev)
+    reg = torch.empty(M, dtype=f32, device=dev)
+    d = None if done is None else _as_u8(done)
+    _need(extras.shape == (M, N_out // 2) and extras.is_contiguous(),
+          "gru_seq_fwd_front_proj_tail: extras must be a contiguous [T*B, A]")
+    check(lib().mi_gru_seq_fwd_front_proj_tail_bf16(
+        ptr(x2, f32), K0, ptr(w0_ff, bf16), ptr(b0, f32), ptr(x_bf), ptr(y_bf), ptr(w_i_ff, bf16),
+        ptr(b_i, f32), ptr(w_h, f32), ptr(b_hn, f32), ptr(h0, f32), ptr(d), ptr(h_out, f32),
+        ptr(h_prev, f32), ptr(gates, f32), ptr(h_final, f32), ptr(hp_bf), ptr(w_out_ff, bf16),
+        ptr(b_out, f32), int(N_out), ptr(ms, f32), ptr(h_bf), ptr(extras, f32), ptr(rng_state),
+        int(offset_add), ptr(eps2, f32), float(min_std), float(std_scale), float(entropy_weight),
+        ptr(ll, f32), ptr(reg, f32), T, B, H, stream()), "mi_gru_seq_fwd_front_proj_tail_bf16")
+    h_prev.bf16_image = hp_bf
+    return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg, x_bf, y_bf
+
+
 def gru_seq_bwd_proj_tail(y_bf, w_i_fb, gates, h_prev, w_h, done, w_out_fb, N_out: int,
                           mean_and_std, extras, rng_state, offset_add: int, g_ll, g_reg: float, *,
                           min_std: float, std_scale: float, entropy_weight: float, eps2=None):

@@ -138,7 +138,7 @@ def test_c4_gru_bf16_mfma_ppo_step_vs_oracle(dev):
             used = _called(prof)
             # the matrix-core recurrence — since round 3 with the head Dense and the sampler's
             # replay riding in the forward sequence launch
-            assert {"mi_gru_seq_fwd_proj_tail_bf16", "mi_gru_seq_bwd_proj_tail_bf16"} <= used, used
+            assert {"mi_gru_seq_fwd_front_proj_tail_bf16", "mi_gru_seq_bwd_proj_tail_bf16"} <= used, used
             assert "mi_gru_seq_fwd_f32" not in used   # the matrix-core recurrence, not VALU
             done = info["rollout"].done
             assert int(done.sum()) >= int(0.15 * N * T)  # reset-heavy: ~20 % of the steps

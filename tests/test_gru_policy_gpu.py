@@ -187,7 +187,8 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
     (sampler backward + the head's dX in front of the BPTT, REC_TAIL_BWD), and for the input
     projection inside both (`mi_gru_seq_fwd_proj_tail_bf16` / `mi_gru_seq_bwd_proj_tail_bf16`,
     REC_PROJ: gi = y W_i + b_i per step from the bf16 image of the relu layer in front, its
-    backward behind the BPTT step).  Every state width of the matrix-core GRU (H = 32 and 96:
+    backward behind the BPTT step), and for the relu Dense in front of the projection
+    (`mi_gru_seq_fwd_front_proj_tail_bf16`, REC_FRONT).  Every state width of the matrix-core GRU (H = 32 and 96:
     waves without a unit tile; 128: two tiles per wave), ragged batches (74 and 132 rows per
     minibatch) and several action sizes."""
     from nnx_ppo_amd import _lib, config
@@ -199,11 +200,14 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
 
     out, n_launch = [], []
     with config.use_compute_dtype("bf16"):
-        for tail, tail_bwd, proj in ((True, True, True), (True, True, False),
-                                     (True, False, False), (False, False, False)):
+        for tail, tail_bwd, proj, front in ((True, True, True, True), (True, True, True, False),
+                                            (True, True, False, False),
+                                            (True, False, False, False),
+                                            (False, False, False, False)):
             monkeypatch.setattr(containers, "REC_TAIL", tail)
             monkeypatch.setattr(containers, "REC_TAIL_BWD", tail_bwd)
             monkeypatch.setattr(containers, "REC_PROJ", proj)
+            monkeypatch.setattr(containers, "REC_FRONT", front)
             env = EpisodeWrapper(MockEnv(5, A, max_steps=5), 1000)
             net = factories.make_gru_actor_critic(5, A, H, [256, 256], Rngs(9))
             ts = ppo.new_training_state(env, net, n_envs, 9, 3e-4, device=dev)
@@ -215,7 +219,9 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
                 used = {name for name, *_ in prof.records}
                 assert ("mi_gru_seq_fwd_tail_bf16" in used) == (tail and not proj), used
                 # ... and `mi_gru_seq_*_proj_tail_bf16` the input projection too (REC_PROJ)
-                assert ("mi_gru_seq_fwd_proj_tail_bf16" in used) == proj, used
+                assert ("mi_gru_seq_fwd_proj_tail_bf16" in used) == (proj and not front), used
+                # ... and the relu Dense in front of it (REC_FRONT)
+                assert ("mi_gru_seq_fwd_front_proj_tail_bf16" in used) == front, used
                 assert ("mi_gru_seq_bwd_proj_tail_bf16" in used) == proj, used
                 if tail and H == 64:  # (other widths roll out through the generic containers)
                     assert "mi_tanh_gauss_fwd_f32" not in used and "mi_gru_seq_fwd_bf16" not in used
@@ -225,9 +231,9 @@ def test_gru_replay_with_head_and_sampler_in_the_sequence_launch(dev, monkeypatc
                     assert not {"mi_tanh_gauss_bwd_f32", "mi_gru_seq_bwd_bf16"} & used, used
             n_launch.append(sum(not name.endswith("_supported") for name, *_ in prof.records))
             out.append((ts.optimizer.params.clone(), ts.optimizer.m.clone(), ms))
-    # 2 epochs x 2 minibatches: the chain's backward launch goes with the projection inside, then
-    # two launches fewer per gradient step each time
-    assert [b - a for a, b in zip(n_launch, n_launch[1:])] == [4, 8, 8], n_launch
+    # 2 epochs x 2 minibatches: the front layer's forward launch goes, the chain's backward launch
+    # goes with the projection inside, then two launches fewer per gradient step each time
+    assert [b - a for a, b in zip(n_launch, n_launch[1:])] == [4, 4, 8, 8], n_launch
     for (pa, ma, la), (pb, mb, lb) in zip(out, out[1:]):
         assert la == lb
         assert torch.equal(pa, pb) and torch.equal(ma, mb)
