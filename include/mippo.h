@@ -374,6 +374,7 @@ int mi_gru_seq_fwd_proj_tail_bf16(
  * and output (x operands of its own and of W_i's dW; y_bf_out is what
  * mi_gru_seq_bwd_proj_tail_bf16 reads).  Bit-identical to mi_mlp_fwd_bf16 on that layer +
  * mi_gru_seq_fwd_proj_tail_bf16. */
+int mi_gru_seq_front_supported(int64_t T, int64_t B, int64_t H, int64_t K0, int64_t N_out);
 int mi_gru_seq_fwd_front_proj_tail_bf16(
     const float* x, int64_t K0, const void* w_0, const float* b_0, void* x_bf_out, void* y_bf_out,
     const void* w_i, const float* b_i, const float* w_h, const float* b_hn, const float* h0,

@@ -1322,10 +1322,11 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
 }
 
 // LDS of the TAIL form: the two carry tiles + the T x 16-row history + the head's rows
-static size_t gru_tail_lds(int64_t T, int64_t H, int64_t N_out) {
+// (`front`: + the front layer's T x 4 input and output rows)
+static size_t gru_tail_lds(int64_t T, int64_t H, int64_t N_out, bool front = false) {
   return (size_t)(2 + T) * GROWS * (H + 8) * sizeof(bf16_t) + DONE_WIN * GROWS +
          packed_lds(fwd_rec_bytes((int)H, true, true, true), kPack) +  // (whether packed or not)
-         (size_t)T * 4 * (8 + H + 8) * sizeof(bf16_t) +  // (FRONT: the x and y rows)
+         (front ? (size_t)T * 4 * (8 + H + 8) * sizeof(bf16_t) : 0) +
          (size_t)T * GROWS * N_out * 4;
 }
 
@@ -1363,7 +1364,9 @@ int gru_fwd_tail_launch(const char* who, const GruProj* proj, const float* gi, c
                   {extras, {rng_state, offset_add, eps2, eps2}, nullptr, nullptr, nullptr, nullptr,
                    loglik, reg, (int)(N_out / 2), min_std, std_scale, entropy_weight, 0},
                   (int)N_out};
-  const size_t lds = gru_tail_lds(T, H, N_out);
+  const size_t lds = gru_tail_lds(T, H, N_out, proj && proj->x);
+  MI_REQUIRE(lds <= (size_t)kGruTailLds, "%s: %zu bytes of LDS needed, %d available", who, lds,
+             kGruTailLds);
   const int rpw = rows_per_group(B);
   MI_REQUIRE(!proj || rpw == kPack, "%s: the projection rides in the small-batch form only", who);
   const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
@@ -1450,6 +1453,14 @@ extern "C" int mi_gru_seq_fwd_proj_tail_bf16(
                              entropy_weight, loglik, reg, T, B, H, stream);
 }
 
+// 1 when the layer in front can ride in the forward launch too (its T x 4 input and output rows
+// need room in LDS beside the history of h).
+extern "C" int mi_gru_seq_front_supported(int64_t T, int64_t B, int64_t H, int64_t K0,
+                                          int64_t N_out) {
+  return K0 >= 1 && K0 <= 8 && mi_gru_seq_proj_supported(T, B, H, H, N_out) &&
+         gru_tail_lds(T, H, N_out, true) <= (size_t)kGruTailLds;
+}
+
 // mi_gru_seq_fwd_proj_tail_bf16 with the relu Dense(K0 <= 8 -> H) in front of the GRU inside the
 // launch as well — see GruProj (FRONT).  x [T*B, K0] fp32: the front layer's input; w_0: forward
 // fragment-major image of its kernel; b_0 [H].  Out, besides mi_gru_seq_fwd_tail_bf16's: x_bf_out
@@ -1468,7 +1479,8 @@ extern "C" int mi_gru_seq_fwd_front_proj_tail_bf16(
   MI_REQUIRE(x && w_0 && b_0 && x_bf_out && y_bf_out && w_i && b_i && K0 >= 1 && K0 <= 8 &&
                  al16(w_0) && al16(b_0) && al16(x_bf_out) && al16(y_bf_out) && al16(w_i),
              "%s: front / projection operands missing, misaligned or K0 outside 1..8", who);
-  MI_REQUIRE(mi_gru_seq_proj_supported(T, B, H, H, N_out), "%s: outside the supported class", who);
+  MI_REQUIRE(mi_gru_seq_front_supported(T, B, H, K0, N_out), "%s: outside the supported class",
+             who);
   const GruProj proj = {static_cast<const bf16_t*>(y_bf_out),
                         H,
                         static_cast<const bf16_t*>(w_i),

@@ -166,8 +166,9 @@ class Sequential(StatefulModule):
                                                           self.layers[j + 1])
                             and ops.gru_seq_bwd_tail_supported(
                                 lead[0], rec.hidden_features, self.layers[j + 1].out_features)):
-                        if REC_FRONT and rec.replay_front_supported(self.layers[i]) \
-                                and x2.dtype == torch.float32:
+                        if REC_FRONT and x2.dtype == torch.float32 \
+                                and rec.replay_front_supported(lead[0], lead[1], self.layers[i],
+                                                               self.layers[j + 1]):
                             y_bf = "front"  # the relu layer inside the sequence launch too
                         else:
                             cctx, _ = dense_chain.forward_train([self.layers[i]], x2, False,

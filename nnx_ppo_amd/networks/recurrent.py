@@ -127,11 +127,13 @@ class GRU(StatefulModule):
                 and ops.gru_seq_proj_supported(T, B, self.hidden_features, self.in_features,
                                                head.out_features))
 
-    @staticmethod
-    def replay_front_supported(front) -> bool:
+    def replay_front_supported(self, T: int, B: int, front, head) -> bool:
         """... and `front` itself (`replay(proj=(None, (T, B), front, x2))`,
-        `mi_gru_seq_fwd_front_proj_tail_bf16`): at most 8 inputs, with a bias."""
-        return front.in_features <= 8 and front.bias is not None
+        `mi_gru_seq_fwd_front_proj_tail_bf16`): at most 8 inputs, with a bias, and room in LDS
+        for its T x 4 input and output rows."""
+        return (front.bias is not None
+                and ops.gru_seq_front_supported(T, B, self.hidden_features, front.in_features,
+                                                head.out_features))
 
     def replay(self, state0, x_seq, done_seq, extras_seq, need_input_grad=True, gi_seq=None,
                tail=None, proj=None):

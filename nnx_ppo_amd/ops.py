@@ -1796,6 +1796,10 @@ def gru_seq_fwd_proj_tail(y_bf, w_i_ff, b_i, w_h, b_hn, h0, done, w_out_ff, b_ou
     return h_out, h_prev, gates, h_final, ms, h_bf, ll, reg
 
 
+def gru_seq_front_supported(T: int, B: int, H: int, K0: int, N_out: int) -> bool:
+    return bool(lib().mi_gru_seq_front_supported(int(T), int(B), int(H), int(K0), int(N_out)))
+
+
 def gru_seq_fwd_front_proj_tail(x2, w0_ff, b0, w_i_ff, b_i, w_h, b_hn, h0, done, w_out_ff, b_out,
                                 N_out: int, extras, rng_state, offset_add: int, T: int, *,
                                 min_std: float, std_scale: float, entropy_weight: float,
