@@ -35,10 +35,11 @@ rep("      unsigned char* const rc0 = pk.rec((int)(t & 1), rr);\n",
 rep("        unsigned char* const rc = rc0 + 4 * ucol[ui];\n",
     "        { volatile float sink = hnew + r + z + n + qn; (void)sink; }\n" + STAMP % 3 +
     "        unsigned char* const rc = rc0 + 4 * ucol[ui];\n")                        # gate math done
-rep("      __syncthreads();\n      pk.sweep((int)(t & 1), tid);\n",
-    STAMP % 4 + "      __syncthreads();\n" + STAMP % 5 + "      pk.sweep((int)(t & 1), tid);\n" +
+rep("      if (t != 0) pk.sweep((int)((t - 1) & 1), tid);\n",
+    "      if (t != 0) pk.sweep((int)((t - 1) & 1), tid);\n" + STAMP % 7)     # sweep issued
+rep("      load_step(t + PFW, gcur);\n      __syncthreads();\n",
+    STAMP % 4 + "      load_step(t + PFW, gcur);\n" + STAMP % 5 + "      __syncthreads();\n" +
     STAMP % 6)
-rep("      load_step(t + PFW, gcur);\n    };\n", "      load_step(t + PFW, gcur);\n" + STAMP % 7 + "    };\n")
 rep("      if (svalid) h_final[srowc * (unsigned)H + ucol[ui]] = hc[ui];\n    }\n",
     "      if (svalid) h_final[srowc * (unsigned)H + ucol[ui]] = hc[ui];\n    }\n"
     "    __syncthreads();\n"

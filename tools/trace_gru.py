@@ -17,11 +17,15 @@ g = torch.Generator().manual_seed(1)
 r = lambda *s: torch.randn(*s, generator=g).to(dev)
 gi, w_h, b, h0 = r(T, B, 3 * H), r(H, 3 * H) / H ** 0.5, r(H), r(B, H)
 done = (torch.rand(T, B, generator=g) < 0.1).to(dev)
-NAMES = ["proj MFMAs", "h MFMAs", "gate math", "LDS writes", "barrier", "sweep", "refill"]
+# stamps in program order: 0 start, 7 operand reads + sweep issued, 1 projection, 2 h MFMAs
+# issued, 3 gate math, 4 LDS writes, 5 refill, 6 barrier
+ORDER = [0, 7, 1, 2, 3, 4, 5, 6]
+NAMES = ["reads + sweep", "proj MFMAs", "h MFMAs", "gate math", "LDS writes", "refill", "barrier"]
 
 
 def report(tag, h_final):
     st = h_final[28:32].contiguous().view(torch.int64).flatten()[:128].view(16, 8).cpu().double()
+    st = st[:, ORDER]
     d = st[:, 1:] - st[:, :-1]
     whole = (st[1:, 0] - st[:-1, 0]).median().item()
     gap = (st[1:, 0] - st[:-1, 7]).median().item()
