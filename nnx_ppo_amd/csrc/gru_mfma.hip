@@ -17,6 +17,18 @@
 // Backward: the same layout with the dh carry in registers; the gate-gradient tile is
 // the A operand of dh = dgh . W_h^T.
 // Cell arithmetic and the reset-on-done rule as in gru.hip (flax GRUCell: PARITY UNPINNED).
+//
+// Forms of the two kernels (template parameters; every form returns the same bits):
+//   * full tiles (16 rows per workgroup, batches that fill the chip): results stored from a
+//     row-major lane arrangement (RowLanes);
+//   * PACK = 4 (small batches, `rows_per_group`): 4 rows per workgroup, ONE element per lane
+//     (spread4), results through per-row LDS records swept with whole stores (PackedStores);
+//   * TAIL: the head Dense + tanh-Gaussian sampler behind the recurrence (forward), their
+//     backward in front of the BPTT (GruTail / GruBwdTail);
+//   * PROJ (with TAIL, PACK): the input projection inside, forward and backward (GruProj /
+//     GruBwdProj); PROJ = 2 (forward): the relu Dense in front of it as well.
+// DESIGN.md section 3 ("The GRU actor's loss replay in two sequence launches") has the
+// measurements behind each of them.
 #include "bf16_common.h"
 #include "sampler_math.h"
 
@@ -1260,10 +1272,13 @@ constexpr int kGruTailLds = 128 * 1024;
 // CU drains the step's stores at ~20 B/clk (T = 30, B = 1024, H = 64 training forward: 15 us with
 // the stores compiled out, 33 us with them, on 64 of the 256 CUs).  So a batch that would leave
 // CUs idle is spread thinner: fewer rows per workgroup, more workgroups.  MIPPO_GRU_ROWS pins it.
-int rows_per_group(int64_t B) {
+int rows_per_group(int64_t B, int64_t T) {
   const char* e = getenv("MIPPO_GRU_ROWS");  // read per launch: the tests switch it
   const int pinned = e ? atoi(e) : 0;
   if (pinned == 4 || pinned == 8 || pinned == 16) return pinned;
+  // a step or two (a rollout step through the generic containers): the launch is its latency,
+  // and the 4-row form's prologue (zeroed tiles, record bookkeeping) costs ~2 us more
+  if (T < 4) return GROWS;
   // full tiles once they cover the chip; below that 4 rows, whose stores go out packed
   // (PackedStores) — 8 rows with the direct stores measured no better than 16 in the forward
   return mippo::ceil_div(B, (int64_t)GROWS) >= 256 ? GROWS : kPack;
@@ -1285,7 +1300,7 @@ extern "C" int mi_gru_seq_fwd_bf16(const float* gi, const float* w_h, const floa
              "mi_gru_seq_fwd_bf16: null pointer");
   MI_REQUIRE((h_prev_out == nullptr) == (gates_out == nullptr),
              "mi_gru_seq_fwd_bf16: h_prev_out and gates_out go together");
-  const int rpw = rows_per_group(B);
+  const int rpw = rows_per_group(B, T);
   const bool pack = rpw == kPack;
   bf16_t* hpb = static_cast<bf16_t*>(h_prev_bf);
   const size_t lds =
@@ -1367,7 +1382,7 @@ int gru_fwd_tail_launch(const char* who, const GruProj* proj, const float* gi, c
   const size_t lds = gru_tail_lds(T, H, N_out, proj && proj->x);
   MI_REQUIRE(lds <= (size_t)kGruTailLds, "%s: %zu bytes of LDS needed, %d available", who, lds,
              kGruTailLds);
-  const int rpw = rows_per_group(B);
+  const int rpw = rows_per_group(B, T);
   MI_REQUIRE(!proj || rpw == kPack, "%s: the projection rides in the small-batch form only", who);
   const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
   hipStream_t st = mippo::as_stream(stream);
@@ -1428,7 +1443,7 @@ extern "C" int mi_gru_seq_fwd_tail_bf16(
 extern "C" int mi_gru_seq_proj_supported(int64_t T, int64_t B, int64_t H, int64_t K_in,
                                          int64_t N_out) {
   return B >= 1 && K_in == H && mi_gru_seq_fwd_tail_supported(T, H, N_out) &&
-         mi_gru_seq_bwd_tail_supported(T, H, N_out) && rows_per_group(B) == kPack;
+         mi_gru_seq_bwd_tail_supported(T, H, N_out) && rows_per_group(B, T) == kPack;
 }
 
 // mi_gru_seq_fwd_tail_bf16 with gi = y W_i + b_i evaluated inside the launch — see GruProj.
@@ -1504,7 +1519,7 @@ extern "C" int mi_gru_seq_bwd_bf16(const float* g_h, const float* gates, const f
              "mi_gru_seq_bwd_bf16: bad shape");
   MI_REQUIRE(g_h && gates && h_prev && w_h && dgi && (dgh || dgh_bf),
              "mi_gru_seq_bwd_bf16: null pointer (dgh or its bf16 image is required)");
-  const int rpw = rows_per_group(B);
+  const int rpw = rows_per_group(B, T);
   const bool pack = rpw == kPack;
   bf16_t* gb = static_cast<bf16_t*>(dgh_bf);
   const size_t lds =
@@ -1577,7 +1592,7 @@ int gru_bwd_tail_launch(const char* who, const GruBwdProj* proj, const float* ga
                       (int)(N_out / 2), min_std, std_scale, entropy_weight},
                      (int)N_out};
   const size_t lds = gru_bwd_tail_lds(T, H);
-  const int rpw = rows_per_group(B);
+  const int rpw = rows_per_group(B, T);
   MI_REQUIRE(!proj || rpw == kPack, "%s: the projection rides in the small-batch form only", who);
   const dim3 grid((unsigned)mippo::ceil_div(B, (int64_t)rpw));
   hipStream_t st = mippo::as_stream(stream);
