@@ -404,6 +404,188 @@ tn256_kernel(Dw256Table tab) {
   }
 }
 
+
+// ---- dW on 128 x 128 tiles with the SAME staging: the small problems of a training-size group ----
+// (the MLP trunks' 64- and 256-wide layers, heads, first layers).  gemm_bf16.hip's tile kernel
+// stages a 64-row tile global -> registers -> ds_write and spends 880 + 370 of its ~3 000 cycles
+// per tile on that (store-to-LDS with the wait for its loads, load issue) beside 1 170 of
+// multiplying; here a slot is 32 rows of 256 bytes of each operand, DMA'd straight into LDS
+// (one instruction = four rows), four 16-KB slots in a ring (64 KB: two workgroups per CU), the
+// wait a counted vmcnt and the barrier raw — tn256_kernel's pipeline with 4 waves (2 x 2, each
+// 64 x 64 = 4 x 4 MFMA tiles).  A row is exactly one 256-byte bank row, so the chunk swizzle of
+// the 512-byte rows carries over unchanged: chunk c of row r at position c ^ 2 f(r).  Same
+// split plan, same k order (32 rows per MFMA k-step, ascending), same operand order as the
+// tile kernel: the slabs are bit-identical.
+constexpr int kT128 = 256;
+constexpr int TB128 = 128;
+constexpr int kRow128 = TB128 * 2;             // bytes of a staged row
+constexpr int kOp128 = KB * kRow128;           // one operand of one slot: 8 KB
+constexpr int kSlot128 = 2 * kOp128;
+constexpr int kLds128 = NSLOT * kSlot128;      // 64 KB
+constexpr int TM128 = 4, TN128 = 4;
+
+__global__ void __launch_bounds__(kT128, 2)
+tn128_kernel(Dw256Table tab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // split-major ids (the tiles of one row range are neighbours), then the XCD remap
+  const unsigned total = gridDim.x;
+  const unsigned hw = blockIdx.x;
+  const unsigned chunk = total / 8, rem = total % 8;
+  const unsigned xcd = hw % 8, idx = hw / 8;
+  const unsigned logical = xcd * chunk + (xcd < rem ? xcd : rem) + idx;
+  const int zsplit = (int)(logical / (unsigned)tab.tiles);
+  const int tile = (int)(logical % (unsigned)tab.tiles);
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxDw256; ++q)
+    if (q < tab.n && tile >= tab.p[q].tile_begin) pi = q;
+  const Dw256Problem pr = tab.p[pi];
+  const int lt = tile - pr.tile_begin;
+  const int64_t i0 = (int64_t)(lt / pr.tiles_j) * TB128;
+  const int64_t j0 = (int64_t)(lt % pr.tiles_j) * TB128;
+  const int64_t I = pr.I, J = pr.J;
+  const int64_t r_begin = (int64_t)zsplit * tab.rows_per_split;
+  int64_t r_end = r_begin + tab.rows_per_split;
+  r_end = r_end < tab.M ? r_end : tab.M;
+  const int nk = r_end > r_begin ? (int)((r_end - r_begin) / KB) : 0;  // whole slots (M % 32 == 0)
+
+  // staging: instruction q of an operand = rows 4q .. 4q + 3 of the slot; wave w issues 2w, 2w + 1
+  const char* ga[2];
+  const char* gb[2];
+  unsigned la[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (wave * 2 + q) * 4 + (lane >> 4);
+    const int src_chunk = (lane & 15) ^ swz_tn(row);
+    // column chunks beyond the operand's row stay inside it (their products land in output
+    // rows / columns that are never stored)
+    const int64_t ca = i0 + src_chunk * 8 < pr.lda ? i0 + src_chunk * 8 : 0;
+    const int64_t cb = j0 + src_chunk * 8 < pr.ldb ? j0 + src_chunk * 8 : 0;
+    ga[q] = reinterpret_cast<const char*>(pr.A + (r_begin + row) * pr.lda + ca);
+    gb[q] = reinterpret_cast<const char*>(pr.B + (r_begin + row) * pr.ldb + cb);
+    la[q] = (unsigned)((wave * 2 + q) * 1024);
+  }
+  const int64_t stride_a = (int64_t)KB * pr.lda * 2, stride_b = (int64_t)KB * pr.ldb * 2;
+  auto stage = [&](int t) {
+    const int tc = t < nk ? t : (nk > 0 ? nk - 1 : 0);
+    unsigned char* slot = lds + (t & (NSLOT - 1)) * kSlot128;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[q] + tc * stride_a),
+                                       (lds_ptr_t)(slot + la[q]), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[q] + tc * stride_b),
+                                       (lds_ptr_t)(slot + kOp128 + la[q]), 16, 0, 0);
+  };
+
+  f32x4 acc[TM128][TN128], accb[TN128];
+#pragma unroll
+  for (int a = 0; a < TM128; ++a)
+#pragma unroll
+    for (int b = 0; b < TN128; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < TN128; ++b) accb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = i0 == 0 && wm == 0;  // column sums of dZ: once per column tile
+  typedef __attribute__((ext_vector_type(8))) short ones_s16x8;
+  const bf16x8 ones = __builtin_bit_cast(
+      bf16x8, ones_s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
+  // transposing fragment gather: lane 4q + p of each 16-lane group g addresses row 8g + q
+  // (+ 4 for the second read), columns c0 + 4p .. 4p + 3
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int xo = swz_tn(8 * g + tq);  // the same for row + 4
+  unsigned oa[TM128], ob[TN128];
+#pragma unroll
+  for (int a = 0; a < TM128; ++a)
+    oa[a] = (unsigned)((8 * g + tq) * kRow128 + (((wm * 8 + 2 * a + (tp >> 1)) ^ xo) * 16) +
+                       8 * (tp & 1));
+#pragma unroll
+  for (int b = 0; b < TN128; ++b)
+    ob[b] = (unsigned)(kOp128 + (8 * g + tq) * kRow128 +
+                       (((wn * 8 + 2 * b + (tp >> 1)) ^ xo) * 16) + 8 * (tp & 1));
+  using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+  auto frag = [&](const unsigned char* slot, unsigned off) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + off));
+    const s16x4 hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(slot + off + 4 * kRow128));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int t = 0; t < nk; ++t) {
+    stage(t + 3);
+    const unsigned char* slot = lds + (t & (NSLOT - 1)) * kSlot128;
+    bf16x8 af[TM128], bfr[TN128];
+#pragma unroll
+    for (int b = 0; b < TN128; ++b) bfr[b] = frag(slot, ob[b]);
+#pragma unroll
+    for (int a = 0; a < TM128; ++a) af[a] = frag(slot, oa[a]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < TM128; ++a)
+#pragma unroll
+      for (int b = 0; b < TN128; ++b)
+        // dZ fragment first: a lane ends with 4 CONSECUTIVE output columns of one row
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int b = 0; b < TN128; ++b)
+        accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], ones, accb[b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* slab = pr.slabs + (int64_t)zsplit * (I * J + J);
+  const int li = lane & 15, lq = lane >> 4;
+  const int In = (int)I, Jn = (int)J;
+  const bool vec = (Jn & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
+#pragma unroll
+  for (int a = 0; a < TM128; ++a) {
+    const int i = (int)i0 + wm * 64 + a * 16 + li;
+#pragma unroll
+    for (int b = 0; b < TN128; ++b) {
+      const int j = (int)j0 + wn * 64 + b * 16 + 4 * lq;
+      if (i < In && j < Jn) {
+        float* dst = slab + i * Jn + j;
+        if (vec) {
+          *reinterpret_cast<f32x4*>(dst) = acc[a][b];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j + e < Jn) dst[e] = acc[a][b][e];
+        }
+      }
+    }
+  }
+  if (do_bias && li == 0) {  // every row of the ones-tile holds the same sums
+#pragma unroll
+    for (int b = 0; b < TN128; ++b) {
+      const int j = (int)j0 + wn * 64 + b * 16 + 4 * lq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j + e < Jn) slab[(int64_t)In * Jn + j + e] = accb[b][e];
+    }
+  }
+}
+
 }  // namespace
 
 namespace mippo_gemm {
@@ -527,6 +709,48 @@ int dw256_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, c
   }
   hipLaunchKernelGGL(tn256_kernel, dim3((unsigned)(tiles * S)), dim3(kT), kLdsBytes, st, tab);
   return mippo::check_launch("tn256_gemm_dw_bf16");
+}
+
+// The 128-tile form (tn128_kernel) for the rest of a group: M a multiple of 32, splits of whole
+// slots; MIPPO_DW128_DMA=0 keeps the register-staged tile kernel (A/B, bit-identity tests).
+bool dw128_takes(int64_t M, int64_t rows_per_split, int n) {
+  const char* e = getenv("MIPPO_DW128_DMA");  // read per launch: the tests switch it
+  const bool enabled = !(e && e[0] == '0');
+  return enabled && n >= 1 && n <= kMaxDw256 && M >= KB && M % KB == 0 && rows_per_split % KB == 0;
+}
+
+int dw128_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, const int64_t* K,
+                 const int64_t* N, int64_t M, float* const* slabs, int64_t rows, int64_t S,
+                 hipStream_t st) {
+  if (n < 1 || n > kMaxDw256) return -EINVAL;
+  Dw256Table tab = {};
+  tab.n = n;
+  tab.M = M;
+  tab.rows_per_split = rows;
+  int tiles = 0;
+  for (int l = 0; l < n; ++l) {
+    Dw256Problem& pr = tab.p[l];
+    pr.A = x_bf[l];
+    pr.B = dz_bf[l];
+    pr.slabs = slabs[l];
+    pr.lda = mippo::ceil_div(K[l], 8) * 8;
+    pr.ldb = mippo::ceil_div(N[l], 8) * 8;
+    pr.I = K[l];
+    pr.J = N[l];
+    pr.tile_begin = tiles;
+    pr.tiles_j = (int)mippo::ceil_div(N[l], TB128);
+    tiles += (int)(mippo::ceil_div(K[l], TB128) * mippo::ceil_div(N[l], TB128));
+  }
+  tab.tiles = tiles;
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&tn128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      kLds128);
+  if (attr != hipSuccess) {
+    mippo::set_error("dw128_launch: cannot raise the LDS limit");
+    return -EIO;
+  }
+  hipLaunchKernelGGL(tn128_kernel, dim3((unsigned)(tiles * S)), dim3(kT128), kLds128, st, tab);
+  return mippo::check_launch("tn128_gemm_dw_bf16");
 }
 
 }  // namespace mippo_gemm

@@ -761,7 +761,17 @@ static void dw_split_plan(int64_t M, int64_t total_tiles, int64_t* rows, int64_t
   }();
   const int64_t target =
       override_target > 0 ? override_target : (int64_t)13 * mippo::kNumCU / 8;
-  int64_t s = mippo::ceil_div(target, total_tiles < 1 ? 1 : total_tiles);
+  const int64_t tiles = total_tiles < 1 ? 1 : total_tiles;
+  int64_t s = mippo::ceil_div(target, tiles);
+  // Whole splits per XCD: workgroup ids are split-major and dealt to the 8 XCDs in equal runs,
+  // so with S a multiple of 8 every XCD's L2 serves the tiles of ITS splits only (they read the
+  // same rows of X and dZ).  Off that grid the launch is a third slower (C2, 13 tiles: S = 32
+  // 28 us; 26 / 40 splits 37-40 us; C4, 14 tiles: S = 30 -> 32 is 4.6 % of the iteration).  Up
+  // if the launch still fits the chip's 2 x 256 workgroup slots, else down.
+  if (override_target <= 0 && s >= 8) {
+    const int64_t up = mippo::ceil_div(s, 8) * 8, down = s / 8 * 8;
+    s = tiles * up <= 2 * (int64_t)mippo::kNumCU ? up : down;
+  }
   const int64_t max_s = mippo::ceil_div(M, 128);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -864,6 +874,32 @@ static int dw_grouped_launch(const char* who, int64_t n, const void* const* x_bf
     if (!big[l]) tiles_all += dw_tiles(K[l], N[l]);
   int64_t rows, S;
   dw_split_plan(M, tiles_all, &rows, &S);
+  {
+    // the same tiles and splits through the DMA-staged 128 x 128 kernel (gemm256_bf16.hip:
+    // tn128_kernel) when the rows come in whole 32-row slots: bit-identical slabs
+    int n_rest = 0;
+    for (int64_t l = 0; l < n; ++l) n_rest += !big[l];
+    if (mippo_gemm::dw128_takes(M, rows, n_rest)) {
+      const bf16_t* xa[kMaxDwProblems];
+      const bf16_t* za[kMaxDwProblems];
+      float* sl[kMaxDwProblems];
+      int64_t Kr[kMaxDwProblems], Nr[kMaxDwProblems];
+      int q = 0;
+      for (int64_t l = 0; l < n; ++l) {
+        if (big[l]) continue;
+        xa[q] = static_cast<const bf16_t*>(x_bf[l]);
+        za[q] = static_cast<const bf16_t*>(dz_bf[l]);
+        Kr[q] = K[l];
+        Nr[q] = N[l];
+        sl[q] = ws;
+        slab_ptr[l] = ws;
+        Sv[l] = S;
+        ws += S * (KNv[l] + N[l]);
+        ++q;
+      }
+      return mippo_gemm::dw128_launch(n_rest, xa, za, Kr, Nr, M, sl, rows, S, st);
+    }
+  }
   size_t lds = 0;
   for (int cls = 0; cls < 3; ++cls) {
     DwTable& tab = all.cls[cls];

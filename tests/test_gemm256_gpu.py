@@ -146,3 +146,44 @@ def test_dw256_asymmetric_identity(dev):
     ops.dense_bwd_dw_bf16(ops.cast_pad_bf16(x), ops.cast_pad_bf16(dz), gw, None, accumulate=False)
     want = dz[:K].to(BF).float() + dz[4096:4096 + K].to(BF).float()
     assert torch.equal(gw, want)
+
+
+GROUPS_128 = [
+    # BASELINE configs[1]'s two trunks, one gradient step (M = 30 720)
+    (30720, [(5, 64), (64, 64), (64, 64), (64, 64), (64, 2), (5, 256), (256, 256), (256, 1)]),
+    # configs[3]: GRU actor (projection and recurrent kernels 64 x 192) beside the 2 x 256 critic
+    (30720, [(5, 64), (64, 192), (64, 192), (64, 2), (5, 256), (256, 256), (256, 1)]),
+    # ragged widths, M = 32 * odd, a last split shorter than the others
+    (32 * 677, [(17, 136), (136, 72), (72, 12), (200, 8)]),
+    (96, [(24, 40), (40, 3)]),
+]
+
+
+@pytest.mark.parametrize("M,layers", GROUPS_128)
+def test_dw128_dma_kernel_equals_tile_kernel(dev, monkeypatch, M, layers):
+    """`tn128_kernel` (csrc/gemm256_bf16.hip): the grouped dW of a training-size step on
+    128 x 128 tiles staged by LDS-DMA — same tiles, same split plan, same k order as the
+    register-staged tile kernel of gemm_bf16.hip (`MIPPO_DW128_DMA=0`), so the weight and bias
+    gradients must come out bit for bit the same; and against fp64 on the same bf16 operands."""
+    from nnx_ppo_amd import ops
+
+    rng = np.random.default_rng(M + len(layers))
+    probs = []
+    for K, N in layers:
+        x = torch.as_tensor(rng.normal(size=(M, K)).astype(np.float32)).to(dev)
+        dz = torch.as_tensor(rng.normal(size=(M, N)).astype(np.float32)).to(dev)
+        probs.append((ops.cast_pad_bf16(x), ops.cast_pad_bf16(dz)))
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIPPO_DW128_DMA", flag)
+        grads = [(torch.zeros(K, N, device=dev), torch.zeros(N, device=dev)) for K, N in layers]
+        ops.dense_bwd_dw_grouped_bf16([(xb, zb, gw, gb) for (xb, zb), (gw, gb) in
+                                       zip(probs, grads)], accumulate=True)
+        ops.flush_pending_slabs()
+        res.append(grads)
+    for (gw1, gb1), (gw0, gb0), (xb, zb), (K, N) in zip(res[0], res[1], probs, layers):
+        assert torch.equal(gw1, gw0) and torch.equal(gb1, gb0), (K, N)
+        want = xb[:, :K].to(D).T @ zb[:, :N].to(D)
+        assert torch.allclose(gw1.to(D), want, rtol=1e-4, atol=1e-3 * math.sqrt(M)), (K, N)
+        assert torch.allclose(gb1.to(D), zb[:, :N].to(D).sum(0), rtol=1e-4,
+                              atol=1e-3 * math.sqrt(M)), (K, N)
