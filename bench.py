@@ -181,8 +181,14 @@ def roofline_of_dominant_kernel(env, ts):
                 add("dW group (tn_gemm_dw_all_kernel + reduce_slabs_grouped)",
                     t_ms, work)
         if name == "mi_dense_bwd_dw_grouped_slabs_bf16":
+            # csrc/gemm_bf16.hip dw_grouped_launch: at training sizes (M a multiple of 32) the
+            # group's tiles go through the DMA-staged 128 x 128 kernel of gemm256_bf16.hip
+            # (MIPPO_DW128_DMA=0: the register-staged tile kernel) — same tiles, same slabs
+            dma = os.environ.get("MIPPO_DW128_DMA", "1")[:1] != "0"
             for (ints, t_ms), work in zip(d["args"], d["work"]):
-                add("tn_gemm_dw_all_kernel (slabs reduced by adam_kernel)", t_ms, work)
+                M = next((v for v in ints if v >= 1024), 0)
+                kern = "tn128_kernel" if dma and M % 32 == 0 else "tn_gemm_dw_all_kernel"
+                add(f"{kern} (slabs reduced by adam_kernel)", t_ms, work)
         if name in GEMM_SYMBOLS:
             if GEMM_SYMBOLS[name] is None:
                 flops += d["flops"]
@@ -222,7 +228,7 @@ def roofline_of_dominant_kernel(env, ts):
     traffic_stale = sig_file != sig_now  # a file without a signature is stale by definition
     trunk = {k: v for k, v in classes.items()
              if k.startswith(("mlp_chain_kernel", "policy_kernel", "policy_bwd_kernel",
-                              "trunk_ws_", "policy_ws_", "tn_gemm_dw", "dW group"))}
+                              "trunk_ws_", "policy_ws_", "tn_gemm_dw", "tn128", "dW group"))}
     if trunk:
         # Dominant kernel = the dense class (trunk forward / backward, dW) with the most
         # device time.  Their arithmetic intensity (50-150 flop/B with the activations kept
