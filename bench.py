@@ -184,10 +184,12 @@ def roofline_of_dominant_kernel(env, ts):
             # csrc/gemm_bf16.hip dw_grouped_launch: at training sizes (M a multiple of 32) the
             # group's tiles go through the DMA-staged 128 x 128 kernel of gemm256_bf16.hip
             # (MIPPO_DW128_DMA=0: the register-staged tile kernel) — same tiles, same slabs
-            dma = os.environ.get("MIPPO_DW128_DMA", "1")[:1] != "0"
+            # (MIPPO_DW128_DMA=2 forces that kernel; by default it takes short splits of groups
+            # made mostly of full-width tiles — not the headline's two trunks, 7 of whose 13
+            # tiles are at most 64 columns wide)
+            forced = os.environ.get("MIPPO_DW128_DMA", "1")[:1] == "2"
             for (ints, t_ms), work in zip(d["args"], d["work"]):
-                M = next((v for v in ints if v >= 1024), 0)
-                kern = "tn128_kernel" if dma and M % 32 == 0 else "tn_gemm_dw_all_kernel"
+                kern = "tn128_kernel" if forced else "tn_gemm_dw_all_kernel"
                 add(f"{kern} (slabs reduced by adam_kernel)", t_ms, work)
         if name in GEMM_SYMBOLS:
             if GEMM_SYMBOLS[name] is None:

@@ -713,10 +713,20 @@ int dw256_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, c
 
 // The 128-tile form (tn128_kernel) for the rest of a group: M a multiple of 32, splits of whole
 // slots; MIPPO_DW128_DMA=0 keeps the register-staged tile kernel (A/B, bit-identity tests).
-bool dw128_takes(int64_t M, int64_t rows_per_split, int n) {
+bool dw128_takes(int64_t M, int64_t rows_per_split, int n, int64_t wide_tiles, int64_t tiles) {
   const char* e = getenv("MIPPO_DW128_DMA");  // read per launch: the tests switch it
   const bool enabled = !(e && e[0] == '0');
-  return enabled && n >= 1 && n <= kMaxDw256 && M >= KB && M % KB == 0 && rows_per_split % KB == 0;
+  // short splits only: the pipeline's prologue and epilogue are cheaper than the register-staged
+  // kernel's, its steady state (a barrier per 32 rows) is not — at 960 rows per workgroup the
+  // launches tie (C2) or this one wins (C4: +2.6 % of the iteration), at 3 840 rows (N = 16 384)
+  // the tile kernel is 11 % of the iteration ahead.  MIPPO_DW128_DMA=2 forces it for any length.
+  // ... and groups made mostly of full-width tiles: every tile costs this kernel a 128 x 128
+  // tile's work, while the tile kernel walks outputs of at most 64 / 16 columns on cheaper
+  // classes (C2: 7 of 13 tiles are such: the tile kernel is 0.8 us ahead; C4: 4 of 14)
+  const bool any_len = e && e[0] == '2';
+  return enabled && n >= 1 && n <= kMaxDw256 && M >= KB && M % KB == 0 &&
+         rows_per_split % KB == 0 &&
+         (any_len || (rows_per_split <= 1024 && 2 * wide_tiles > tiles));
 }
 
 int dw128_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, const int64_t* K,

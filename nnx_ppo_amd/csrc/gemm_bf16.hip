@@ -878,8 +878,13 @@ static int dw_grouped_launch(const char* who, int64_t n, const void* const* x_bf
     // the same tiles and splits through the DMA-staged 128 x 128 kernel (gemm256_bf16.hip:
     // tn128_kernel) when the rows come in whole 32-row slots: bit-identical slabs
     int n_rest = 0;
-    for (int64_t l = 0; l < n; ++l) n_rest += !big[l];
-    if (mippo_gemm::dw128_takes(M, rows, n_rest)) {
+    int64_t wide = 0;  // tiles of outputs wider than 64 columns
+    for (int64_t l = 0; l < n; ++l) {
+      if (big[l]) continue;
+      ++n_rest;
+      if (N[l] > 64) wide += dw_tiles(K[l], N[l]);
+    }
+    if (mippo_gemm::dw128_takes(M, rows, n_rest, wide, tiles_all)) {
       const bf16_t* xa[kMaxDwProblems];
       const bf16_t* za[kMaxDwProblems];
       float* sl[kMaxDwProblems];

@@ -37,7 +37,7 @@ int64_t dw256_tiles(int64_t K, int64_t N);
 int dw256_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, const int64_t* K,
                  const int64_t* N, int64_t M, float* const* slabs, int64_t rows, int64_t S,
                  hipStream_t st);
-bool dw128_takes(int64_t M, int64_t rows_per_split, int n);
+bool dw128_takes(int64_t M, int64_t rows_per_split, int n, int64_t wide_tiles, int64_t tiles);
 int dw128_launch(int n, const bf16_t* const* x_bf, const bf16_t* const* dz_bf, const int64_t* K,
                  const int64_t* N, int64_t M, float* const* slabs, int64_t rows, int64_t S,
                  hipStream_t st);

@@ -174,7 +174,7 @@ def test_dw128_dma_kernel_equals_tile_kernel(dev, monkeypatch, M, layers):
         dz = torch.as_tensor(rng.normal(size=(M, N)).astype(np.float32)).to(dev)
         probs.append((ops.cast_pad_bf16(x), ops.cast_pad_bf16(dz)))
     res = []
-    for flag in ("1", "0"):
+    for flag in ("2", "0"):  # 2: the DMA-staged kernel whatever the split length
         monkeypatch.setenv("MIPPO_DW128_DMA", flag)
         grads = [(torch.zeros(K, N, device=dev), torch.zeros(N, device=dev)) for K, N in layers]
         ops.dense_bwd_dw_grouped_bf16([(xb, zb, gw, gb) for (xb, zb), (gw, gb) in
