@@ -230,20 +230,24 @@ struct GatherTable {
   GatherLeaf leaf[kMaxSelectLeaves];
 };
 
+// IT = the integer type of the element index arithmetic: uint32_t whenever every leaf has
+// fewer than 2^32 elements (always, at the reference's sizes) — four 64-bit divisions per
+// element were most of this kernel's time (25 us for 5 M elements at C2)
+template <typename IT>
 __global__ void __launch_bounds__(kThreads)
 gather_cols_multi_kernel(GatherTable tab, const int64_t* __restrict__ idx, int64_t N, int64_t L,
                          int64_t GL) {
   const GatherLeaf lf = tab.leaf[blockIdx.y];
-  const int64_t total = lf.T * L * lf.words;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * kThreads) {
-    const int64_t w = i % lf.words;
-    const int64_t j = (i / lf.words) % L;
-    const int64_t t = i / (lf.words * L);
-    const int64_t s = (t * N + idx[j]) * lf.words + w;
+  const IT words = (IT)lf.words, Ls = (IT)L, GLs = (IT)GL;
+  const IT total = (IT)(lf.T * L * lf.words);
+  const IT stride = (IT)gridDim.x * kThreads;
+  for (IT i = (IT)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+    const IT row = i / words, w = i - row * words;
+    const IT t = row / Ls, j = row - t * Ls;
+    const int64_t s = ((int64_t)t * N + idx[j]) * lf.words + w;
     // group g = j / GL is a contiguous [T][GL][row] block of the output
-    const int64_t g = j / GL, jj = j - g * GL;
-    const int64_t d = ((g * lf.T + t) * GL + jj) * lf.words + w;
+    const IT g = j / GLs, jj = j - g * GLs;
+    const int64_t d = (((int64_t)g * lf.T + t) * GL + jj) * lf.words + w;
     if (lf.word_bytes == 4)
       static_cast<uint32_t*>(lf.dst)[d] = static_cast<const uint32_t*>(lf.src)[s];
     else
@@ -364,8 +368,13 @@ extern "C" int mi_gather_cols_multi(const void* const* src, void* const* dst, co
     if (tot > max_total) max_total = tot;
   }
   dim3 grid((unsigned)stream_grid(max_total), (unsigned)n_leaves);
-  hipLaunchKernelGGL(gather_cols_multi_kernel, grid, dim3(kThreads), 0, mippo::as_stream(stream),
-                     tab, idx, N, L, group_len);
+  // (the grid-stride loop's `i += stride` must not wrap: leave room for one stride)
+  if (max_total < (1LL << 32) - (int64_t)grid.x * kThreads)
+    hipLaunchKernelGGL(gather_cols_multi_kernel<uint32_t>, grid, dim3(kThreads), 0,
+                       mippo::as_stream(stream), tab, idx, N, L, group_len);
+  else
+    hipLaunchKernelGGL(gather_cols_multi_kernel<uint64_t>, grid, dim3(kThreads), 0,
+                       mippo::as_stream(stream), tab, idx, N, L, group_len);
   return mippo::check_launch("mi_gather_cols_multi");
 }
 
