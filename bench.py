@@ -643,6 +643,16 @@ def main():
     _log("warm-up done")
     # size the repetition count from one untimed window
     est = run_window(args.steps)
+    if world > 1:
+        # every rank must run the SAME number of windows (each window holds two barriers): the
+        # count comes from the slowest rank's estimate, not from each rank's own clock
+        import torch.distributed as dist
+
+        et = torch.tensor([est], dtype=torch.float64, device=device)
+        if backend != "nccl":
+            et = et.cpu()
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        est = float(et.cpu()[0])
     reps = max(1, min(200, int(args.min_timed_seconds / max(est, 1e-6)) + 1))
     _log(f"one window of {args.steps} iterations = {est * 1e3:.1f} ms; timing {reps} windows")
     windows, iter_ms = [], []
